@@ -1,0 +1,278 @@
+/*
+ * peneo_hip.h — C ABI of libpeneo_hip.so, the MI355X (gfx950) device library behind the
+ * PEneo forward/backward hot path.
+ *
+ * The upstream reference (ZeningLin/PEneo) is pure Python; it has no FFI.  The boundary a
+ * maintainer swaps is the nn.Module contract of model/modeling_peneo.py:108-175 and
+ * model/peneo_decoder.py:338-443.  Each entry point below names the reference code whose
+ * device work it replaces.  INTEGRATION.md shows the ctypes stub that binds them.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - sizes are explicit; no hidden allocation: workspaces are passed in by the caller;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it;
+ *   - return 0 on success, a negative PENEO_ERR_* otherwise; peneo_last_error() gives the
+ *     (thread-local) message;
+ *   - "dtype" selects the storage type of activations/weights: PENEO_BF16 (MFMA bf16 inputs,
+ *     fp32 accumulate; the throughput mode) or PENEO_F32 (exact fp32 MFMA; the parity mode).
+ *     Gradients of parameters, losses, logits, LayerNorm statistics and softmax
+ *     log-sum-exps are always fp32.
+ */
+#ifndef PENEO_HIP_H
+#define PENEO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PENEO_OK 0
+#define PENEO_ERR_INVALID (-1)
+#define PENEO_ERR_LAUNCH (-2)
+
+#define PENEO_F32 0
+#define PENEO_BF16 1
+
+#define PENEO_ACT_NONE 0
+#define PENEO_ACT_GELU 1 /* exact erf GELU (transformers RobertaIntermediate) */
+#define PENEO_ACT_SILU 2 /* nn.SiLU (model/peneo_decoder.py:217,220,235) */
+
+#define PENEO_MAX_HEADS 8 /* pair-classifier heads (the reference has 5) */
+
+typedef void* peneo_stream_t;
+
+int peneo_version(void);
+const char* peneo_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction:  C[m,n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+ *   a_kmajor != 0 : A is [M, K] row-major (leading dim lda >= K)   else A is [K, M] (lda >= M)
+ *   b_kmajor != 0 : B is [N, K] row-major (ldb >= K)               else B is [K, N] (ldb >= N)
+ * so  forward  y = x W^T      -> (a_kmajor=1, b_kmajor=1)            [nn.Linear everywhere]
+ *     dgrad    dx = dy W      -> (1, 0)
+ *     wgrad    dW = dy^T x    -> (0, 0)
+ * Epilogue order:  v = alpha*acc (+bias[n]) ; preact <- v ; v = act(v) ; v *= act'(grad_src[m,n]) ;
+ *                  dropout ; v += residual[m,n] ; v += C[m,n] if accumulate ; C <- v
+ * Replaces torch.nn.Linear / F.linear call sites: modeling_layoutlmv3.py:292-294,335-360,
+ * RobertaSelfOutput/Intermediate/Output, peneo_decoder.py:126,213-222 and their autograd.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct peneo_gemm_epilogue {
+  const float* bias;        /* [N] fp32 or NULL */
+  int act;                  /* PENEO_ACT_* applied after bias */
+  void* preact;             /* optional [M, ld_preact] (dtype c_dtype): value before act */
+  int64_t ld_preact;
+  const void* grad_src;     /* optional [M, ld_grad] (dtype c_dtype): multiply by act'(grad_src) */
+  int64_t ld_grad;
+  int grad_act;             /* which act' */
+  const void* residual;     /* optional [M, ld_res] (dtype c_dtype) added last */
+  int64_t ld_res;
+  float alpha;              /* 0 is read as 1 */
+  int accumulate;           /* C += result (c_dtype must be PENEO_F32) */
+  float drop_p;             /* dropout probability (0 = off); keep mask = f(drop_seed, m*N+n) */
+  uint32_t drop_seed;
+} peneo_gemm_epilogue;
+
+size_t peneo_gemm_workspace_bytes(int M, int N, int K, int split_k);
+int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, int K,
+               const void* A, int64_t lda, const void* B, int64_t ldb,
+               void* C, int64_t ldc, int c_dtype, const peneo_gemm_epilogue* ep,
+               int split_k, void* workspace, size_t workspace_bytes, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise plumbing
+ * ------------------------------------------------------------------------------------------ */
+int peneo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, peneo_stream_t stream);
+/* dst[r, c] = src[r, c] for a strided 2-D block (row strides in elements), with optional dropout */
+int peneo_copy2d(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                 float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+/* out[n] (+)= sum_m x[m, n]   (bias gradients) */
+int peneo_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,
+                 peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (modeling_layoutlmv3.py:225,930,1113; Roberta*Output.LayerNorm).
+ * Row r of the logical [rows, H] matrix lives at  (r / rpb) * bstride + (r % rpb) * H  elements
+ * (rpb = 0 means contiguous), separately for input and output, so that sub-ranges of a
+ * [B, T, H] buffer can be normalised in place.
+ * ------------------------------------------------------------------------------------------ */
+int peneo_layernorm_fwd(int dtype, const void* x, int64_t x_rpb, int64_t x_bstride,
+                        void* y, int64_t y_rpb, int64_t y_bstride,
+                        const float* gamma, const float* beta, float eps,
+                        float* mean, float* rstd, int64_t rows, int H,
+                        float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+/* dx may alias dy.  dgamma/dbeta (fp32, [H]) are accumulated into. */
+int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bstride,
+                        const void* x, int64_t x_rpb, int64_t x_bstride,
+                        void* dx, int64_t dx_rpb, int64_t dx_bstride,
+                        const float* gamma, const float* mean, const float* rstd,
+                        float* dgamma, float* dbeta, int64_t rows, int H,
+                        float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1 — text embeddings (modeling_layoutlmv3.py:131-227, modeling_lilt.py:75-130,160-210)
+ * ------------------------------------------------------------------------------------------ */
+/* RoBERTa position ids: cumsum(ids != pad) * (ids != pad) + pad   (:164-181) */
+int peneo_position_ids(const int64_t* input_ids, int B, int S, int64_t pad_id, int32_t* pos_ids,
+                       peneo_stream_t stream);
+/* out[b,s,:] = word[ids] + type0 + pos[pid] (+ cat(x[l],y[t],x[r],y[b],h[b-t],w[r-l]) if spatial) ;
+ * returns PENEO_ERR_INVALID through `status` (device int, may be NULL) when a coordinate is outside
+ * [0, max_2d) — the reference raises IndexError (:133,138-141).
+ * clip_hw != 0 clips the h/w lookups to [0, max_2d-1] (LayoutLMv3); LiLT does not clip.         */
+typedef struct peneo_embed_tables {
+  const float* word;   /* [vocab, H] */
+  const float* type0;  /* [H] row 0 of token_type_embeddings */
+  const float* pos;    /* [max_pos, H] */
+  const float* x; const float* y; const float* h; const float* w; /* [max_2d, coord|shape]; NULL = no spatial part */
+  int coord_size; int shape_size; int max_2d; int vocab; int max_pos;
+} peneo_embed_tables;
+int peneo_embed_text_fwd(int dtype, const int64_t* input_ids, const int32_t* pos_ids, const int64_t* bbox,
+                         const peneo_embed_tables* tab, int B, int S, int H, int clip_hw,
+                         void* out, int64_t out_rpb, int64_t out_bstride, int32_t* status, peneo_stream_t stream);
+/* scatter-add of d_out into fp32 table gradients (dense, like nn.Embedding(sparse=False));
+ * rows equal to pad_id are skipped for word/pos (padding_idx semantics). */
+typedef struct peneo_embed_grads {
+  float* word; float* type0; float* pos; float* x; float* y; float* h; float* w;
+} peneo_embed_grads;
+int peneo_embed_text_bwd(int dtype, const void* d_out, int64_t rpb, int64_t bstride,
+                         const int64_t* input_ids, const int32_t* pos_ids, const int64_t* bbox,
+                         const peneo_embed_grads* g, int coord_size, int shape_size, int max_2d,
+                         int B, int S, int H, int clip_hw, int64_t pad_id, peneo_stream_t stream);
+/* spatial-only embedding for LiLT: out[b,s,:] = cat(x[l],y[t],x[r],y[b],h[b-t],w[r-l]) */
+
+/* ------------------------------------------------------------------------------------------
+ * K2 — patch embedding (modeling_layoutlmv3.py:51-84, 910-931)
+ * ------------------------------------------------------------------------------------------ */
+/* image [B, C, Hi, Wi] fp32 -> patches [B * (Hi/16) * (Wi/16), C*256] (k = c*256 + py*16 + px) */
+int peneo_im2col_patch16(int dtype, const float* image, int B, int C, int Hi, int Wi, void* patches,
+                         peneo_stream_t stream);
+/* vis[b,0,:] = cls + pos[0]; vis[b,1+p,:] = proj[b*np+p,:] + pos[1+p]  */
+int peneo_visual_assemble_fwd(int dtype, const void* proj, const float* cls, const float* pos, int B, int np, int H,
+                              void* vis, peneo_stream_t stream);
+/* d_proj <- d_vis[:,1:]; d_cls += sum_b d_vis[b,0]; d_pos += sum_b d_vis[b] */
+int peneo_visual_assemble_bwd(int dtype, const void* d_vis, int B, int np, int H, void* d_proj, float* d_cls,
+                              float* d_pos, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4 — relative-position bias (modeling_layoutlmv3.py:586-676), computed once per forward.
+ * lut[|delta|] holds the *unsigned* part of relative_position_bucket (the host fills it with
+ * the reference's own fp32 formula so bucket indices are bit-exact); the sign adds nb/2.
+ * ------------------------------------------------------------------------------------------ */
+int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const int32_t* ys, int B, int T,
+                         const uint8_t* lut1, int lut1_len, int half1,
+                         const uint8_t* lut2, int lut2_len, int half2,
+                         uint8_t* bk1, uint8_t* bkx, uint8_t* bky, peneo_stream_t stream);
+/* bias[b,h,i,j] = scale * (w1[h,bk1] + wx[h,bkx] + wy[h,bky]); any of the three may be NULL */
+int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
+                          const float* w1, int bins1, const float* wx, const float* wy, int bins2,
+                          float scale, int B, int nh, int T, void* bias, peneo_stream_t stream);
+/* dw*[h,bin] += scale * sum_{b,i,j in bin} g[b,h,i,j]  */
+int peneo_relpos_bias_bwd(const float* g, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
+                          float* dw1, int bins1, float* dwx, float* dwy, int bins2,
+                          float scale, int B, int nh, int T, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6 — attention core (modeling_layoutlmv3.py:365-404; the "cogview" softmax :308-321 is exactly
+ * softmax).  q/k/v are rows of a [B*T, ld] matrix, head h at columns h*d..; scores =
+ * scale * q.k + bias[b,h,i,j] ; keys with key_mask[b,j] == 0 get probability 0.
+ * `lse` [B, nh, T] fp32 is the log-sum-exp per query row (saved for backward).
+ * ------------------------------------------------------------------------------------------ */
+int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv,
+                   int B, int nh, int T, int d, float scale, const void* bias, const int32_t* key_mask,
+                   void* out, int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed,
+                   peneo_stream_t stream);
+/* dq/dk/dv share the q/k/v layout (ld_dqkv).  g_bias (fp32 [B,nh,T,T], may be NULL) is
+ * accumulated with dS so the bias-table gradient can be reduced once per step.
+ * `delta` is a [B, nh, T] fp32 scratch. */
+int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv,
+                   const void* out, const void* d_out, int64_t ld_out, const float* lse,
+                   int B, int nh, int T, int d, float scale, const void* bias, const int32_t* key_mask,
+                   void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
+                   float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11 + K12 (+ K13) — handshaking + the pair-classifier heads + class-weighted CE, fused
+ * (model/peneo_decoder.py:149-177, 231-292, 315-336, 355-428; model/custom_loss.py:189-202).
+ *
+ * ab [B, N, 2D]: a_i = W_c[:, :D] h_i  (cols 0..D) and b_j = W_c[:, D:] h_j + bias_c (cols D..2D),
+ * so that  combine_fc(cat(h_i, h_j)) = a_i + b_j.  For every packed upper-triangular pair
+ * p(i,j) = i*N - i(i-1)/2 + (j-i):  x = SiLU(a_i + b_j);  per head: SiLU(W1_h x + b1_h) -> W2_h . + b2_h.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct peneo_pair_heads_desc {
+  int num_heads;                       /* <= PENEO_MAX_HEADS */
+  int D;                               /* decoder hidden size (multiple of 32) */
+  int classes[PENEO_MAX_HEADS];        /* 2,3,3,3,3 */
+  const void* w1_packed;               /* from peneo_pair_heads_pack_w1 */
+  const float* b1;                     /* [num_heads * D] */
+  const void* w2_packed;               /* from peneo_pair_heads_pack_w2 */
+  const float* b2;                     /* [sum classes] */
+} peneo_pair_heads_desc;
+
+size_t peneo_pair_heads_w1_packed_bytes(int dtype, int num_heads, int D);
+size_t peneo_pair_heads_w2_packed_bytes(int dtype, int num_heads, int D);
+/* w1[h] : [D, D] row-major fp32 (nn.Linear weight), w2[h] : [classes[h], D] fp32 */
+/* w1 / w2 / classes are HOST arrays (of device pointers / ints) with num_heads entries */
+int peneo_pair_heads_pack_w1(int dtype, const float* const* w1, int num_heads, int D, void* packed,
+                             peneo_stream_t stream);
+int peneo_pair_heads_pack_w2(int dtype, const float* const* w2, const int* classes, int num_heads,
+                             int D, void* packed, peneo_stream_t stream);
+
+typedef struct peneo_pair_loss {
+  const int64_t* tags[PENEO_MAX_HEADS];   /* [B, P] label maps (data/collator.py:170-204); NULL = no loss */
+  const float* class_weight[PENEO_MAX_HEADS]; /* [classes[h]] fp32 device */
+  float* loss_num;                        /* [num_heads] sum_p w[tag] * nll   (accumulated, zero it first) */
+  float* loss_den;                        /* [num_heads] sum_p w[tag]         (accumulated, zero it first) */
+  float* dlogits[PENEO_MAX_HEADS];        /* optional [B, P, classes[h]] fp32: w[tag] * (softmax - onehot) (unnormalised) */
+  float* dl_sum;                          /* optional [sum classes] sum_p dlogits (accumulated): the second-layer bias gradient */
+} peneo_pair_loss;
+
+/* logits[h] : [B, P, classes[h]] fp32, contiguous, P = N (N + 1) / 2 (may be NULL when only the loss is wanted) */
+int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
+                         float* const* logits /* host array of num_heads device pointers, or NULL */,
+                         const peneo_pair_loss* loss, peneo_stream_t stream);
+
+/* --- building blocks of the chunked backward (rows i0..i1 of the pair triangle = pairs
+ *     p(i0,i0) .. p(i1,i1)-1 of one document) ------------------------------------------- */
+/* x[p - p0, :] = SiLU(a_i + b_j)                         [npairs, D]  */
+int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, void* x, peneo_stream_t stream);
+/* du = dx * SiLU'(a_i + b_j);  d_ab_doc[i, :D] += sum_j du ; d_ab_doc[j, D:] += sum_i du   (fp32 [N, 2D]) */
+int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* dx, float* d_ab_doc,
+                     peneo_stream_t stream);
+/* For the [npairs, nh*D] pre-activations z of all heads' first layers:
+ *   y = SiLU(z);  dy[p, h*D+k] = sum_c dlogits_h[p, c] * w2_h[c, k];  dz = dy * SiLU'(z)  (written over z)
+ *   dw2_h[c, k] += sum_p dlogits_h[p,c] * y[p, h*D+k];   db1[h*D+k] += sum_p dz
+ * dlogits scale[h] (= loss_ratio_h / den_h) is applied on the fly. */
+typedef struct peneo_pair_dz_args {
+  int num_heads; int D; int classes[PENEO_MAX_HEADS];
+  const float* dlogits[PENEO_MAX_HEADS];  /* [npairs, classes[h]] (already offset to the chunk) */
+  const float* w2[PENEO_MAX_HEADS];       /* [classes[h], D] fp32 */
+  float* dw2[PENEO_MAX_HEADS];            /* [classes[h], D] fp32, accumulated */
+  float* db1;                             /* [num_heads * D] fp32, accumulated */
+  const float* scale;                     /* [num_heads] device fp32 */
+} peneo_pair_dz_args;
+int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K13 helpers — loss finish:  loss_h = num_h / den_h ; total = sum_h ratio_h * loss_h ;
+ * scale_h = ratio_h / den_h (the factor the backward applies to dlogits).
+ * out: [num_heads + 1] = per-head losses then the total.
+ * ------------------------------------------------------------------------------------------ */
+int peneo_loss_finish(const float* num, const float* den, const float* ratio, int num_heads, float* out,
+                      float* scale, peneo_stream_t stream);
+/* stand-alone weighted CE on materialised logits [rows, C] (used by the unfused parity path) */
+int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* class_weight, int64_t rows, int C,
+                      float* num, float* den, float* dlogits, peneo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K14 — decode front end (model/peneo_decoder.py:98-114): softmax -> argmax/max -> compaction of
+ * the non-zero tags of one [P, C] map into (i, j, tag, score) spots in increasing p order.
+ * count: device int (number found, may exceed max_spots; only max_spots are stored).
+ * ------------------------------------------------------------------------------------------ */
+int peneo_spots_compact(const float* logits, int64_t P, int C, int N, int32_t* spots_ijt, float* scores,
+                        int32_t* count, int max_spots, peneo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PENEO_HIP_H */

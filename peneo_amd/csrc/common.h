@@ -1,0 +1,171 @@
+// Shared device helpers for the peneo_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/peneo_hip.h"
+
+namespace peneo {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------- error plumbing (host)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PENEO_REQUIRE(cond, ...)                \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::peneo::set_error(__VA_ARGS__);          \
+      return PENEO_ERR_INVALID;                 \
+    }                                           \
+  } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kVec = 4;  // elements per 16-byte vector
+  static constexpr int kDtype = PENEO_F32;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kVec = 8;
+  static constexpr int kDtype = PENEO_BF16;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// 16-byte vector <-> floats
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y);
+  out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+  out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+  out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
+  out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
+  return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
+  return make_uint4(pack_bf16x2(in[0], in[1]), pack_bf16x2(in[2], in[3]), pack_bf16x2(in[4], in[5]),
+                    pack_bf16x2(in[6], in[7]));
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_f(int act, float x) {
+  return act == PENEO_ACT_GELU ? gelu_f(x) : (act == PENEO_ACT_SILU ? silu_f(x) : x);
+}
+__device__ __forceinline__ float act_grad_f(int act, float x) {
+  return act == PENEO_ACT_GELU ? gelu_grad_f(x) : (act == PENEO_ACT_SILU ? silu_grad_f(x) : 1.0f);
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(seed, idx) is a pure function, so backward kernels regenerate the forward mask.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint32_t seed, uint64_t idx, uint32_t thresh /* p * 2^32 */) {
+  uint32_t h = mix32((uint32_t)idx ^ mix32(seed ^ (uint32_t)(idx >> 32) * 0x9e3779b9u));
+  return h >= thresh;
+}
+
+// ---------------------------------------------------------------- MFMA wrappers
+// One "k-step" covers 16 reduction elements: lanes 0-31 hold k 0..7, lanes 32-63 hold k 8..15 of the step,
+// for row/col (lane & 31).  For bf16 that is one v_mfma_f32_32x32x16_bf16; for fp32 eight
+// v_mfma_f32_32x32x2_f32 (exact fp32, element t of each lane pairs k=t with k=8+t).
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { uint4 v; };
+template <> struct Frag<float> { uint4 v[2]; };
+
+__device__ __forceinline__ void mma_step(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x16_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v),
+                                                acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_step(const Frag<float>& a, const Frag<float>& b, f32x16_t& acc) {
+  const uint32_t* pa = reinterpret_cast<const uint32_t*>(&a.v[0]);
+  const uint32_t* pb = reinterpret_cast<const uint32_t*>(&b.v[0]);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(pa[t]), __uint_as_float(pb[t]), acc, 0, 0, 0);
+}
+
+// 8 floats -> one MFMA fragment (bf16: rounded to nearest-even; fp32: verbatim)
+template <typename T> __device__ __forceinline__ Frag<T> pack_frag8(const float* v);
+template <> __device__ __forceinline__ Frag<bf16_t> pack_frag8<bf16_t>(const float* v) {
+  Frag<bf16_t> f; f.v = pack16<bf16_t>(v); return f;
+}
+template <> __device__ __forceinline__ Frag<float> pack_frag8<float>(const float* v) {
+  Frag<float> f; f.v[0] = pack16<float>(v); f.v[1] = pack16<float>(v + 4); return f;
+}
+
+// accumulator element r of lane l of a 32x32 tile sits at (row, col):
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
+
+// ---------------------------------------------------------------- packed upper-triangular pair index
+// p(i, j) = i*n - i(i-1)/2 + (j - i),  0 <= i <= j < n   (reference: model/peneo_decoder.py:129-147)
+__device__ __host__ __forceinline__ int64_t pair_row_start(int64_t i, int64_t n) { return i * n - i * (i - 1) / 2; }
+__device__ __forceinline__ void pair_decode(int64_t p, int n, int& i, int& j) {
+  // largest i with row_start(i) <= p
+  double nn = 2.0 * n + 1.0;
+  int ii = (int)((nn - sqrt(nn * nn - 8.0 * (double)p)) * 0.5);
+  if (ii < 0) ii = 0;
+  if (ii > n - 1) ii = n - 1;
+  while (ii > 0 && pair_row_start(ii, n) > p) --ii;
+  while (ii < n - 1 && pair_row_start(ii + 1, n) <= p) ++ii;
+  i = ii;
+  j = ii + (int)(p - pair_row_start(ii, n));
+}
+
+}  // namespace peneo

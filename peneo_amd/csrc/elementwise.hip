@@ -1,0 +1,109 @@
+// Memory-bound plumbing kernels: dtype casts, strided 2-D copy (+dropout), column sums.
+#include "common.h"
+
+namespace peneo {
+
+__device__ __forceinline__ float ld_any(const void* p, int dt, int64_t i) {
+  return dt == PENEO_F32 ? reinterpret_cast<const float*>(p)[i] : bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+__device__ __forceinline__ void st_any(void* p, int dt, int64_t i, float v) {
+  if (dt == PENEO_F32) reinterpret_cast<float*>(p)[i] = v; else reinterpret_cast<bf16_t*>(p)[i] = f32_to_bf16(v);
+}
+
+// 8 elements per thread: 16/32-byte vector traffic per lane
+__global__ void cast_kernel(const void* src, int sdt, void* dst, int ddt, int64_t n) {
+  int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (; base < n; base += stride) {
+    if (base + 8 <= n) {
+      float f[8];
+      if (sdt == PENEO_F32) {
+        const uint4* s = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(src) + base);
+        unpack16<float>(s[0], f); unpack16<float>(s[1], f + 4);
+      } else {
+        unpack16<bf16_t>(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(src) + base), f);
+      }
+      if (ddt == PENEO_F32) {
+        uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<float*>(dst) + base);
+        d[0] = pack16<float>(f); d[1] = pack16<float>(f + 4);
+      } else {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + base) = pack16<bf16_t>(f);
+      }
+    } else {
+      for (int64_t i = base; i < n; ++i) st_any(dst, ddt, i, ld_any(src, sdt, i));
+    }
+  }
+}
+
+__global__ void copy2d_kernel(int dt, const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols,
+                              float drop_p, uint32_t seed) {
+  const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / cols, c = i % cols;
+    float v = ld_any(src, dt, r * lds_ + c);
+    if (drop_p > 0.f) v = dropout_keep(seed, (uint64_t)i, thresh) ? v * keep_scale : 0.f;
+    st_any(dst, dt, r * ldd + c, v);
+  }
+}
+
+// block = 64 columns x 4 row lanes; each block reduces ROWS_PER_BLOCK rows and adds into out.
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(int dt, const void* x, int64_t ldx, int64_t M, int64_t N, float* out) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + cl;
+  const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
+  const int64_t m1 = min(M, m0 + (int64_t)CS_ROWS);
+  float s = 0.f;
+  if (n < N)
+    for (int64_t m = m0 + rl; m < m1; m += 4) s += ld_any(x, dt, m * ldx + n);
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) atomicAdd(out + n, part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
+}
+
+}  // namespace peneo
+using namespace peneo;
+
+static inline bool ok_dt(int d) { return d == PENEO_F32 || d == PENEO_BF16; }
+
+extern "C" int peneo_cast(const void* src, int sdt, void* dst, int ddt, int64_t n, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(sdt) && ok_dt(ddt), "peneo_cast: bad dtype");
+  if (n <= 0) return PENEO_OK;
+  PENEO_REQUIRE(src && dst, "peneo_cast: null pointer");
+  PENEO_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+                "peneo_cast: pointers must be 16-byte aligned");
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, sdt, dst, ddt, n);
+  return check_launch("peneo_cast");
+}
+
+extern "C" int peneo_copy2d(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows,
+                            int64_t cols, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype), "peneo_copy2d: bad dtype");
+  if (rows <= 0 || cols <= 0) return PENEO_OK;
+  PENEO_REQUIRE(src && dst && ld_src >= cols && ld_dst >= cols, "peneo_copy2d: bad arguments");
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_copy2d: drop_p out of range");
+  int64_t blocks = (rows * cols + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dtype, src, ld_src, dst,
+                     ld_dst, rows, cols, drop_p, drop_seed);
+  return check_launch("peneo_copy2d");
+}
+
+extern "C" int peneo_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,
+                            peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype), "peneo_colsum: bad dtype");
+  PENEO_REQUIRE(x && out && M > 0 && N > 0 && ldx >= N, "peneo_colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) { set_error("peneo_colsum: memset failed"); return PENEO_ERR_LAUNCH; }
+  }
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + CS_ROWS - 1) / CS_ROWS));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, dtype, x, ldx, M, N, out);
+  return check_launch("peneo_colsum");
+}

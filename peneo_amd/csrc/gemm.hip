@@ -1,0 +1,308 @@
+// Dense contraction for gfx950: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, each
+// wave a 64x64 sub-tile = 2x2 MFMA 32x32 accumulators), k-tiles of 128 bytes per row staged
+// global -> registers -> LDS (XOR-swizzled 16-byte slots, conflict-free ds_read_b128), double
+// buffered with one barrier per k-tile.  Operands may be k-major or mn-major in memory
+// (mn-major tiles are transposed in registers on their way to LDS), which gives forward
+// (x W^T), dgrad (dy W) and wgrad (dy^T x) from one template.  bf16 -> v_mfma_f32_32x32x16_bf16,
+// fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32; the parity mode).
+#include "common.h"
+
+namespace peneo {
+
+constexpr int GB = 128;        // tile edge (both M and N)
+constexpr int ROWB = 128;      // bytes per LDS row (8 slots of 16 B)
+constexpr int TILE_BYTES = GB * ROWB;
+
+struct GemmParams {
+  const void* A; const void* B; void* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int c_dtype;
+  peneo_gemm_epilogue ep;
+  int split_k;        // >1: write raw fp32 partials to `ws` [split][M][N]
+  float* ws;
+  int kt_per_split;   // k-tiles per split
+};
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+// ---- global -> register staging ---------------------------------------------------------------
+template <typename T> struct Stage { uint4 v[4]; };
+
+template <typename T>
+__device__ __forceinline__ uint4 guarded_vec_load(const T* base, int64_t ld, int r, int c, int rmax, int cmax) {
+  // 16-byte vector at (r, c..c+VEC) of a row-major matrix; zero outside [rmax, cmax)
+  constexpr int VEC = Elem<T>::kVec;
+  uint4 z = make_uint4(0, 0, 0, 0);
+  if (r >= rmax || c >= cmax) return z;
+  const T* p = base + (int64_t)r * ld + c;
+  if (c + VEC <= cmax && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) return *reinterpret_cast<const uint4*>(p);
+  float f[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) f[e] = (c + e < cmax) ? Elem<T>::load(p + e) : 0.f;
+  return pack16<T>(f);
+}
+
+// k-major operand: matrix [rows, K]; tile rows r0.., k from k0..; thread t owns vectors t + 256*i
+template <typename T>
+__device__ __forceinline__ void load_kmajor(Stage<T>& s, const T* base, int64_t ld, int r0, int k0, int rmax, int kmax,
+                                            int tid) {
+  constexpr int VEC = Elem<T>::kVec;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int v = tid + 256 * i;
+    int row = v >> 3, slot = v & 7;
+    s.v[i] = guarded_vec_load<T>(base, ld, r0 + row, k0 + slot * VEC, rmax, kmax);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_kmajor(const Stage<T>& s, char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int v = tid + 256 * i;
+    int row = v >> 3, slot = v & 7;
+    *reinterpret_cast<uint4*>(tile + lds_off(row, slot)) = s.v[i];
+  }
+}
+
+// mn-major operand: matrix [K, rows] (rows contiguous).  Each thread loads 4 consecutive k-rows of one
+// 16-byte vector of tile-rows and writes them k-contiguous.
+template <typename T>
+__device__ __forceinline__ void load_mnmajor(Stage<T>& s, const T* base, int64_t ld, int r0, int k0, int rmax, int kmax,
+                                             int tid) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int MG = GB / VEC;  // vectors along the tile-row dim: 16 (bf16) / 32 (fp32)
+  int mg = tid % MG, kg = tid / MG;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s.v[i] = guarded_vec_load<T>(base, ld, k0 + kg * 4 + i, r0 + mg * VEC, kmax, rmax);
+}
+template <typename T> __device__ __forceinline__ void store_mnmajor(const Stage<T>& s, char* tile, int tid);
+template <>
+__device__ __forceinline__ void store_mnmajor<bf16_t>(const Stage<bf16_t>& s, char* tile, int tid) {
+  int mg = tid % 16, kg = tid / 16;  // kg: group of 4 k (8 bytes), 16 groups per 64-k tile
+  const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&s.v[0]);
+  const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&s.v[1]);
+  const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&s.v[2]);
+  const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&s.v[3]);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int sh = (e & 1) * 16;
+    uint32_t a = (w0[e >> 1] >> sh) & 0xffffu, b = (w1[e >> 1] >> sh) & 0xffffu;
+    uint32_t c = (w2[e >> 1] >> sh) & 0xffffu, d = (w3[e >> 1] >> sh) & 0xffffu;
+    int row = mg * 8 + e;
+    *reinterpret_cast<uint2*>(tile + lds_off(row, kg >> 1) + (kg & 1) * 8) = make_uint2(a | (b << 16), c | (d << 16));
+  }
+}
+template <>
+__device__ __forceinline__ void store_mnmajor<float>(const Stage<float>& s, char* tile, int tid) {
+  int mg = tid % 32, kg = tid / 32;  // kg: group of 4 k (16 bytes), 8 groups per 32-k tile
+  const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&s.v[0]);
+  const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&s.v[1]);
+  const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&s.v[2]);
+  const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&s.v[3]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int row = mg * 4 + e;
+    *reinterpret_cast<uint4*>(tile + lds_off(row, kg)) = make_uint4(w0[e], w1[e], w2[e], w3[e]);
+  }
+}
+
+// ---- LDS -> MFMA fragments -------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ Frag<T> read_frag(const char* tile, int row, int ks, int lane);
+template <>
+__device__ __forceinline__ Frag<bf16_t> read_frag<bf16_t>(const char* tile, int row, int ks, int lane) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const uint4*>(tile + lds_off(row, 2 * ks + (lane >> 5)));
+  return f;
+}
+template <>
+__device__ __forceinline__ Frag<float> read_frag<float>(const char* tile, int row, int ks, int lane) {
+  Frag<float> f;
+  int s = 4 * ks + 2 * (lane >> 5);
+  f.v[0] = *reinterpret_cast<const uint4*>(tile + lds_off(row, s));
+  f.v[1] = *reinterpret_cast<const uint4*>(tile + lds_off(row, s + 1));
+  return f;
+}
+
+// ---- epilogue --------------------------------------------------------------------------------
+__device__ __forceinline__ float load_any(const void* p, int dtype, int64_t idx) {
+  return dtype == PENEO_F32 ? reinterpret_cast<const float*>(p)[idx] : bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[idx]);
+}
+__device__ __forceinline__ void store_any(void* p, int dtype, int64_t idx, float v) {
+  if (dtype == PENEO_F32) reinterpret_cast<float*>(p)[idx] = v;
+  else reinterpret_cast<bf16_t*>(p)[idx] = f32_to_bf16(v);
+}
+
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float acc) {
+  const peneo_gemm_epilogue& e = p.ep;
+  float v = acc * e.alpha;
+  if (e.bias) v += e.bias[n];
+  if (e.preact) store_any(e.preact, p.c_dtype, (int64_t)m * e.ld_preact + n, v);
+  v = act_f(e.act, v);
+  if (e.grad_src) v *= act_grad_f(e.grad_act, load_any(e.grad_src, p.c_dtype, (int64_t)m * e.ld_grad + n));
+  if (e.drop_p > 0.f) {
+    uint32_t thresh = (uint32_t)fminf(e.drop_p * 4294967296.0f, 4294967040.0f);
+    v = dropout_keep(e.drop_seed, (uint64_t)m * (uint64_t)p.N + n, thresh) ? v * (1.0f / (1.0f - e.drop_p)) : 0.f;
+  }
+  if (e.residual) v += load_any(e.residual, p.c_dtype, (int64_t)m * e.ld_res + n);
+  int64_t ci = (int64_t)m * p.ldc + n;
+  if (e.accumulate) v += reinterpret_cast<float*>(p.C)[ci];
+  store_any(p.C, p.c_dtype, ci, v);
+}
+
+template <typename T, bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KT = ROWB / sizeof(T);             // k elements per tile: 64 (bf16) / 32 (fp32)
+  constexpr int KSTEPS = KT / 16;
+  char* sA = smem;                                 // [2][TILE_BYTES]
+  char* sB = smem + 2 * TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+
+  const int ktiles = (p.K + KT - 1) / KT;
+  int kt_begin = 0, kt_end = ktiles;
+  if (p.split_k > 1) {
+    kt_begin = blockIdx.z * p.kt_per_split;
+    kt_end = min(ktiles, kt_begin + p.kt_per_split);
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stage<T> ra, rb;
+  auto gload = [&](int kt) {
+    int k0 = kt * KT;
+    if (AK) load_kmajor<T>(ra, A, p.lda, m0, k0, p.M, p.K, tid); else load_mnmajor<T>(ra, A, p.lda, m0, k0, p.M, p.K, tid);
+    if (BK) load_kmajor<T>(rb, B, p.ldb, n0, k0, p.N, p.K, tid); else load_mnmajor<T>(rb, B, p.ldb, n0, k0, p.N, p.K, tid);
+  };
+  auto lstore = [&](int buf) {
+    if (AK) store_kmajor<T>(ra, sA + buf * TILE_BYTES, tid); else store_mnmajor<T>(ra, sA + buf * TILE_BYTES, tid);
+    if (BK) store_kmajor<T>(rb, sB + buf * TILE_BYTES, tid); else store_mnmajor<T>(rb, sB + buf * TILE_BYTES, tid);
+  };
+
+  if (kt_begin < kt_end) {
+    gload(kt_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) gload(kt + 1);
+    const char* tA = sA + buf * TILE_BYTES;
+    const char* tB = sB + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag<T> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = read_frag<T>(tA, wm * 64 + i * 32 + (lane & 31), ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag<T>(tB, wn * 64 + j * 32 + (lane & 31), ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma_step(fa[i], fb[j], acc[i][j]);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: park the accumulators in LDS (the staging buffers are dead now), then walk the tile
+  // row-major so that consecutive lanes own consecutive columns (coalesced C / residual traffic)
+  // and the fused epilogue stays a compact rolled loop.
+  float* sC = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sC[(wm * 64 + i * 32 + acc_row(r, lane)) * GB + wn * 64 + j * 32 + acc_col(lane)] = acc[i][j][r];
+  __syncthreads();
+  const int mrem = min(GB, p.M - m0), nrem = min(GB, p.N - n0);
+  for (int idx = tid; idx < GB * GB; idx += 256) {
+    const int r = idx >> 7, c = idx & (GB - 1);
+    if (r < mrem && c < nrem) {
+      const float v = sC[idx];
+      if (p.split_k > 1) p.ws[((int64_t)blockIdx.z * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
+      else epilogue_store(p, m0 + r, n0 + c, v);
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(GemmParams p) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)p.M * p.N;
+  if (idx >= total) return;
+  float s = 0.f;
+  for (int z = 0; z < p.split_k; ++z) s += p.ws[(int64_t)z * total + idx];
+  epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), s);
+}
+
+template <typename T>
+static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
+  size_t shmem = 4 * TILE_BYTES;
+  if (ak && bk) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), shmem, st, p);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), shmem, st, p);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(256), shmem, st, p);
+  else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), shmem, st, p);
+  return check_launch("peneo_gemm");
+}
+
+}  // namespace peneo
+
+using namespace peneo;
+
+extern "C" size_t peneo_gemm_workspace_bytes(int M, int N, int K, int split_k) {
+  (void)K;
+  return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int64_t lda,
+                          const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype,
+                          const peneo_gemm_epilogue* ep, int split_k, void* workspace, size_t workspace_bytes,
+                          peneo_stream_t stream) {
+  PENEO_REQUIRE(dtype == PENEO_F32 || dtype == PENEO_BF16, "peneo_gemm: bad dtype %d", dtype);
+  PENEO_REQUIRE(c_dtype == PENEO_F32 || c_dtype == PENEO_BF16, "peneo_gemm: bad c_dtype %d", c_dtype);
+  PENEO_REQUIRE(M > 0 && N > 0 && K > 0, "peneo_gemm: empty problem %dx%dx%d", M, N, K);
+  PENEO_REQUIRE(A && B && C, "peneo_gemm: null operand");
+  PENEO_REQUIRE(lda >= (a_kmajor ? K : M) && ldb >= (b_kmajor ? K : N) && ldc >= N, "peneo_gemm: leading dim too small");
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.c_dtype = c_dtype;
+  if (ep) p.ep = *ep; else { peneo_gemm_epilogue z = {}; p.ep = z; }
+  if (p.ep.alpha == 0.f) p.ep.alpha = 1.f;
+  PENEO_REQUIRE(!p.ep.accumulate || c_dtype == PENEO_F32, "peneo_gemm: accumulate needs an fp32 C");
+  PENEO_REQUIRE(p.ep.drop_p >= 0.f && p.ep.drop_p < 1.f, "peneo_gemm: drop_p out of range");
+  const int KT = dtype == PENEO_BF16 ? 64 : 32;
+  const int ktiles = (K + KT - 1) / KT;
+  if (split_k < 1) split_k = 1;
+  if (split_k > ktiles) split_k = ktiles;
+  p.kt_per_split = (ktiles + split_k - 1) / split_k;
+  split_k = (ktiles + p.kt_per_split - 1) / p.kt_per_split;
+  p.split_k = split_k;
+  p.ws = reinterpret_cast<float*>(workspace);
+  if (split_k > 1)
+    PENEO_REQUIRE(workspace && workspace_bytes >= peneo_gemm_workspace_bytes(M, N, K, split_k),
+                  "peneo_gemm: split-k workspace too small");
+  dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, split_k);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = dtype == PENEO_BF16 ? launch_gemm<bf16_t>(p, a_kmajor != 0, b_kmajor != 0, grid, st)
+                               : launch_gemm<float>(p, a_kmajor != 0, b_kmajor != 0, grid, st);
+  if (rc != PENEO_OK) return rc;
+  if (split_k > 1) {
+    int64_t total = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return check_launch("peneo_gemm(split-k reduce)");
+  }
+  return PENEO_OK;
+}

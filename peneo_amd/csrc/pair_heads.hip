@@ -1,0 +1,622 @@
+// K11 + K12 + K13 fused: handshaking + the five pair-classifier heads + class-weighted CE.
+//
+// The reference materialises [B, N, N, 2D] and [B, P, D] tensors (model/peneo_decoder.py:164-175)
+// and runs five Linear(D->D)+SiLU+Linear(D->C) heads over all P = N(N+1)/2 token pairs
+// (:231-292, :355-363).  Here one workgroup owns 128 consecutive pairs of one document; each
+// 64-lane wave owns 32 pairs (lane & 31 = pair) and
+//   * builds x = SiLU(a_i + b_j) for its pairs straight into MFMA B-operand registers
+//     (a_i + b_j == combine_fc(cat(h_i, h_j)), a/b come from one [N, 2D] GEMM),
+//   * streams the concatenated first-layer weights (all heads, [nh*D, D], pre-packed in MFMA
+//     A-fragment order) through LDS, double buffered, one 32-row slab at a time:
+//     z^T[hidden, pair] = W1 . x^T  on v_mfma_f32_32x32x16_bf16 (fp32 accumulate),
+//   * applies bias + SiLU in registers; the C-layout accumulator of a slab is, under a fixed
+//     row permutation, exactly the B operand of the second layer, whose (block-diagonal, zero
+//     padded to 32 classes) weights are pre-packed with that permutation:
+//     logits^T[class, pair] += W2 . y   — two more MFMAs per slab, nothing leaves registers,
+//   * finishes with soft-max cross-entropy per head (fp32) and writes only the 14 logits per pair
+//     (and, for training, the un-normalised dlogits and the loss partial sums).
+// HBM traffic per document is the 7.3 MB of logits; everything else is L2/LDS resident.
+#include "common.h"
+
+namespace peneo {
+
+constexpr int PH_PAIRS = 128;       // pairs per workgroup (4 waves x 32)
+constexpr int NCP = 16;             // padded class rows that are ever non-zero (<= 16)
+
+struct PackSrc {
+  const float* w[PENEO_MAX_HEADS];
+  int classes[PENEO_MAX_HEADS];
+  int num_heads;
+  int D;
+};
+
+// packed W1: [(ht * KS + ks) * 64 + lane] * 8 + e  <-  W1cat[ht*32 + (lane&31)][16*ks + 8*(lane>>5) + e]
+template <typename T>
+__global__ void pack_w1_kernel(PackSrc s, T* out) {
+  const int D = s.D, KS = D / 16;
+  const int64_t total = (int64_t)s.num_heads * D * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int e = (int)(i & 7);
+    int lane = (int)((i >> 3) & 63);
+    int64_t blk = i >> 9;
+    int ks = (int)(blk % KS);
+    int ht = (int)(blk / KS);
+    int row = ht * 32 + (lane & 31);           // hidden unit in [0, nh*D)
+    int col = 16 * ks + 8 * (lane >> 5) + e;
+    int h = row / D;
+    Elem<T>::store(out + i, s.w[h][(int64_t)(row - h * D) * D + col]);
+  }
+}
+
+// packed W2: [(ht * 2 + kk) * 64 + lane] * 8 + t  <-  W2full[class = lane&31][hidden = ht*32 + 16*kk + (t&3) + 8*(t>>2) + 4*(lane>>5)]
+// where W2full is the block-diagonal [sum classes (padded to 32), nh*D] matrix.
+template <typename T>
+__global__ void pack_w2_kernel(PackSrc s, T* out) {
+  const int D = s.D;
+  const int64_t total = (int64_t)s.num_heads * D / 32 * 2 * 64 * 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int t = (int)(i & 7);
+    int lane = (int)((i >> 3) & 63);
+    int64_t blk = i >> 9;
+    int kk = (int)(blk & 1);
+    int ht = (int)(blk >> 1);
+    int cls = lane & 31;
+    int hidden = ht * 32 + 16 * kk + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
+    int h = hidden / D;
+    int off = 0;
+    for (int q = 0; q < h; ++q) off += s.classes[q];
+    float v = 0.f;
+    if (cls >= off && cls < off + s.classes[h]) v = s.w[h][(int64_t)(cls - off) * D + (hidden - h * D)];
+    Elem<T>::store(out + i, v);
+  }
+}
+
+struct PairFwdParams {
+  const void* ab; int B, N, D; int64_t P;
+  int num_heads; int classes[PENEO_MAX_HEADS]; int total_classes;
+  const void* w1p; const float* b1; const void* w2p; const float* b2;
+  float* logits[PENEO_MAX_HEADS];
+  const int64_t* tags[PENEO_MAX_HEADS];
+  const float* cw[PENEO_MAX_HEADS];
+  float* loss_num; float* loss_den; float* dl_sum;
+  float* dlogits[PENEO_MAX_HEADS];
+};
+
+constexpr float NEG_INF_F = -3.0e38f;
+// register arrays must only ever be indexed by compile-time constants (dynamic indices go to scratch)
+__device__ __forceinline__ float cls_at(const float (&cls)[NCP], int idx) {
+  float v = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCP; ++c) v = (c == idx) ? cls[c] : v;
+  return v;
+}
+__device__ __forceinline__ void dls_add(float (&dls)[NCP], int idx, float g) {
+#pragma unroll
+  for (int c = 0; c < NCP; ++c) dls[c] += (c == idx) ? g : 0.f;
+}
+
+template <typename T> struct FragBytes { static constexpr int v = 8 * (int)sizeof(T); };  // per lane per fragment
+
+template <typename T>
+__device__ __forceinline__ Frag<T> load_frag_linear(const char* base, int frag_index, int lane) {
+  Frag<T> f;
+  const char* p = base + ((int64_t)frag_index * 64 + lane) * FragBytes<T>::v;
+  if constexpr (sizeof(T) == 2) f.v = *reinterpret_cast<const uint4*>(p);
+  else { f.v[0] = *reinterpret_cast<const uint4*>(p); f.v[1] = *reinterpret_cast<const uint4*>(p + 16); }
+  return f;
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void pair_heads_fwd_kernel(PairFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SLAB_BYTES = KS * 64 * FragBytes<T>::v;     // one 32-row slab of W1 in fragment order
+  constexpr int NV = SLAB_BYTES / 16;                       // 16-byte vectors per slab
+  constexpr int VPT = (NV + 255) / 256;                     // ... per thread
+  char* sW = smem;                                           // [2][SLAB_BYTES]
+  float* sB1 = reinterpret_cast<float*>(smem + 2 * SLAB_BYTES);  // [nh * D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int D = p.D, N = p.N;
+  const int b = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
+  const int64_t mypair = p0 + wave * 32 + (lane & 31);
+  const bool pair_ok = mypair < p.P;
+  int pi, pj;
+  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
+  const int nslab = p.num_heads * D / 32;
+
+  for (int i = tid; i < p.num_heads * D; i += 256) sB1[i] = p.b1[i];
+
+  // ---- x = SiLU(a_i + b_j) as B-operand fragments (k = decoder dim), kept in registers ----
+  const T* abd = reinterpret_cast<const T*>(p.ab) + (int64_t)b * N * 2 * D;
+  const T* arow = abd + (int64_t)pi * 2 * D;
+  const T* brow = abd + (int64_t)pj * 2 * D + D;
+  Frag<T> xf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = 16 * ks + 8 * half;
+    float a[8], bb[8];
+    if constexpr (sizeof(T) == 2) {
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+    } else {
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c + 4), a + 4);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c + 4), bb + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+    if constexpr (sizeof(T) == 2) xf[ks].v = pack16<T>(a);
+    else { xf[ks].v[0] = pack16<T>(a); xf[ks].v[1] = pack16<T>(a + 4); }
+  }
+
+  f32x16_t lg;  // logits^T[class, pair]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lg[r] = 0.f;
+
+  // ---- stream W1 slabs through LDS (register-staged double buffer) ----
+  const uint4* w1g = reinterpret_cast<const uint4*>(p.w1p);
+  uint4 stage[VPT];
+  auto gload = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+      if (tid + 256 * i < NV) stage[i] = w1g[(int64_t)slab * NV + tid + 256 * i];
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+      if (tid + 256 * i < NV) *reinterpret_cast<uint4*>(sW + buf * SLAB_BYTES + (tid + 256 * i) * 16) = stage[i];
+  };
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int slab = 0; slab < nslab; ++slab) {
+    const int buf = slab & 1;
+    const bool more = slab + 1 < nslab;
+    if (more) gload(slab + 1);
+    // second-layer fragments for this slab (L2 resident, 2 KiB per wave)
+    Frag<T> w2f0 = load_frag_linear<T>(reinterpret_cast<const char*>(p.w2p), slab * 2 + 0, lane);
+    Frag<T> w2f1 = load_frag_linear<T>(reinterpret_cast<const char*>(p.w2p), slab * 2 + 1, lane);
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    const char* wb = sW + buf * SLAB_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
+      mma_step(wf, xf[ks], z);
+    }
+    float y[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = silu_f(z[r] + sB1[slab * 32 + acc_row(r, lane)]);
+    Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
+    mma_step(w2f0, y0, lg);
+    mma_step(w2f1, y1, lg);
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- logits: rows 0..15 of lg live in regs 0..7 (half 0: rows 0-3, 8-11; half 1: rows 4-7, 12-15) ----
+  float mine[8], other[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { mine[r] = lg[r]; other[r] = __shfl_xor(lg[r], 32, 64); }
+  float cls[NCP];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cls[c] = half == 0 ? mine[c] : other[c];
+    cls[4 + c] = half == 0 ? other[c] : mine[c];
+    cls[8 + c] = half == 0 ? mine[4 + c] : other[4 + c];
+    cls[12 + c] = half == 0 ? other[4 + c] : mine[4 + c];
+  }
+  float num[PENEO_MAX_HEADS], den[PENEO_MAX_HEADS], dls[NCP];
+#pragma unroll
+  for (int h = 0; h < PENEO_MAX_HEADS; ++h) { num[h] = 0.f; den[h] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < NCP; ++c) dls[c] = 0.f;
+  const bool writer = pair_ok && half == 0;
+  {
+    int off = 0;
+#pragma unroll
+    for (int h = 0; h < PENEO_MAX_HEADS; ++h) {
+      if (h < p.num_heads) {
+        const int C = p.classes[h];
+        float l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) l[c] = (c < C) ? cls_at(cls, off + c) + p.b2[off + c] : NEG_INF_F;
+        if (writer && p.logits[h]) {
+          float* dst = p.logits[h] + ((int64_t)b * p.P + mypair) * C;
+          for (int c = 0; c < C; ++c) dst[c] = l[c];
+        }
+        if (writer && p.tags[h]) {
+          const int tag = (int)p.tags[h][(int64_t)b * p.P + mypair];
+          float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+          float e[4], se = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { e[c] = (c < C) ? __expf(l[c] - mx) : 0.f; se += e[c]; }
+          const float lse = mx + __logf(se);
+          float lt = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) lt = (c == tag) ? l[c] : lt;
+          const float w = p.cw[h] ? p.cw[h][tag] : 1.f;
+          num[h] = w * (lse - lt);
+          den[h] = w;
+          const float inv = 1.f / se;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (c < C) {
+              float g = w * (e[c] * inv - (c == tag ? 1.f : 0.f));
+              if (p.dlogits[h]) p.dlogits[h][((int64_t)b * p.P + mypair) * C + c] = g;
+              dls_add(dls, off + c, g);
+            }
+          }
+        }
+        off += C;
+      }
+    }
+  }
+  if (p.loss_num) {
+#pragma unroll
+    for (int h = 0; h < PENEO_MAX_HEADS; ++h) {
+      if (h < p.num_heads && p.tags[h]) {
+        float a = wave_sum(num[h]), d2 = wave_sum(den[h]);
+        if (lane == 0) { atomicAdd(p.loss_num + h, a); atomicAdd(p.loss_den + h, d2); }
+      }
+    }
+    if (p.dl_sum) {
+#pragma unroll
+      for (int c = 0; c < NCP; ++c) {
+        float a = wave_sum(dls[c]);
+        if (lane == 0 && c < p.total_classes) atomicAdd(p.dl_sum + c, a);
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// building blocks of the chunked backward
+// ================================================================================================
+template <typename T>
+__global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pbase, int64_t npairs, T* x) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int vpr = D / VEC;
+  const int64_t total = npairs * vpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pr = idx / vpr;
+    const int c = (int)(idx % vpr) * VEC;
+    int i, j;
+    pair_decode(pbase + pr, N, i, j);
+    float a[VEC], b[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)i * 2 * D + c), a);
+    unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)j * 2 * D + D + c), b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = silu_f(a[e] + b[e]);
+    *reinterpret_cast<uint4*>(x + pr * D + c) = pack16<T>(a);
+  }
+}
+
+// d_a[i, k] += sum_{j >= i} dx[p(i,j)] * SiLU'(a_i + b_j): one block per row i, threads along k
+template <typename T>
+__global__ void pair_x_bwd_a_kernel(const T* abd, int N, int D, int i0, int64_t pbase, const T* dx, float* d_ab) {
+  const int i = i0 + blockIdx.x;
+  const int64_t prow = pair_row_start(i, N) - pbase;
+  for (int k = threadIdx.x; k < D; k += blockDim.x) {
+    const float a = Elem<T>::load(abd + (int64_t)i * 2 * D + k);
+    float s = 0.f;
+    for (int j = i; j < N; ++j) {
+      const float u = a + Elem<T>::load(abd + (int64_t)j * 2 * D + D + k);
+      s += Elem<T>::load(dx + (prow + (j - i)) * D + k) * silu_grad_f(u);
+    }
+    d_ab[(int64_t)i * 2 * D + k] += s;
+  }
+}
+// d_b[j, k] += sum_{i0 <= i < i1, i <= j} dx[p(i,j)] * SiLU'(a_i + b_j): one block per column j
+template <typename T>
+__global__ void pair_x_bwd_b_kernel(const T* abd, int N, int D, int i0, int i1, int64_t pbase, const T* dx, float* d_ab) {
+  const int j = i0 + blockIdx.x;  // columns below i0 have no pair in this chunk
+  const int iend = min(i1, j + 1);
+  for (int k = threadIdx.x; k < D; k += blockDim.x) {
+    const float bj = Elem<T>::load(abd + (int64_t)j * 2 * D + D + k);
+    float s = 0.f;
+    for (int i = i0; i < iend; ++i) {
+      const float u = Elem<T>::load(abd + (int64_t)i * 2 * D + k) + bj;
+      const int64_t pr = pair_row_start(i, N) + (j - i) - pbase;
+      s += Elem<T>::load(dx + pr * D + k) * silu_grad_f(u);
+    }
+    d_ab[(int64_t)j * 2 * D + D + k] += s;
+  }
+}
+
+struct DzParams {
+  peneo_pair_dz_args a;
+};
+constexpr int DZ_ROWS = 256;  // pairs per block
+// grid.x = nh*D/128 column blocks (each inside one head), grid.y = row blocks; thread = one hidden column
+template <typename T>
+__global__ __launch_bounds__(128) void pair_dz_kernel(T* z, int64_t npairs, DzParams pp) {
+  const peneo_pair_dz_args& a = pp.a;
+  const int col = blockIdx.x * 128 + threadIdx.x;   // hidden column in [0, nh*D)
+  const int h = col / a.D, k = col - h * a.D;
+  const int C = a.classes[h];
+  const int ncol = a.num_heads * a.D;
+  float w2[4], dw2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { w2[c] = (c < C) ? a.w2[h][(int64_t)c * a.D + k] : 0.f; dw2[c] = 0.f; }
+  const float sc = a.scale[h];
+  float db1 = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.y * DZ_ROWS, r1 = min(npairs, r0 + DZ_ROWS);
+  const float* dl = a.dlogits[h];
+  for (int64_t r = r0; r < r1; ++r) {
+    const float zv = Elem<T>::load(z + r * ncol + col);
+    const float sg = sigmoid_f(zv);
+    const float y = zv * sg;
+    float dy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < C) {
+        const float g = dl[r * C + c] * sc;
+        dy += g * w2[c];
+        dw2[c] += g * y;
+      }
+    }
+    const float dz = dy * sg * (1.f + zv * (1.f - sg));
+    db1 += dz;
+    Elem<T>::store(z + r * ncol + col, dz);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) if (c < C) atomicAdd(a.dw2[h] + (int64_t)c * a.D + k, dw2[c]);
+  atomicAdd(a.db1 + col, db1);
+}
+
+__global__ void loss_finish_kernel(const float* num, const float* den, const float* ratio, int nh, float* out, float* scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float tot = 0.f;
+    for (int h = 0; h < nh; ++h) {
+      float l = num[h] / den[h];
+      out[h] = l;
+      tot += ratio[h] * l;
+      if (scale) scale[h] = ratio[h] / den[h];
+    }
+    out[nh] = tot;
+  }
+}
+
+__global__ void weighted_ce_kernel(const float* logits, const int64_t* tags, const float* cw, int64_t rows, int C, float* num,
+                                   float* den, float* dlogits) {
+  float n = 0.f, d = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const float* l = logits + r * C;
+    const int tag = (int)tags[r];
+    float mx = l[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(l[c] - mx);
+    const float lse = mx + __logf(se);
+    const float w = cw ? cw[tag] : 1.f;
+    n += w * (lse - l[tag]);
+    d += w;
+    if (dlogits)
+      for (int c = 0; c < C; ++c) dlogits[r * C + c] = w * (__expf(l[c] - lse) - (c == tag ? 1.f : 0.f));
+  }
+  n = wave_sum(n); d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(num, n); atomicAdd(den, d); }
+}
+
+// K14: argmax != 0 compaction, in increasing p order (one block; P is ~1e5 so a single-block scan is fine)
+__global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits, int64_t P, int C, int N, int32_t* spots,
+                                                             float* scores, int32_t* count, int max_spots) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t p0 = 0; p0 < P; p0 += 1024) {
+    const int64_t pp = p0 + threadIdx.x;
+    int tag = 0; float sc = 0.f;
+    if (pp < P) {
+      const float* l = logits + pp * C;
+      float mx = l[0]; int am = 0;
+      for (int c = 1; c < C; ++c) if (l[c] > mx) { mx = l[c]; am = c; }
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += __expf(l[c] - mx);
+      tag = am; sc = 1.f / se;
+    }
+    const unsigned long long bal = __ballot(tag != 0);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+    if (tag != 0) {
+      const int slot = base + woff + before;
+      if (slot < max_spots) {
+        int i, j;
+        pair_decode(pp, N, i, j);
+        spots[slot * 3 + 0] = i; spots[slot * 3 + 1] = j; spots[slot * 3 + 2] = tag;
+        scores[slot] = sc;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+
+template <typename T, int KS>
+static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
+  size_t sh = (size_t)2 * KS * 64 * FragBytes<T>::v + (size_t)p.num_heads * p.D * sizeof(float);
+  if (sh > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
+      return PENEO_ERR_LAUNCH;
+    }
+  }
+  dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
+  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS>), grid, dim3(256), sh, st, p);
+  return check_launch("peneo_pair_heads_fwd");
+}
+template <typename T>
+static int dispatch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
+  switch (p.D / 16) {
+    case 2: return launch_pair_fwd<T, 2>(p, st);
+    case 4: return launch_pair_fwd<T, 4>(p, st);
+    case 6: return launch_pair_fwd<T, 6>(p, st);
+    case 8: return launch_pair_fwd<T, 8>(p, st);
+    case 12: return launch_pair_fwd<T, 12>(p, st);
+    case 16: return launch_pair_fwd<T, 16>(p, st);
+    case 24: return launch_pair_fwd<T, 24>(p, st);
+    case 32: return launch_pair_fwd<T, 32>(p, st);
+    default: set_error("peneo_pair_heads_fwd: D=%d not supported (D/16 in {2,4,6,8,12,16,24,32})", p.D); return PENEO_ERR_INVALID;
+  }
+}
+
+}  // namespace peneo
+using namespace peneo;
+
+static inline bool ok_dt(int d) { return d == PENEO_F32 || d == PENEO_BF16; }
+static inline unsigned cap_blocks(int64_t n, int per = 256, int64_t cap = 8192) {
+  int64_t b = (n + per - 1) / per;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+static int total_classes(const int* classes, int nh) { int t = 0; for (int h = 0; h < nh; ++h) t += classes[h]; return t; }
+
+extern "C" size_t peneo_pair_heads_w1_packed_bytes(int dtype, int num_heads, int D) {
+  return (size_t)num_heads * D * D * (dtype == PENEO_BF16 ? 2 : 4);
+}
+extern "C" size_t peneo_pair_heads_w2_packed_bytes(int dtype, int num_heads, int D) {
+  return (size_t)num_heads * D / 32 * 2 * 64 * 8 * (dtype == PENEO_BF16 ? 2 : 4);
+}
+
+static int fill_pack_src(PackSrc& s, const float* const* w, const int* classes, int num_heads, int D, const char* who) {
+  PENEO_REQUIRE(num_heads > 0 && num_heads <= PENEO_MAX_HEADS, "%s: num_heads out of range", who);
+  PENEO_REQUIRE(D > 0 && D % 32 == 0, "%s: D must be a multiple of 32", who);
+  s.num_heads = num_heads; s.D = D;
+  for (int h = 0; h < PENEO_MAX_HEADS; ++h) { s.w[h] = h < num_heads ? w[h] : nullptr; s.classes[h] = (classes && h < num_heads) ? classes[h] : 0; }
+  for (int h = 0; h < num_heads; ++h) PENEO_REQUIRE(s.w[h] != nullptr, "%s: null weight pointer for head %d", who, h);
+  return PENEO_OK;
+}
+
+extern "C" int peneo_pair_heads_pack_w1(int dtype, const float* const* w1, int num_heads, int D, void* packed, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && w1 && packed, "peneo_pair_heads_pack_w1: bad arguments");
+  PackSrc s;
+  int rc = fill_pack_src(s, w1, nullptr, num_heads, D, "peneo_pair_heads_pack_w1");
+  if (rc) return rc;
+  int64_t total = (int64_t)num_heads * D * D;
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pack_w1_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)packed);
+  else hipLaunchKernelGGL(pack_w1_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (float*)packed);
+  return check_launch("peneo_pair_heads_pack_w1");
+}
+
+extern "C" int peneo_pair_heads_pack_w2(int dtype, const float* const* w2, const int* classes, int num_heads, int D, void* packed,
+                                        peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && w2 && classes && packed, "peneo_pair_heads_pack_w2: bad arguments");
+  PackSrc s;
+  int rc = fill_pack_src(s, w2, classes, num_heads, D, "peneo_pair_heads_pack_w2");
+  if (rc) return rc;
+  PENEO_REQUIRE(total_classes(classes, num_heads) <= NCP, "peneo_pair_heads_pack_w2: more than %d classes in total", NCP);
+  for (int h = 0; h < num_heads; ++h) PENEO_REQUIRE(classes[h] >= 1 && classes[h] <= 4, "peneo_pair_heads_pack_w2: classes[%d] must be 1..4", h);
+  int64_t total = (int64_t)num_heads * D / 32 * 2 * 64 * 8;
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pack_w2_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)packed);
+  else hipLaunchKernelGGL(pack_w2_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (float*)packed);
+  return check_launch("peneo_pair_heads_pack_w2");
+}
+
+extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
+                                    float* const* logits, const peneo_pair_loss* loss, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && ab && desc && B > 0 && N > 0, "peneo_pair_heads_fwd: bad arguments");
+  PENEO_REQUIRE(desc->num_heads > 0 && desc->num_heads <= PENEO_MAX_HEADS, "peneo_pair_heads_fwd: num_heads out of range");
+  PENEO_REQUIRE(desc->D > 0 && desc->D % 32 == 0, "peneo_pair_heads_fwd: D must be a multiple of 32");
+  PENEO_REQUIRE(desc->w1_packed && desc->b1 && desc->w2_packed && desc->b2, "peneo_pair_heads_fwd: null weights");
+  PairFwdParams p = {};
+  p.ab = ab; p.B = B; p.N = N; p.D = desc->D; p.P = (int64_t)N * (N + 1) / 2; p.num_heads = desc->num_heads;
+  p.total_classes = total_classes(desc->classes, desc->num_heads);
+  PENEO_REQUIRE(p.total_classes <= NCP, "peneo_pair_heads_fwd: more than %d classes in total", NCP);
+  p.w1p = desc->w1_packed; p.b1 = desc->b1; p.w2p = desc->w2_packed; p.b2 = desc->b2;
+  for (int h = 0; h < desc->num_heads; ++h) {
+    PENEO_REQUIRE(desc->classes[h] >= 1 && desc->classes[h] <= 4, "peneo_pair_heads_fwd: classes[%d] must be 1..4", h);
+    p.classes[h] = desc->classes[h];
+    p.logits[h] = logits ? logits[h] : nullptr;
+    if (loss) { p.tags[h] = loss->tags[h]; p.cw[h] = loss->class_weight[h]; p.dlogits[h] = loss->dlogits[h]; }
+  }
+  if (loss) {
+    p.loss_num = loss->loss_num; p.loss_den = loss->loss_den; p.dl_sum = loss->dl_sum;
+    bool any = false;
+    for (int h = 0; h < desc->num_heads; ++h) any = any || loss->tags[h];
+    if (any) PENEO_REQUIRE(p.loss_num && p.loss_den, "peneo_pair_heads_fwd: loss accumulators missing");
+  }
+  return dtype == PENEO_BF16 ? dispatch_pair_fwd<bf16_t>(p, (hipStream_t)stream) : dispatch_pair_fwd<float>(p, (hipStream_t)stream);
+}
+
+static int chunk_check(const char* who, int dtype, int N, int D, int i0, int i1) {
+  PENEO_REQUIRE(ok_dt(dtype), "%s: bad dtype", who);
+  PENEO_REQUIRE(N > 0 && D > 0 && D % 8 == 0, "%s: bad N/D", who);
+  PENEO_REQUIRE(0 <= i0 && i0 < i1 && i1 <= N, "%s: bad row range [%d, %d)", who, i0, i1);
+  return PENEO_OK;
+}
+
+extern "C" int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, void* x, peneo_stream_t stream) {
+  int rc = chunk_check("peneo_pair_x_fwd", dtype, N, D, i0, i1);
+  if (rc) return rc;
+  PENEO_REQUIRE(ab_doc && x, "peneo_pair_x_fwd: null pointer");
+  const int64_t pbase = pair_row_start(i0, N), npairs = pair_row_start(i1, N) - pbase;
+  const int64_t total = npairs * (D / (dtype == PENEO_BF16 ? 8 : 4));
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_x_fwd_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab_doc, N, D, i0, pbase, npairs, (bf16_t*)x);
+  else hipLaunchKernelGGL(pair_x_fwd_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)ab_doc, N, D, i0, pbase, npairs, (float*)x);
+  return check_launch("peneo_pair_x_fwd");
+}
+
+extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* dx, float* d_ab_doc,
+                                peneo_stream_t stream) {
+  int rc = chunk_check("peneo_pair_x_bwd", dtype, N, D, i0, i1);
+  if (rc) return rc;
+  PENEO_REQUIRE(ab_doc && dx && d_ab_doc, "peneo_pair_x_bwd: null pointer");
+  const int64_t pbase = pair_row_start(i0, N);
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = D >= 256 ? 256 : (D >= 128 ? 128 : 64);
+  if (dtype == PENEO_BF16) {
+    hipLaunchKernelGGL(pair_x_bwd_a_kernel<bf16_t>, dim3(i1 - i0), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, pbase, (const bf16_t*)dx, d_ab_doc);
+    hipLaunchKernelGGL(pair_x_bwd_b_kernel<bf16_t>, dim3(N - i0), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, i1, pbase, (const bf16_t*)dx, d_ab_doc);
+  } else {
+    hipLaunchKernelGGL(pair_x_bwd_a_kernel<float>, dim3(i1 - i0), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, pbase, (const float*)dx, d_ab_doc);
+    hipLaunchKernelGGL(pair_x_bwd_b_kernel<float>, dim3(N - i0), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, i1, pbase, (const float*)dx, d_ab_doc);
+  }
+  return check_launch("peneo_pair_x_bwd");
+}
+
+extern "C" int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && z_inout && args && npairs > 0, "peneo_pair_dz: bad arguments");
+  PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D % 128 == 0,
+                "peneo_pair_dz: D must be a multiple of 128 (got %d)", args->D);
+  PENEO_REQUIRE(args->db1 && args->scale, "peneo_pair_dz: null db1/scale");
+  for (int h = 0; h < args->num_heads; ++h)
+    PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->dw2[h] && args->classes[h] >= 1 && args->classes[h] <= 4,
+                  "peneo_pair_dz: head %d arguments invalid", h);
+  DzParams pp; pp.a = *args;
+  dim3 grid(args->num_heads * args->D / 128, (unsigned)((npairs + DZ_ROWS - 1) / DZ_ROWS));
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_dz_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, (bf16_t*)z_inout, npairs, pp);
+  else hipLaunchKernelGGL(pair_dz_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, (float*)z_inout, npairs, pp);
+  return check_launch("peneo_pair_dz");
+}
+
+extern "C" int peneo_loss_finish(const float* num, const float* den, const float* ratio, int num_heads, float* out, float* scale,
+                                 peneo_stream_t stream) {
+  PENEO_REQUIRE(num && den && ratio && out && num_heads > 0 && num_heads <= PENEO_MAX_HEADS, "peneo_loss_finish: bad arguments");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, num, den, ratio, num_heads, out, scale);
+  return check_launch("peneo_loss_finish");
+}
+
+extern "C" int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* class_weight, int64_t rows, int C,
+                                 float* num, float* den, float* dlogits, peneo_stream_t stream) {
+  PENEO_REQUIRE(logits && tags && num && den && rows > 0 && C > 0 && C <= 16, "peneo_weighted_ce: bad arguments");
+  hipLaunchKernelGGL(weighted_ce_kernel, dim3(cap_blocks(rows, 256, 1024)), dim3(256), 0, (hipStream_t)stream, logits, tags,
+                     class_weight, rows, C, num, den, dlogits);
+  return check_launch("peneo_weighted_ce");
+}
+
+extern "C" int peneo_spots_compact(const float* logits, int64_t P, int C, int N, int32_t* spots_ijt, float* scores,
+                                   int32_t* count, int max_spots, peneo_stream_t stream) {
+  PENEO_REQUIRE(logits && spots_ijt && scores && count && P > 0 && C > 1 && N > 0 && max_spots >= 0, "peneo_spots_compact: bad arguments");
+  PENEO_REQUIRE(P == (int64_t)N * (N + 1) / 2, "peneo_spots_compact: P != N(N+1)/2");
+  hipLaunchKernelGGL(spots_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, P, C, N, spots_ijt, scores, count, max_spots);
+  return check_launch("peneo_spots_compact");
+}

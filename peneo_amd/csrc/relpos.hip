@@ -1,0 +1,129 @@
+// K4: relative-position buckets and the summed 1-D + 2-D attention bias, computed once per forward
+// and shared by all layers (reference: modeling_layoutlmv3.py:586-676 builds one-hot [B,T,T,bins]
+// tensors and multiplies them by Linear(bins -> heads); algorithmically it is a three-table lookup).
+#include "common.h"
+
+namespace peneo {
+
+__device__ __forceinline__ uint8_t bucket_of(int d, const uint8_t* lut, int lut_len, int half) {
+  int n = d < 0 ? -d : d;
+  if (n > lut_len - 1) n = lut_len - 1;
+  return (uint8_t)(lut[n] + (d > 0 ? half : 0));
+}
+
+__global__ __launch_bounds__(256) void relpos_buckets_kernel(const int32_t* pos, const int32_t* xs, const int32_t* ys, int T,
+                                                             const uint8_t* lut1, int n1, int half1, const uint8_t* lut2,
+                                                             int n2, int half2, uint8_t* bk1, uint8_t* bkx, uint8_t* bky) {
+  const int64_t row = blockIdx.x;  // b * T + i
+  const int64_t b = row / T;
+  const int32_t pi = pos ? pos[row] : 0, xi = xs ? xs[row] : 0, yi = ys ? ys[row] : 0;
+  for (int j = threadIdx.x; j < T; j += blockDim.x) {
+    const int64_t o = row * T + j, cj = b * T + j;
+    if (bk1) bk1[o] = bucket_of(pos[cj] - pi, lut1, n1, half1);
+    if (bkx) bkx[o] = bucket_of(xs[cj] - xi, lut2, n2, half2);
+    if (bky) bky[o] = bucket_of(ys[cj] - yi, lut2, n2, half2);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
+                                                              const float* w1, int bins1, const float* wx, const float* wy,
+                                                              int bins2, float scale, int nh, int Tn, T* bias) {
+  extern __shared__ float tab[];  // [nh][bins1] [nh][bins2] [nh][bins2]
+  float* t1 = tab;
+  float* tx = t1 + nh * bins1;
+  float* ty = tx + nh * bins2;
+  for (int i = threadIdx.x; i < nh * bins1; i += blockDim.x) t1[i] = w1 ? w1[i] * scale : 0.f;
+  for (int i = threadIdx.x; i < nh * bins2; i += blockDim.x) { tx[i] = wx ? wx[i] * scale : 0.f; ty[i] = wy ? wy[i] * scale : 0.f; }
+  __syncthreads();
+  const int64_t row = blockIdx.x;  // b * T + i
+  const int64_t b = row / Tn, i = row % Tn;
+  for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
+    const int64_t o = row * Tn + j;
+    const int a = bk1 ? bk1[o] : 0, bx = bkx ? bkx[o] : 0, by = bky ? bky[o] : 0;
+    for (int h = 0; h < nh; ++h) {
+      float v = 0.f;
+      if (bk1) v += t1[h * bins1 + a];
+      if (bkx) v += tx[h * bins2 + bx] + ty[h * bins2 + by];
+      Elem<T>::store(bias + (((b * nh + h) * Tn + i) * Tn + j), v);
+    }
+  }
+}
+
+// one block per (b, h, 32-row slab): LDS histograms, then one global atomic per bin
+__global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, const uint8_t* bk1, const uint8_t* bkx,
+                                                              const uint8_t* bky, float* dw1, int bins1, float* dwx, float* dwy,
+                                                              int bins2, float scale, int nh, int Tn) {
+  extern __shared__ float hist[];  // [bins1] [bins2] [bins2]
+  float* h1 = hist;
+  float* hx = h1 + bins1;
+  float* hy = hx + bins2;
+  for (int i = threadIdx.x; i < bins1 + 2 * bins2; i += blockDim.x) hist[i] = 0.f;
+  __syncthreads();
+  const int slabs = (Tn + 31) / 32;
+  const int slab = blockIdx.x % slabs;
+  const int h = (blockIdx.x / slabs) % nh;
+  const int64_t b = blockIdx.x / ((int64_t)slabs * nh);
+  const int i0 = slab * 32, i1 = min(Tn, i0 + 32);
+  for (int i = i0; i < i1; ++i) {
+    const float* grow = g + (((b * nh + h) * Tn + i) * (int64_t)Tn);
+    const int64_t brow = (b * Tn + i) * (int64_t)Tn;
+    for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
+      const float v = grow[j];
+      if (bk1) atomicAdd(h1 + bk1[brow + j], v);
+      if (bkx) { atomicAdd(hx + bkx[brow + j], v); atomicAdd(hy + bky[brow + j], v); }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins1; i += blockDim.x) if (dw1) atomicAdd(dw1 + h * bins1 + i, h1[i] * scale);
+  for (int i = threadIdx.x; i < bins2; i += blockDim.x) {
+    if (dwx) atomicAdd(dwx + h * bins2 + i, hx[i] * scale);
+    if (dwy) atomicAdd(dwy + h * bins2 + i, hy[i] * scale);
+  }
+}
+
+}  // namespace peneo
+using namespace peneo;
+
+extern "C" int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const int32_t* ys, int B, int T,
+                                    const uint8_t* lut1, int lut1_len, int half1, const uint8_t* lut2, int lut2_len,
+                                    int half2, uint8_t* bk1, uint8_t* bkx, uint8_t* bky, peneo_stream_t stream) {
+  PENEO_REQUIRE(B > 0 && T > 0, "peneo_relpos_buckets: empty problem");
+  if (bk1) PENEO_REQUIRE(pos && lut1 && lut1_len > 0, "peneo_relpos_buckets: 1-D inputs missing");
+  if (bkx || bky) PENEO_REQUIRE(bkx && bky && xs && ys && lut2 && lut2_len > 0, "peneo_relpos_buckets: 2-D inputs missing");
+  hipLaunchKernelGGL(relpos_buckets_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, (hipStream_t)stream, pos, xs, ys, T,
+                     lut1, lut1_len, half1, lut2, lut2_len, half2, bk1, bkx, bky);
+  return check_launch("peneo_relpos_buckets");
+}
+
+extern "C" int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky, const float* w1,
+                                     int bins1, const float* wx, const float* wy, int bins2, float scale, int B, int nh, int T,
+                                     void* bias, peneo_stream_t stream) {
+  PENEO_REQUIRE((dtype == PENEO_F32 || dtype == PENEO_BF16) && bias && B > 0 && nh > 0 && T > 0, "peneo_relpos_bias_fwd: bad arguments");
+  PENEO_REQUIRE((bk1 != nullptr) == (w1 != nullptr), "peneo_relpos_bias_fwd: bk1/w1 mismatch");
+  PENEO_REQUIRE((bkx != nullptr) == (wx != nullptr) && (bky != nullptr) == (wy != nullptr) && (bkx != nullptr) == (bky != nullptr),
+                "peneo_relpos_bias_fwd: 2-D inputs mismatch");
+  size_t sh = sizeof(float) * (size_t)nh * (bins1 + 2 * bins2);
+  PENEO_REQUIRE(sh <= 64 * 1024, "peneo_relpos_bias_fwd: tables too large for LDS");
+  dim3 grid((unsigned)((int64_t)B * T));
+  if (dtype == PENEO_BF16)
+    hipLaunchKernelGGL(relpos_bias_fwd_kernel<bf16_t>, grid, dim3(256), sh, (hipStream_t)stream, bk1, bkx, bky, w1, bins1, wx, wy,
+                       bins2, scale, nh, T, (bf16_t*)bias);
+  else
+    hipLaunchKernelGGL(relpos_bias_fwd_kernel<float>, grid, dim3(256), sh, (hipStream_t)stream, bk1, bkx, bky, w1, bins1, wx, wy,
+                       bins2, scale, nh, T, (float*)bias);
+  return check_launch("peneo_relpos_bias_fwd");
+}
+
+extern "C" int peneo_relpos_bias_bwd(const float* g, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky, float* dw1,
+                                     int bins1, float* dwx, float* dwy, int bins2, float scale, int B, int nh, int T,
+                                     peneo_stream_t stream) {
+  PENEO_REQUIRE(g && B > 0 && nh > 0 && T > 0, "peneo_relpos_bias_bwd: bad arguments");
+  PENEO_REQUIRE((bkx != nullptr) == (bky != nullptr), "peneo_relpos_bias_bwd: 2-D inputs mismatch");
+  size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2);
+  int slabs = (T + 31) / 32;
+  dim3 grid((unsigned)((int64_t)B * nh * slabs));
+  hipLaunchKernelGGL(relpos_bias_bwd_kernel, grid, dim3(256), sh, (hipStream_t)stream, g, bk1, bkx, bky, dw1, bins1, dwx, dwy,
+                     bins2, scale, nh, T);
+  return check_launch("peneo_relpos_bias_bwd");
+}

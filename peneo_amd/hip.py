@@ -1,0 +1,164 @@
+"""ctypes binding of libpeneo_hip.so (the C ABI declared in include/peneo_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails this
+module raises — the product path never silently degrades to PyTorch ops or to the oracle.
+PyTorch is used only for device memory (tensors), streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpeneo_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+MAX_HEADS = 8
+
+_vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
+
+
+class PeneoHipError(RuntimeError):
+    pass
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [
+        ("bias", _vp), ("act", _i), ("preact", _vp), ("ld_preact", _i64),
+        ("grad_src", _vp), ("ld_grad", _i64), ("grad_act", _i),
+        ("residual", _vp), ("ld_res", _i64), ("alpha", _f), ("accumulate", _i),
+        ("drop_p", _f), ("drop_seed", _u32),
+    ]
+
+
+class EmbedTables(C.Structure):
+    _fields_ = [("word", _vp), ("type0", _vp), ("pos", _vp), ("x", _vp), ("y", _vp), ("h", _vp), ("w", _vp),
+                ("coord_size", _i), ("shape_size", _i), ("max_2d", _i), ("vocab", _i), ("max_pos", _i)]
+
+
+class EmbedGrads(C.Structure):
+    _fields_ = [("word", _vp), ("type0", _vp), ("pos", _vp), ("x", _vp), ("y", _vp), ("h", _vp), ("w", _vp)]
+
+
+class PairHeadsDesc(C.Structure):
+    _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("w1_packed", _vp), ("b1", _vp),
+                ("w2_packed", _vp), ("b2", _vp)]
+
+
+class PairLoss(C.Structure):
+    _fields_ = [("tags", _vp * MAX_HEADS), ("class_weight", _vp * MAX_HEADS), ("loss_num", _vp), ("loss_den", _vp),
+                ("dlogits", _vp * MAX_HEADS), ("dl_sum", _vp)]
+
+
+class PairDzArgs(C.Structure):
+    _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("dlogits", _vp * MAX_HEADS),
+                ("w2", _vp * MAX_HEADS), ("dw2", _vp * MAX_HEADS), ("db1", _vp),
+                ("scale", _vp)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/peneo_hip.h appears here
+SIGNATURES = {
+    "peneo_version": (_i, []),
+    "peneo_last_error": (C.c_char_p, []),
+    "peneo_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "peneo_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, C.POINTER(GemmEpilogue), _i, _vp,
+                        _sz, _vp]),
+    "peneo_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    "peneo_copy2d": (_i, [_i, _vp, _i64, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
+    "peneo_colsum": (_i, [_i, _vp, _i64, _i64, _i64, _vp, _i, _vp]),
+    "peneo_layernorm_fwd": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _i64, _i, _f, _u32, _vp]),
+    "peneo_layernorm_bwd": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
+                                 _i, _f, _u32, _vp]),
+    "peneo_position_ids": (_i, [_vp, _i, _i, _i64, _vp, _vp]),
+    "peneo_embed_text_fwd": (_i, [_i, _vp, _vp, _vp, C.POINTER(EmbedTables), _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp]),
+    "peneo_embed_text_bwd": (_i, [_i, _vp, _i64, _i64, _vp, _vp, _vp, C.POINTER(EmbedGrads), _i, _i, _i, _i, _i, _i, _i,
+                                  _i64, _vp]),
+    "peneo_im2col_patch16": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "peneo_visual_assemble_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "peneo_visual_assemble_bwd": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "peneo_relpos_buckets": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "peneo_relpos_bias_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
+    "peneo_relpos_bias_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
+    "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
+                            _i64, _vp, _vp, _f, _u32, _vp]),
+    "peneo_pair_heads_w1_packed_bytes": (_sz, [_i, _i, _i]),
+    "peneo_pair_heads_w2_packed_bytes": (_sz, [_i, _i, _i]),
+    "peneo_pair_heads_pack_w1": (_i, [_i, _vp, _i, _i, _vp, _vp]),
+    "peneo_pair_heads_pack_w2": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),
+    "peneo_pair_heads_fwd": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp]),
+    "peneo_pair_x_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "peneo_pair_x_bwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "peneo_pair_dz": (_i, [_i, _vp, _i64, C.POINTER(PairDzArgs), _vp]),
+    "peneo_loss_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """Load libpeneo_hip.so and bind every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PeneoHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C peneo_amd/csrc`).  peneo_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib() -> C.CDLL:
+    return _lib if _lib is not None else load_library()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().peneo_last_error().decode("utf-8", "replace")
+        raise PeneoHipError(f"{what or 'peneo_hip'} failed ({rc}): {msg}")
+
+
+# ----------------------------------------------------------------------------------------------
+# tensor helpers
+# ----------------------------------------------------------------------------------------------
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise PeneoHipError(f"unsupported dtype {t}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PeneoHipError("peneo_hip kernels need device tensors (no CPU path exists)")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr_array(ts: Sequence[Optional[torch.Tensor]], n: int = MAX_HEADS):
+    arr = (_vp * n)()
+    for i, t in enumerate(ts):
+        arr[i] = ptr(t)
+    return arr
