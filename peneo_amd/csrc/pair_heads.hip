@@ -107,7 +107,7 @@ __device__ __forceinline__ Frag<T> load_frag_linear(const char* base, int frag_i
 }
 
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void pair_heads_fwd_kernel(PairFwdParams p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SLAB_BYTES = KS * 64 * FragBytes<T>::v;     // one 32-row slab of W1 in fragment order
   constexpr int NV = SLAB_BYTES / 16;                       // 16-byte vectors per slab
@@ -157,23 +157,22 @@ __global__ __launch_bounds__(256) void pair_heads_fwd_kernel(PairFwdParams p) {
   // ---- stream W1 slabs through LDS (register-staged double buffer) ----
   const uint4* w1g = reinterpret_cast<const uint4*>(p.w1p);
   uint4 stage[VPT];
-  auto gload = [&](int slab) {
-#pragma unroll
-    for (int i = 0; i < VPT; ++i)
-      if (tid + 256 * i < NV) stage[i] = w1g[(int64_t)slab * NV + tid + 256 * i];
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < VPT; ++i)
-      if (tid + 256 * i < NV) *reinterpret_cast<uint4*>(sW + buf * SLAB_BYTES + (tid + 256 * i) * 16) = stage[i];
-  };
-  gload(0);
-  lstore(0);
+#define PH_GLOAD(slab_)                                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < VPT; ++i_) {                                       \
+    if (NV % 256 == 0 || tid + 256 * i_ < NV) stage[i_] = w1g[(int64_t)(slab_) * NV + tid + 256 * i_]; \
+  }
+#define PH_LSTORE(buf_)                                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < VPT; ++i_) {                                       \
+    if (NV % 256 == 0 || tid + 256 * i_ < NV)                                                 \
+      *reinterpret_cast<uint4*>(sW + (buf_) * SLAB_BYTES + (tid + 256 * i_) * 16) = stage[i_]; \
+  }
+  PH_GLOAD(0)
+  PH_LSTORE(0)
   __syncthreads();
   for (int slab = 0; slab < nslab; ++slab) {
     const int buf = slab & 1;
     const bool more = slab + 1 < nslab;
-    if (more) gload(slab + 1);
+    PH_GLOAD(more ? slab + 1 : slab)   // unconditional (a predicated refill sends `stage` to scratch)
     // second-layer fragments for this slab (L2 resident, 2 KiB per wave)
     Frag<T> w2f0 = load_frag_linear<T>(reinterpret_cast<const char*>(p.w2p), slab * 2 + 0, lane);
     Frag<T> w2f1 = load_frag_linear<T>(reinterpret_cast<const char*>(p.w2p), slab * 2 + 1, lane);
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256) void pair_heads_fwd_kernel(PairFwdParams p) {
     Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
     mma_step(w2f0, y0, lg);
     mma_step(w2f1, y1, lg);
-    if (more) lstore(buf ^ 1);
+    PH_LSTORE(buf ^ 1)
     __syncthreads();
   }
 

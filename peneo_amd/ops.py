@@ -1,0 +1,413 @@
+"""Functional wrappers: torch tensors in, libpeneo_hip.so kernels on the current stream, tensors out.
+
+These are 1:1 with the C entry points of include/peneo_hip.h (no autograd here; the
+autograd.Functions in peneo_amd/model compose them).  Nothing falls back to PyTorch math.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+from .hip import ACT_GELU, ACT_NONE, ACT_SILU, BF16, F32, check, dtype_code, lib, ptr, stream
+
+_i64p = C.POINTER(C.c_int64)
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_contiguous():
+        raise hip.PeneoHipError("tensor must be contiguous")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------
+def choose_split_k(M: int, N: int, K: int, dtype: torch.dtype) -> int:
+    """Split the reduction only when the output grid cannot fill the 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    kt = (K + (63 if dtype == torch.bfloat16 else 31)) // (64 if dtype == torch.bfloat16 else 32)
+    if tiles >= 192 or kt < 8:
+        return 1
+    return max(1, min(kt // 4, (512 + tiles - 1) // tiles, 16))
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True,
+         bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+         preact: Optional[torch.Tensor] = None, grad_src: Optional[torch.Tensor] = None, grad_act: int = ACT_NONE,
+         out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, accumulate: bool = False,
+         alpha: float = 1.0, drop_p: float = 0.0, drop_seed: int = 0, split_k: Optional[int] = None) -> torch.Tensor:
+    """C = epilogue(alpha * A.B^T); a, b are 2-D (row stride may exceed the row length)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    if a_kmajor:
+        M, K = a.shape
+    else:
+        K, M = a.shape
+    if b_kmajor:
+        N, Kb = b.shape
+    else:
+        Kb, N = b.shape
+    assert K == Kb, f"inner dims differ: {K} vs {Kb}"
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or a.dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    ep = hip.GemmEpilogue()
+    ep.bias = ptr(bias)
+    ep.act = act
+    if preact is not None:
+        assert preact.dtype == out.dtype and preact.shape == out.shape
+        ep.preact, ep.ld_preact = ptr(preact), preact.stride(0)
+    if grad_src is not None:
+        assert grad_src.dtype == out.dtype and grad_src.shape == out.shape
+        ep.grad_src, ep.ld_grad, ep.grad_act = ptr(grad_src), grad_src.stride(0), grad_act
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape == out.shape
+        ep.residual, ep.ld_res = ptr(residual), residual.stride(0)
+    ep.alpha = alpha
+    ep.accumulate = 1 if accumulate else 0
+    ep.drop_p, ep.drop_seed = drop_p, drop_seed & 0xFFFFFFFF
+    if split_k is None:
+        split_k = choose_split_k(M, N, K, a.dtype)
+    ws, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = lib().peneo_gemm_workspace_bytes(M, N, K, split_k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+    check(lib().peneo_gemm(dtype_code(a.dtype), int(a_kmajor), int(b_kmajor), M, N, K, ptr(a), a.stride(0), ptr(b),
+                           b.stride(0), ptr(out), out.stride(0), dtype_code(out.dtype), C.byref(ep), split_k, ptr(ws),
+                           ws_bytes, stream()), "peneo_gemm")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# element-wise plumbing
+# ----------------------------------------------------------------------------------------------
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _c(src)
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib().peneo_cast(ptr(src), dtype_code(src.dtype), ptr(out), dtype_code(out.dtype), src.numel(), stream()),
+          "peneo_cast")
+    return out
+
+
+def copy2d(src: torch.Tensor, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    assert src.dim() == 2 and src.stride(1) == 1
+    if out is None:
+        out = torch.empty(src.shape, dtype=src.dtype, device=src.device)
+    assert out.shape == src.shape and out.stride(1) == 1
+    check(lib().peneo_copy2d(dtype_code(src.dtype), ptr(src), src.stride(0), ptr(out), out.stride(0), src.shape[0],
+                             src.shape[1], drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_copy2d")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+        accumulate = False
+    check(lib().peneo_colsum(dtype_code(x.dtype), ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), int(accumulate),
+                             stream()), "peneo_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------------------------
+def _rowmap(t: torch.Tensor, H: int) -> Tuple[int, int, int]:
+    """(rows, rows_per_batch, batch_stride) for a [rows, H] or a sliced [B, R, H] tensor."""
+    assert t.stride(-1) == 1 and t.shape[-1] == H
+    if t.dim() == 2:
+        assert t.stride(0) == H
+        return t.shape[0], 0, 0
+    assert t.dim() == 3 and t.stride(1) == H
+    return t.shape[0] * t.shape[1], t.shape[1], t.stride(0)
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None,
+                  drop_p: float = 0.0, drop_seed: int = 0):
+    H = x.shape[-1]
+    rows, xr, xb = _rowmap(x, H)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    orows, yr, yb = _rowmap(out, H)
+    assert orows == rows and out.dtype == x.dtype
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().peneo_layernorm_fwd(dtype_code(x.dtype), ptr(x), xr, xb, ptr(out), yr, yb, ptr(gamma), ptr(beta), eps,
+                                    ptr(mean), ptr(rstd), rows, H, drop_p, drop_seed & 0xFFFFFFFF, stream()),
+          "peneo_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                  dgamma: torch.Tensor, dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop_p: float = 0.0,
+                  drop_seed: int = 0) -> torch.Tensor:
+    H = x.shape[-1]
+    rows, xr, xb = _rowmap(x, H)
+    drows, dr, db = _rowmap(dy, H)
+    assert drows == rows and dy.dtype == x.dtype
+    if dx is None:
+        dx = torch.empty(dy.shape, dtype=x.dtype, device=x.device)
+    _, gr, gb = _rowmap(dx, H)
+    check(lib().peneo_layernorm_bwd(dtype_code(x.dtype), ptr(dy), dr, db, ptr(x), xr, xb, ptr(dx), gr, gb, ptr(gamma),
+                                    ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), rows, H, drop_p,
+                                    drop_seed & 0xFFFFFFFF, stream()), "peneo_layernorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# embeddings
+# ----------------------------------------------------------------------------------------------
+def position_ids(input_ids: torch.Tensor, pad_id: int) -> torch.Tensor:
+    _c(input_ids)
+    B, S = input_ids.shape
+    out = torch.empty((B, S), dtype=torch.int32, device=input_ids.device)
+    check(lib().peneo_position_ids(ptr(input_ids), B, S, pad_id, ptr(out), stream()), "peneo_position_ids")
+    return out
+
+
+def embed_fwd(dtype: torch.dtype, out: torch.Tensor, B: int, S: int, H: int, *, input_ids=None, pos_ids=None, bbox=None,
+              word=None, type0=None, pos=None, x=None, y=None, h=None, w=None, clip_hw: bool = True,
+              status: Optional[torch.Tensor] = None) -> torch.Tensor:
+    tab = hip.EmbedTables()
+    tab.word, tab.type0, tab.pos = ptr(word), ptr(type0), ptr(pos)
+    tab.x, tab.y, tab.h, tab.w = ptr(x), ptr(y), ptr(h), ptr(w)
+    if x is not None:
+        tab.coord_size, tab.shape_size, tab.max_2d = x.shape[1], h.shape[1], x.shape[0]
+    if word is not None:
+        tab.vocab, tab.max_pos = word.shape[0], pos.shape[0]
+    rows, rpb, bs = _rowmap(out, H)
+    assert rows == B * S and out.dtype == dtype
+    check(lib().peneo_embed_text_fwd(dtype_code(dtype), ptr(input_ids), ptr(pos_ids), ptr(bbox), C.byref(tab), B, S, H,
+                                     int(clip_hw), ptr(out), rpb, bs, ptr(status), stream()), "peneo_embed_text_fwd")
+    return out
+
+
+def embed_bwd(d_out: torch.Tensor, B: int, S: int, H: int, *, input_ids=None, pos_ids=None, bbox=None, g_word=None,
+              g_pos=None, g_x=None, g_y=None, g_h=None, g_w=None, clip_hw: bool = True, pad_id: int = 1) -> None:
+    g = hip.EmbedGrads()
+    g.word, g.pos = ptr(g_word), ptr(g_pos)
+    g.x, g.y, g.h, g.w = ptr(g_x), ptr(g_y), ptr(g_h), ptr(g_w)
+    cs = g_x.shape[1] if g_x is not None else 0
+    ss = g_h.shape[1] if g_h is not None else 0
+    m2 = g_x.shape[0] if g_x is not None else 0
+    rows, rpb, bs = _rowmap(d_out, H)
+    assert rows == B * S
+    check(lib().peneo_embed_text_bwd(dtype_code(d_out.dtype), ptr(d_out), rpb, bs, ptr(input_ids), ptr(pos_ids), ptr(bbox),
+                                     C.byref(g), cs, ss, m2, B, S, H, int(clip_hw), pad_id, stream()),
+          "peneo_embed_text_bwd")
+
+
+def im2col_patch16(image: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _c(image)
+    assert image.dtype == torch.float32
+    B, Cc, Hi, Wi = image.shape
+    out = torch.empty((B * (Hi // 16) * (Wi // 16), Cc * 256), dtype=dtype, device=image.device)
+    check(lib().peneo_im2col_patch16(dtype_code(dtype), ptr(image), B, Cc, Hi, Wi, ptr(out), stream()),
+          "peneo_im2col_patch16")
+    return out
+
+
+def visual_assemble_fwd(proj: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int) -> torch.Tensor:
+    npch, H = proj.shape[0] // B, proj.shape[1]
+    vis = torch.empty((B, npch + 1, H), dtype=proj.dtype, device=proj.device)
+    check(lib().peneo_visual_assemble_fwd(dtype_code(proj.dtype), ptr(_c(proj)), ptr(cls), ptr(pos), B, npch, H, ptr(vis),
+                                          stream()), "peneo_visual_assemble_fwd")
+    return vis
+
+
+def visual_assemble_bwd(d_vis: torch.Tensor, d_cls: Optional[torch.Tensor], d_pos: Optional[torch.Tensor]) -> torch.Tensor:
+    B, t, H = d_vis.shape
+    d_proj = torch.empty((B * (t - 1), H), dtype=d_vis.dtype, device=d_vis.device)
+    check(lib().peneo_visual_assemble_bwd(dtype_code(d_vis.dtype), ptr(_c(d_vis)), B, t - 1, H, ptr(d_proj), ptr(d_cls),
+                                          ptr(d_pos), stream()), "peneo_visual_assemble_bwd")
+    return d_proj
+
+
+# ----------------------------------------------------------------------------------------------
+# relative-position bias
+# ----------------------------------------------------------------------------------------------
+def relpos_buckets(pos: Optional[torch.Tensor], xs: Optional[torch.Tensor], ys: Optional[torch.Tensor], B: int, T: int,
+                   lut1: Optional[torch.Tensor], half1: int, lut2: Optional[torch.Tensor], half2: int):
+    dev = (pos if pos is not None else xs).device
+    mk = lambda: torch.empty((B, T, T), dtype=torch.uint8, device=dev)
+    bk1 = mk() if pos is not None else None
+    bkx = mk() if xs is not None else None
+    bky = mk() if ys is not None else None
+    check(lib().peneo_relpos_buckets(ptr(pos), ptr(xs), ptr(ys), B, T, ptr(lut1), lut1.numel() if lut1 is not None else 0,
+                                     half1, ptr(lut2), lut2.numel() if lut2 is not None else 0, half2, ptr(bk1), ptr(bkx),
+                                     ptr(bky), stream()), "peneo_relpos_buckets")
+    return bk1, bkx, bky
+
+
+def relpos_bias_fwd(dtype: torch.dtype, bk1, bkx, bky, w1, wx, wy, scale: float, B: int, nh: int, T: int) -> torch.Tensor:
+    dev = (bk1 if bk1 is not None else bkx).device
+    bias = torch.empty((B, nh, T, T), dtype=dtype, device=dev)
+    check(lib().peneo_relpos_bias_fwd(dtype_code(dtype), ptr(bk1), ptr(bkx), ptr(bky), ptr(w1),
+                                      w1.shape[1] if w1 is not None else 0, ptr(wx), ptr(wy),
+                                      wx.shape[1] if wx is not None else 0, scale, B, nh, T, ptr(bias), stream()),
+          "peneo_relpos_bias_fwd")
+    return bias
+
+
+def relpos_bias_bwd(g: torch.Tensor, bk1, bkx, bky, dw1, dwx, dwy, scale: float) -> None:
+    B, nh, T, _ = g.shape
+    check(lib().peneo_relpos_bias_bwd(ptr(_c(g)), ptr(bk1), ptr(bkx), ptr(bky), ptr(dw1),
+                                      dw1.shape[1] if dw1 is not None else 0, ptr(dwx), ptr(dwy),
+                                      dwx.shape[1] if dwx is not None else 0, scale, B, nh, T, stream()),
+          "peneo_relpos_bias_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int, T: int, d: int, scale: float,
+             bias: Optional[torch.Tensor], key_mask: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0):
+    """q/k/v: 2-D views [B*T, nh*d] with a common row stride (e.g. slices of a fused QKV buffer)."""
+    assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
+    out = torch.empty((B * T, nh * d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), B, nh, T, d, scale, ptr(bias),
+                               ptr(key_mask), ptr(out), out.stride(0), ptr(lse), drop_p, drop_seed & 0xFFFFFFFF, stream()),
+          "peneo_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_mask,
+             dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations)."""
+    H = nh * d
+    dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
+    delta = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    assert out.stride(0) == d_out.stride(0)
+    check(lib().peneo_attn_bwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), ptr(d_out),
+                               out.stride(0), ptr(lse), B, nh, T, d, scale, ptr(bias), ptr(key_mask), ptr(dq), ptr(dk),
+                               ptr(dv), dqkv.stride(0), ptr(g_bias), ptr(delta), drop_p, drop_seed & 0xFFFFFFFF, stream()),
+          "peneo_attn_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------------------------
+# pair heads
+# ----------------------------------------------------------------------------------------------
+def _ptr_list(ts: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = ptr(t)
+    return arr
+
+
+def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence[torch.Tensor]):
+    """w1[h]: [D, D] fp32, w2[h]: [C_h, D] fp32 -> (w1_packed, w2_packed) byte buffers."""
+    nh, D = len(w1), w1[0].shape[1]
+    dc = dtype_code(dtype)
+    dev = w1[0].device
+    p1 = torch.empty(lib().peneo_pair_heads_w1_packed_bytes(dc, nh, D), dtype=torch.uint8, device=dev)
+    p2 = torch.empty(lib().peneo_pair_heads_w2_packed_bytes(dc, nh, D), dtype=torch.uint8, device=dev)
+    classes = (C.c_int * nh)(*[w.shape[0] for w in w2])
+    check(lib().peneo_pair_heads_pack_w1(dc, _ptr_list([_c(w) for w in w1]), nh, D, ptr(p1), stream()),
+          "peneo_pair_heads_pack_w1")
+    check(lib().peneo_pair_heads_pack_w2(dc, _ptr_list([_c(w) for w in w2]), classes, nh, D, ptr(p2), stream()),
+          "peneo_pair_heads_pack_w2")
+    return p1, p2
+
+
+def pair_heads_fwd(ab: torch.Tensor, w1p: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
+                   classes: Sequence[int], *, want_logits: bool = True, tags: Optional[Sequence[torch.Tensor]] = None,
+                   class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False):
+    """ab: [B, N, 2D].  Returns (logits list | None, loss_num, loss_den, dlogits list | None, dl_sum)."""
+    _c(ab)
+    B, N, D2 = ab.shape
+    D = D2 // 2
+    P = N * (N + 1) // 2
+    nh = len(classes)
+    desc = hip.PairHeadsDesc()
+    desc.num_heads, desc.D = nh, D
+    for h, c in enumerate(classes):
+        desc.classes[h] = c
+    desc.w1_packed, desc.b1, desc.w2_packed, desc.b2 = ptr(w1p), ptr(b1), ptr(w2p), ptr(b2)
+    logits = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes] if want_logits else None
+    lp = _ptr_list(logits) if logits is not None else None
+    loss = None
+    num = den = dls = None
+    dlog = None
+    if tags is not None:
+        loss = hip.PairLoss()
+        num = torch.zeros(nh, dtype=torch.float32, device=ab.device)
+        den = torch.zeros(nh, dtype=torch.float32, device=ab.device)
+        dls = torch.zeros(sum(classes), dtype=torch.float32, device=ab.device)
+        if want_dlogits:
+            dlog = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes]
+        for h in range(nh):
+            assert tags[h].dtype == torch.int64 and tags[h].shape == (B, P)
+            loss.tags[h] = ptr(_c(tags[h]))
+            loss.class_weight[h] = ptr(class_weights[h]) if class_weights is not None else None
+            if dlog is not None:
+                loss.dlogits[h] = ptr(dlog[h])
+        loss.loss_num, loss.loss_den, loss.dl_sum = ptr(num), ptr(den), ptr(dls)
+    check(lib().peneo_pair_heads_fwd(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
+                                     C.byref(loss) if loss is not None else None, stream()), "peneo_pair_heads_fwd")
+    return logits, num, den, dlog, dls
+
+
+def pair_x_fwd(ab_doc: torch.Tensor, i0: int, i1: int, out: torch.Tensor) -> torch.Tensor:
+    N, D2 = ab_doc.shape
+    check(lib().peneo_pair_x_fwd(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(out), stream()),
+          "peneo_pair_x_fwd")
+    return out
+
+
+def pair_x_bwd(ab_doc: torch.Tensor, i0: int, i1: int, dx: torch.Tensor, d_ab_doc: torch.Tensor) -> None:
+    N, D2 = ab_doc.shape
+    assert d_ab_doc.dtype == torch.float32 and d_ab_doc.shape == ab_doc.shape
+    check(lib().peneo_pair_x_bwd(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(dx), ptr(_c(d_ab_doc)),
+                                 stream()), "peneo_pair_x_bwd")
+
+
+def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor],
+            w2: Sequence[torch.Tensor], dw2: Sequence[torch.Tensor], db1: torch.Tensor, scale: torch.Tensor) -> None:
+    a = hip.PairDzArgs()
+    a.num_heads, a.D = len(classes), D
+    for h, c in enumerate(classes):
+        a.classes[h] = c
+        a.dlogits[h], a.w2[h], a.dw2[h] = ptr(dlogits[h]), ptr(w2[h]), ptr(dw2[h])
+    a.db1, a.scale = ptr(db1), ptr(scale)
+    check(lib().peneo_pair_dz(dtype_code(z.dtype), ptr(z), npairs, C.byref(a), stream()), "peneo_pair_dz")
+
+
+def loss_finish(num: torch.Tensor, den: torch.Tensor, ratio: torch.Tensor):
+    nh = num.numel()
+    out = torch.empty(nh + 1, dtype=torch.float32, device=num.device)
+    scale = torch.empty(nh, dtype=torch.float32, device=num.device)
+    check(lib().peneo_loss_finish(ptr(num), ptr(den), ptr(ratio), nh, ptr(out), ptr(scale), stream()), "peneo_loss_finish")
+    return out, scale
+
+
+def weighted_ce(logits: torch.Tensor, tags: torch.Tensor, cw: Optional[torch.Tensor], want_dlogits: bool = False):
+    _c(logits)
+    C_ = logits.shape[-1]
+    rows = logits.numel() // C_
+    num = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    den = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_dlogits else None
+    check(lib().peneo_weighted_ce(ptr(logits), ptr(_c(tags)), ptr(cw), rows, C_, ptr(num), ptr(den), ptr(dl), stream()),
+          "peneo_weighted_ce")
+    return num, den, dl
+
+
+def spots_compact(logits: torch.Tensor, N: int, max_spots: int = 4096):
+    """[P, C] fp32 logits -> (spots int32 [n, 3] (i, j, tag), scores fp32 [n]) in increasing p order."""
+    _c(logits)
+    P, C_ = logits.shape
+    spots = torch.empty((max_spots, 3), dtype=torch.int32, device=logits.device)
+    scores = torch.empty(max_spots, dtype=torch.float32, device=logits.device)
+    count = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    check(lib().peneo_spots_compact(ptr(logits), P, C_, N, ptr(spots), ptr(scores), ptr(count), max_spots, stream()),
+          "peneo_spots_compact")
+    n = int(count.item())
+    if n > max_spots:
+        return spots_compact(logits, N, max_spots=n)
+    return spots[:n], scores[:n]

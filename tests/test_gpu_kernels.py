@@ -1,0 +1,421 @@
+"""Per-kernel parity: every libpeneo_hip.so entry point against a plain fp32 PyTorch statement of the same op.
+
+fp32 mode (exact fp32 MFMA) is held to ~1e-5 relative; bf16 mode is compared with the fp32
+result computed from the *same bf16-rounded inputs* (so only accumulation order and the output
+rounding differ) at ~1e-2 relative.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from peneo_amd import ops as o
+    from peneo_amd import hip
+    hip.load_library()
+    return o
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2e-2
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(709, 200, 136), (128, 128, 64), (300, 768, 768), (33, 24, 8)])
+def test_gemm_layouts(ops, dtype, ak, bk, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(DEV).to(dtype)
+    b = torch.randn(N, K, generator=g).to(DEV).to(dtype)
+    ref = a.float() @ b.float().t()
+    A = a if ak else a.t().contiguous()
+    Bm = b if bk else b.t().contiguous()
+    out = ops.gemm(A, Bm, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32)
+    assert rel_err(out, ref) < tol(dtype), (rel_err(out, ref))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_is_transpose_detecting(ops, dtype):
+    # A = identity against an asymmetric B catches swapped C rows/cols
+    n = 128
+    a = torch.eye(n, device=DEV, dtype=dtype)
+    b = (torch.arange(n * n, device=DEV, dtype=torch.float32).view(n, n) % 251).to(dtype)
+    out = ops.gemm(a, b, out_dtype=torch.float32)
+    assert torch.equal(out, b.float().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    from peneo_amd.hip import ACT_GELU, ACT_SILU
+    M, N, K = 260, 192, 96
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(DEV).to(dtype)
+    b = (torch.randn(N, K, generator=g) * 0.2).to(DEV).to(dtype)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV).to(dtype)
+    z_ref = a.float() @ b.float().t() + bias
+    pre = torch.empty(M, N, device=DEV, dtype=dtype)
+    out = ops.gemm(a, b, bias=bias, act=ACT_GELU, residual=res, preact=pre)
+    assert rel_err(pre, z_ref) < tol(dtype)
+    assert rel_err(out, F.gelu(z_ref) + res.float()) < tol(dtype)
+    # dgrad-style: multiply by SiLU'(src)
+    src = torch.randn(M, N, generator=g).to(DEV).to(dtype)
+    out2 = ops.gemm(a, b, grad_src=src, grad_act=ACT_SILU)
+    s = torch.sigmoid(src.float())
+    assert rel_err(out2, (a.float() @ b.float().t()) * (s * (1 + src.float() * (1 - s)))) < tol(dtype)
+    # accumulate into fp32 + split-k
+    acc = torch.ones(M, N, device=DEV)
+    ops.gemm(a, b, out=acc, accumulate=True, split_k=3)
+    assert rel_err(acc, 1 + a.float() @ b.float().t()) < tol(dtype)
+    # alpha
+    out3 = ops.gemm(a, b, alpha=0.25, out_dtype=torch.float32)
+    assert rel_err(out3, 0.25 * (a.float() @ b.float().t())) < tol(dtype)
+
+
+def test_gemm_dropout_mask_is_reproducible(ops):
+    M, N, K = 256, 128, 64
+    a = torch.randn(M, K, device=DEV)
+    b = torch.randn(N, K, device=DEV)
+    base = ops.gemm(a, b)
+    d1 = ops.gemm(a, b, drop_p=0.25, drop_seed=77)
+    d2 = ops.gemm(a, b, drop_p=0.25, drop_seed=77)
+    d3 = ops.gemm(a, b, drop_p=0.25, drop_seed=78)
+    assert torch.equal(d1, d2) and not torch.equal(d1, d3)
+    kept = d1 != 0
+    frac = float(kept.float().mean())
+    assert 0.72 < frac < 0.78
+    assert rel_err(d1[kept], base[kept] / 0.75) < 1e-5
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from peneo_amd.hip import PeneoHipError
+    a = torch.randn(8, 8, device=DEV)
+    with pytest.raises(PeneoHipError):
+        ops.gemm(a, a, out=torch.empty(8, 8, device=DEV, dtype=torch.bfloat16), accumulate=True)
+
+
+# ---------------------------------------------------------------------------------------------- element-wise
+def test_cast_copy_colsum(ops):
+    x = torch.randn(1000, 77, device=DEV)
+    xb = ops.cast(x, torch.bfloat16)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(xb, torch.float32), xb.float())
+    big = torch.randn(50, 200, device=DEV)
+    sub = big[:, 10:90]
+    assert torch.equal(ops.copy2d(sub), sub)
+    for dt in DTYPES:
+        y = torch.randn(1300, 200, device=DEV).to(dt)
+        assert rel_err(ops.colsum(y), y.float().sum(0)) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H", [768, 64, 1024, 24])
+def test_layernorm_fwd_bwd(ops, dtype, H):
+    rows = 517
+    g = torch.Generator().manual_seed(H)
+    x = (torch.randn(rows, H, generator=g) * 2 + 0.3).to(DEV).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(H, generator=g)).to(DEV)
+    dy = torch.randn(rows, H, generator=g).to(DEV).to(dtype)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (H,), gr, br, 1e-5)
+    yr.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    assert rel_err(y, yr) < tol(dtype)
+    dg = torch.zeros(H, device=DEV)
+    db = torch.zeros(H, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
+    assert rel_err(dx, xr.grad) < tol(dtype)
+    assert rel_err(dg, gr.grad) < 5e-4 and rel_err(db, br.grad) < 5e-4
+
+
+def test_layernorm_strided_rows(ops):
+    B, T, S, H = 3, 50, 20, 64
+    buf = torch.randn(B, T, H, device=DEV)
+    gamma, beta = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    ref = buf.clone()
+    ref[:, :S] = F.layer_norm(buf[:, :S], (H,), gamma, beta, 1e-5)
+    ops.layernorm_fwd(buf[:, :S], gamma, beta, 1e-5, out=buf[:, :S])
+    assert rel_err(buf, ref) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- embeddings
+def test_position_ids(ops):
+    ids = torch.randint(3, 100, (4, 57), device=DEV)
+    ids[0, 40:] = 1
+    ids[2, 10:] = 1
+    ids[3, :] = 1
+    mask = ids.ne(1).int()
+    ref = (torch.cumsum(mask, 1).type_as(mask) * mask).long() + 1
+    assert torch.equal(ops.position_ids(ids, 1).long(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_fwd_bwd(ops, dtype):
+    B, S, H, cs, ss, V, MP = 2, 37, 64, 11, 10, 300, 66
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(3, V, (B, S), generator=g)
+    ids[1, 30:] = 1
+    bbox = torch.randint(0, 500, (B, S, 4), generator=g)
+    bbox[..., 2] += bbox[..., 0]
+    bbox[..., 3] += bbox[..., 1]
+    tabs = {n: torch.randn(s, generator=g).to(DEV) for n, s in
+            dict(word=(V, H), type=(1, H), pos=(MP, H), x=(1024, cs), y=(1024, cs), h=(1024, ss), w=(1024, ss)).items()}
+    ids, bbox = ids.to(DEV), bbox.to(DEV)
+    pid = ops.position_ids(ids, 1)
+    leaf = {n: t.clone().requires_grad_(True) for n, t in tabs.items()}
+    ref = (F.embedding(ids, leaf["word"], padding_idx=1) + leaf["type"][0] + F.embedding(pid.long(), leaf["pos"], padding_idx=1)
+           + torch.cat([F.embedding(bbox[..., 0], leaf["x"]), F.embedding(bbox[..., 1], leaf["y"]),
+                        F.embedding(bbox[..., 2], leaf["x"]), F.embedding(bbox[..., 3], leaf["y"]),
+                        F.embedding((bbox[..., 3] - bbox[..., 1]).clip(0, 1023), leaf["h"]),
+                        F.embedding((bbox[..., 2] - bbox[..., 0]).clip(0, 1023), leaf["w"])], -1))
+    out = torch.empty(B, S, H, device=DEV, dtype=dtype)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.embed_fwd(dtype, out, B, S, H, input_ids=ids, pos_ids=pid, bbox=bbox, word=tabs["word"], type0=tabs["type"][0],
+                  pos=tabs["pos"], x=tabs["x"], y=tabs["y"], h=tabs["h"], w=tabs["w"], status=status)
+    assert int(status) == 0
+    assert rel_err(out, ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+    d_out = torch.randn(B, S, H, generator=g).to(DEV).to(dtype)
+    ref.backward(d_out.float())
+    grads = {n: torch.zeros_like(t) for n, t in tabs.items()}
+    ops.embed_bwd(d_out, B, S, H, input_ids=ids, pos_ids=pid, bbox=bbox, g_word=grads["word"], g_pos=grads["pos"],
+                  g_x=grads["x"], g_y=grads["y"], g_h=grads["h"], g_w=grads["w"], pad_id=1)
+    for n in ("word", "pos", "x", "y", "h", "w"):
+        assert rel_err(grads[n], leaf[n].grad) < 1e-4, n
+    # out-of-range coordinate -> status flag (the reference raises IndexError)
+    bad = bbox.clone()
+    bad[0, 3, 2] = 1500
+    ops.embed_fwd(dtype, out, B, S, H, input_ids=ids, pos_ids=pid, bbox=bad, word=tabs["word"], type0=tabs["type"][0],
+                  pos=tabs["pos"], x=tabs["x"], y=tabs["y"], h=tabs["h"], w=tabs["w"], status=status)
+    assert int(status) == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patch_embed_pieces(ops, dtype):
+    B, H = 2, 64
+    img = torch.randn(B, 3, 224, 224, device=DEV)
+    w = torch.randn(H, 3, 16, 16, device=DEV) * 0.05
+    bias = torch.randn(H, device=DEV)
+    cls, pos = torch.randn(H, device=DEV), torch.randn(197, H, device=DEV)
+    patches = ops.im2col_patch16(img, dtype)
+    proj = ops.gemm(patches, w.view(H, -1).to(dtype).contiguous(), bias=bias)
+    ref = F.conv2d(img.to(dtype).float(), w.to(dtype).float(), bias, stride=16).flatten(2).transpose(1, 2)
+    assert rel_err(proj.view(B, 196, H), ref) < tol(dtype)
+    vis = ops.visual_assemble_fwd(proj, cls, pos, B)
+    refv = torch.cat([cls.expand(B, 1, H), proj.float().view(B, 196, H)], 1) + pos
+    assert rel_err(vis, refv) < tol(dtype)
+    dv = torch.randn(B, 197, H, device=DEV).to(dtype)
+    dc, dp = torch.zeros(H, device=DEV), torch.zeros(197, H, device=DEV)
+    dproj = ops.visual_assemble_bwd(dv, dc, dp)
+    assert torch.equal(dproj.view(B, 196, H), dv[:, 1:])
+    assert rel_err(dp, dv.float().sum(0)) < 1e-5 and rel_err(dc, dv.float()[:, 0].sum(0)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- rel-pos bias
+def test_relpos_buckets_and_bias(ops):
+    from oracle import peneo_oracle as O
+    from peneo_amd.model.relpos import bucket_lut
+    B, T, nh = 2, 237, 4
+    g = torch.Generator().manual_seed(11)
+    pos = torch.cat([torch.arange(40), torch.arange(197)]).repeat(B, 1)
+    xs = torch.randint(0, 1001, (B, T), generator=g)
+    ys = torch.randint(0, 1001, (B, T), generator=g)
+    lut1, lut2 = bucket_lut(32, 128, 1024).to(DEV), bucket_lut(64, 256, 1024).to(DEV)
+    bk1, bkx, bky = ops.relpos_buckets(pos.int().to(DEV), xs.int().to(DEV), ys.int().to(DEV), B, T, lut1, 16, lut2, 32)
+    r1 = O.relative_position_bucket(pos.unsqueeze(-2) - pos.unsqueeze(-1), 32, 128)
+    rx = O.relative_position_bucket(xs.unsqueeze(-2) - xs.unsqueeze(-1), 64, 256)
+    ry = O.relative_position_bucket(ys.unsqueeze(-2) - ys.unsqueeze(-1), 64, 256)
+    assert torch.equal(bk1.cpu().long(), r1) and torch.equal(bkx.cpu().long(), rx) and torch.equal(bky.cpu().long(), ry)
+    w1 = torch.randn(nh, 32, generator=g).to(DEV)
+    wx, wy = torch.randn(nh, 64, generator=g).to(DEV), torch.randn(nh, 64, generator=g).to(DEV)
+    scale = 0.25
+    bias = ops.relpos_bias_fwd(torch.float32, bk1, bkx, bky, w1, wx, wy, scale, B, nh, T)
+    ref = scale * (w1.t()[r1.to(DEV)] + wx.t()[rx.to(DEV)] + wy.t()[ry.to(DEV)]).permute(0, 3, 1, 2)
+    assert rel_err(bias, ref) < 1e-6
+    gg = torch.randn(B, nh, T, T, generator=g).to(DEV)
+    d1, dx, dy = torch.zeros_like(w1), torch.zeros_like(wx), torch.zeros_like(wy)
+    ops.relpos_bias_bwd(gg, bk1, bkx, bky, d1, dx, dy, scale)
+    w1r, wxr, wyr = (t.clone().requires_grad_(True) for t in (w1, wx, wy))
+    (scale * (w1r.t()[r1.to(DEV)] + wxr.t()[rx.to(DEV)] + wyr.t()[ry.to(DEV)]).permute(0, 3, 1, 2) * gg).sum().backward()
+    assert rel_err(d1, w1r.grad) < 1e-4 and rel_err(dx, wxr.grad) < 1e-4 and rel_err(dy, wyr.grad) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, bias, mask, scale):
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    if bias is not None:
+        s = s + bias
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    p = torch.softmax(s, -1)
+    return torch.einsum("bhqk,bhkd->bhqd", p, v)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,nh,T,d", [(2, 3, 237, 16), (1, 2, 709, 64), (2, 2, 64, 30)])
+def test_attention_fwd_bwd(ops, dtype, B, nh, T, d):
+    g = torch.Generator().manual_seed(T + d)
+    H = nh * d
+    qkv = (torch.randn(B * T, 3 * H, generator=g)).to(DEV).to(dtype)
+    bias = (0.5 * torch.randn(B, nh, T, T, generator=g)).to(DEV).to(dtype)
+    mask = torch.ones(B, T, dtype=torch.int32)
+    mask[0, T // 3: T // 2] = 0
+    mask = mask.to(DEV)
+    scale = 1.0 / math.sqrt(d)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    leaf = qkv.float().clone().requires_grad_(True)
+    br = bias.float().clone().requires_grad_(True)
+    hd = lambda t: t.view(B, T, nh, d).permute(0, 2, 1, 3)
+    ref = _attn_ref(hd(leaf[:, :H]), hd(leaf[:, H:2 * H]), hd(leaf[:, 2 * H:]), br, mask, scale)
+    ref2d = ref.permute(0, 2, 1, 3).reshape(B * T, H)
+    out, lse = ops.attn_fwd(q, k, v, B, nh, T, d, scale, bias, mask)
+    assert rel_err(out, ref2d) < tol(dtype), rel_err(out, ref2d)
+    d_out = torch.randn(B * T, H, generator=g).to(DEV).to(dtype)
+    ref2d.backward(d_out.float())
+    dqkv = torch.empty_like(qkv)
+    gbias = torch.zeros(B, nh, T, T, device=DEV)
+    ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, scale, bias, mask, dqkv, gbias)
+    t = 3e-5 if dtype == torch.float32 else 4e-2
+    assert rel_err(dqkv[:, 2 * H:], leaf.grad[:, 2 * H:]) < t, "dv"
+    assert rel_err(dqkv[:, H:2 * H], leaf.grad[:, H:2 * H]) < t, "dk"
+    assert rel_err(dqkv[:, :H], leaf.grad[:, :H]) < t, "dq"
+    assert rel_err(gbias, br.grad) < t, "dbias"
+    # accumulation semantics of the bias gradient
+    ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, scale, bias, mask, dqkv, gbias)
+    assert rel_err(gbias, 2 * br.grad) < t
+
+
+def test_attention_without_bias_or_mask(ops):
+    B, nh, T, d = 1, 2, 100, 32
+    qkv = torch.randn(B * T, 3 * nh * d, device=DEV)
+    H = nh * d
+    out, _ = ops.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, T, d, 0.2, None, None)
+    hd = lambda t: t.view(B, T, nh, d).permute(0, 2, 1, 3)
+    ref = _attn_ref(hd(qkv[:, :H]), hd(qkv[:, H:2 * H]), hd(qkv[:, 2 * H:]), None, None, 0.2)
+    assert rel_err(out, ref.permute(0, 2, 1, 3).reshape(B * T, H)) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- pair heads
+def _pair_ref(ab, w1, b1, w2, b2):
+    B, N, D2 = ab.shape
+    D = D2 // 2
+    ii, jj = torch.triu_indices(N, N, device=ab.device)
+    x = F.silu(ab[:, ii, :D] + ab[:, jj, D:])
+    return [F.linear(F.silu(F.linear(x, a, b)), c, d) for a, b, c, d in zip(w1, b1, w2, b2)], x
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,D", [(39, 32), (71, 96), (130, 384)])
+def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
+    B, classes = 2, [2, 3, 3, 3, 3]
+    g = torch.Generator().manual_seed(N)
+    ab = torch.randn(B, N, 2 * D, generator=g).to(DEV).to(dtype)
+    w1 = [(torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV) for _ in classes]
+    b1 = [0.1 * torch.randn(D, generator=g).to(DEV) for _ in classes]
+    w2 = [(torch.randn(c, D, generator=g) / math.sqrt(D)).to(DEV) for c in classes]
+    b2 = [0.1 * torch.randn(c, generator=g).to(DEV) for c in classes]
+    rd = lambda t: t.to(dtype).float()
+    ref, _ = _pair_ref(ab.float(), [rd(w) for w in w1], b1, [rd(w) for w in w2], b2)
+    p1, p2 = ops.pair_heads_pack(dtype, w1, w2)
+    P = N * (N + 1) // 2
+    tags = [torch.randint(0, c, (B, P), generator=g).to(DEV) for c in classes]
+    cw = [torch.tensor([1.0, 10.0, 10.0][:c], device=DEV) for c in classes]
+    logits, num, den, dlog, dls = ops.pair_heads_fwd(ab, p1, torch.cat(b1), p2, torch.cat(b2), classes, tags=tags,
+                                                      class_weights=cw, want_dlogits=True)
+    for h in range(5):
+        assert rel_err(logits[h], ref[h]) < tol(dtype), (h, rel_err(logits[h], ref[h]))
+        lr = logits[h].clone().requires_grad_(True)
+        loss_sum = F.cross_entropy(lr.view(-1, classes[h]), tags[h].view(-1), weight=cw[h], reduction="sum")
+        loss_sum.backward()
+        wsum = cw[h][tags[h].view(-1)].sum()
+        assert abs(float(num[h]) - float(loss_sum)) / float(loss_sum) < 1e-4
+        assert abs(float(den[h]) - float(wsum)) / float(wsum) < 1e-5
+        assert rel_err(dlog[h], lr.grad) < 1e-4
+    assert rel_err(dls, torch.cat([d.sum((0, 1)) for d in dlog])) < 1e-3
+    out, scale = ops.loss_finish(num, den, torch.ones(5, device=DEV))
+    assert abs(float(out[5]) - float((num / den).sum())) < 1e-5
+    # loss-only call (no logits written) agrees
+    _, num2, den2, _, _ = ops.pair_heads_fwd(ab, p1, torch.cat(b1), p2, torch.cat(b2), classes, want_logits=False,
+                                             tags=tags, class_weights=cw)
+    assert rel_err(num2, num) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pair_backward_blocks(ops, dtype):
+    N, D, classes = 45, 128, [2, 3, 3, 3, 3]
+    g = torch.Generator().manual_seed(9)
+    ab = torch.randn(N, 2 * D, generator=g).to(DEV).to(dtype)
+    ii, jj = torch.triu_indices(N, N, device=DEV)
+    i0, i1 = 7, 30
+    p0, p1 = i0 * N - i0 * (i0 - 1) // 2, i1 * N - i1 * (i1 - 1) // 2
+    npairs = p1 - p0
+    abr = ab.float().clone().requires_grad_(True)
+    xr = F.silu(abr[ii, :D] + abr[jj, D:])[p0:p1]
+    x = torch.empty(npairs, D, device=DEV, dtype=dtype)
+    ops.pair_x_fwd(ab, i0, i1, x)
+    assert rel_err(x, xr) < tol(dtype)
+    dx = torch.randn(npairs, D, generator=g).to(DEV).to(dtype)
+    xr.backward(dx.float())
+    dab = torch.zeros(N, 2 * D, device=DEV)
+    ops.pair_x_bwd(ab, i0, i1, dx, dab)
+    assert rel_err(dab, abr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    # dz block
+    nh = len(classes)
+    z = torch.randn(npairs, nh * D, generator=g).to(DEV).to(dtype)
+    w2 = [torch.randn(c, D, generator=g).to(DEV) for c in classes]
+    dl = [torch.randn(npairs, c, generator=g).to(DEV) for c in classes]
+    scale = torch.rand(nh, generator=g).to(DEV) + 0.5
+    zr = z.float().clone().requires_grad_(True)
+    w2r = [w.clone().requires_grad_(True) for w in w2]
+    tot = 0
+    for h in range(nh):
+        y = F.silu(zr[:, h * D:(h + 1) * D])
+        tot = tot + ((y @ w2r[h].t()) * dl[h] * scale[h]).sum()
+    tot.backward()
+    dw2 = [torch.zeros_like(w) for w in w2]
+    db1 = torch.zeros(nh * D, device=DEV)
+    zz = z.clone()
+    ops.pair_dz(zz, npairs, D, classes, dl, w2, dw2, db1, scale)
+    t = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(zz, zr.grad) < t
+    assert rel_err(db1, zr.grad.sum(0)) < t
+    for h in range(nh):
+        assert rel_err(dw2[h], w2r[h].grad) < t
+
+
+def test_weighted_ce_and_spots(ops):
+    from oracle import peneo_oracle as O
+    N = 40
+    P = N * (N + 1) // 2
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(P, 3, generator=g)
+    logits[:, 0] += 2.5
+    tags = torch.randint(0, 3, (P,), generator=g)
+    cw = torch.tensor([1.0, 10.0, 10.0])
+    num, den, dl = ops.weighted_ce(logits.to(DEV), tags.to(DEV), cw.to(DEV), want_dlogits=True)
+    lr = logits.clone().requires_grad_(True)
+    ls = F.cross_entropy(lr, tags, weight=cw, reduction="sum")
+    ls.backward()
+    assert abs(float(num) - float(ls)) / float(ls) < 1e-5 and rel_err(dl.cpu(), lr.grad) < 1e-5
+    spots, scores = ops.spots_compact(logits.to(DEV), N, max_spots=16)  # forces the regrow path
+    ref = O.spots_from_logits(logits)
+    assert [tuple(r) for r in spots.cpu().tolist()] == [(i, j, t) for i, j, t, _ in ref]
+    assert rel_err(scores.cpu(), torch.tensor([s for *_, s in ref])) < 1e-5
