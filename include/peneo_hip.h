@@ -87,6 +87,11 @@ int peneo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t
 /* dst[r, c] = src[r, c] for a strided 2-D block (row strides in elements), with optional dropout */
 int peneo_copy2d(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
                  float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+/* batched variant: logical row r of side X lives at (r / X_rpb) * X_bstride + (r % X_rpb) * ld_X elements
+ * (X_rpb = 0: r * ld_X).  Used for the CLS / visual-token crop of model/modeling_peneo.py:138-163. */
+int peneo_copy_rows(int dtype, const void* src, int64_t src_rpb, int64_t src_bstride, int64_t ld_src,
+                    void* dst, int64_t dst_rpb, int64_t dst_bstride, int64_t ld_dst, int64_t rows, int64_t cols,
+                    float drop_p, uint32_t drop_seed, peneo_stream_t stream);
 /* out[n] (+)= sum_m x[m, n]   (bias gradients) */
 int peneo_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,
                  peneo_stream_t stream);

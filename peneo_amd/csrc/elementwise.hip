@@ -48,6 +48,22 @@ __global__ void copy2d_kernel(int dt, const void* src, int64_t lds_, void* dst, 
   }
 }
 
+// rows of a batched, strided 2-D view: row r lives at (r / rpb) * bstride + (r % rpb) * ld  (rpb = 0: r * ld)
+__global__ void copy_rows_kernel(int dt, const void* src, int64_t s_rpb, int64_t s_bs, int64_t s_ld, void* dst, int64_t d_rpb,
+                                 int64_t d_bs, int64_t d_ld, int64_t rows, int64_t cols, float drop_p, uint32_t seed) {
+  const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / cols, c = i % cols;
+    int64_t so = (s_rpb > 0 ? (r / s_rpb) * s_bs + (r % s_rpb) * s_ld : r * s_ld) + c;
+    int64_t dof = (d_rpb > 0 ? (r / d_rpb) * d_bs + (r % d_rpb) * d_ld : r * d_ld) + c;
+    float v = ld_any(src, dt, so);
+    if (drop_p > 0.f) v = dropout_keep(seed, (uint64_t)i, thresh) ? v * keep_scale : 0.f;
+    st_any(dst, dt, dof, v);
+  }
+}
+
 // block = 64 columns x 4 row lanes; each block reduces ROWS_PER_BLOCK rows and adds into out.
 constexpr int CS_ROWS = 512;
 __global__ __launch_bounds__(256) void colsum_kernel(int dt, const void* x, int64_t ldx, int64_t M, int64_t N, float* out) {
@@ -93,6 +109,20 @@ extern "C" int peneo_copy2d(int dtype, const void* src, int64_t ld_src, void* ds
   hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dtype, src, ld_src, dst,
                      ld_dst, rows, cols, drop_p, drop_seed);
   return check_launch("peneo_copy2d");
+}
+
+extern "C" int peneo_copy_rows(int dtype, const void* src, int64_t src_rpb, int64_t src_bstride, int64_t ld_src, void* dst,
+                               int64_t dst_rpb, int64_t dst_bstride, int64_t ld_dst, int64_t rows, int64_t cols, float drop_p,
+                               uint32_t drop_seed, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype), "peneo_copy_rows: bad dtype");
+  if (rows <= 0 || cols <= 0) return PENEO_OK;
+  PENEO_REQUIRE(src && dst && ld_src >= cols && ld_dst >= cols, "peneo_copy_rows: bad arguments");
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_copy_rows: drop_p out of range");
+  int64_t blocks = (rows * cols + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dtype, src, src_rpb,
+                     src_bstride, ld_src, dst, dst_rpb, dst_bstride, ld_dst, rows, cols, drop_p, drop_seed);
+  return check_launch("peneo_copy_rows");
 }
 
 extern "C" int peneo_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,

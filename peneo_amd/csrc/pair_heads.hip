@@ -329,11 +329,11 @@ struct DzParams {
   peneo_pair_dz_args a;
 };
 constexpr int DZ_ROWS = 256;  // pairs per block
-// grid.x = nh*D/128 column blocks (each inside one head), grid.y = row blocks; thread = one hidden column
+// grid.x = nh*D/blockDim column blocks (each inside one head), grid.y = row blocks; thread = one hidden column
 template <typename T>
 __global__ __launch_bounds__(128) void pair_dz_kernel(T* z, int64_t npairs, DzParams pp) {
   const peneo_pair_dz_args& a = pp.a;
-  const int col = blockIdx.x * 128 + threadIdx.x;   // hidden column in [0, nh*D)
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;   // hidden column in [0, nh*D)
   const int h = col / a.D, k = col - h * a.D;
   const int C = a.classes[h];
   const int ncol = a.num_heads * a.D;
@@ -584,16 +584,17 @@ extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int
 
 extern "C" int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, peneo_stream_t stream) {
   PENEO_REQUIRE(ok_dt(dtype) && z_inout && args && npairs > 0, "peneo_pair_dz: bad arguments");
-  PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D % 128 == 0,
-                "peneo_pair_dz: D must be a multiple of 128 (got %d)", args->D);
+  PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D > 0 && args->D % 32 == 0,
+                "peneo_pair_dz: D must be a multiple of 32 (got %d)", args->D);
+  const int bs = args->D % 128 == 0 ? 128 : (args->D % 64 == 0 ? 64 : 32);
   PENEO_REQUIRE(args->db1 && args->scale, "peneo_pair_dz: null db1/scale");
   for (int h = 0; h < args->num_heads; ++h)
     PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->dw2[h] && args->classes[h] >= 1 && args->classes[h] <= 4,
                   "peneo_pair_dz: head %d arguments invalid", h);
   DzParams pp; pp.a = *args;
-  dim3 grid(args->num_heads * args->D / 128, (unsigned)((npairs + DZ_ROWS - 1) / DZ_ROWS));
-  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_dz_kernel<bf16_t>, grid, dim3(128), 0, (hipStream_t)stream, (bf16_t*)z_inout, npairs, pp);
-  else hipLaunchKernelGGL(pair_dz_kernel<float>, grid, dim3(128), 0, (hipStream_t)stream, (float*)z_inout, npairs, pp);
+  dim3 grid(args->num_heads * args->D / bs, (unsigned)((npairs + DZ_ROWS - 1) / DZ_ROWS));
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_dz_kernel<bf16_t>, grid, dim3(bs), 0, (hipStream_t)stream, (bf16_t*)z_inout, npairs, pp);
+  else hipLaunchKernelGGL(pair_dz_kernel<float>, grid, dim3(bs), 0, (hipStream_t)stream, (float*)z_inout, npairs, pp);
   return check_launch("peneo_pair_dz");
 }
 

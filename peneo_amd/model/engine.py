@@ -1,0 +1,94 @@
+"""Shared runtime pieces of the HIP model path: working-precision weight cache and dropout seeds."""
+from __future__ import annotations
+
+import threading
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+
+
+class WeightCache:
+    """fp32 master parameters -> working-precision copies (cast / concatenated / re-packed on the
+    device by libpeneo_hip kernels), refreshed whenever a parameter's ``_version`` changes, i.e.
+    after every optimizer step, and reused as-is during evaluation."""
+
+    def __init__(self) -> None:
+        self._store: Dict[Tuple, Tuple[Tuple, object]] = {}
+
+    @staticmethod
+    def _stamp(params: Sequence[torch.Tensor]) -> Tuple:
+        return tuple((p.data_ptr(), p._version) for p in params)
+
+    def get(self, key: Tuple, params: Sequence[torch.Tensor], build):
+        stamp = self._stamp(params)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        val = build()
+        self._store[key] = (stamp, val)
+        return val
+
+    def clear(self) -> None:
+        self._store.clear()
+
+    # ---- common builders -------------------------------------------------------------------
+    def cast(self, name: str, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """Row-major working copy of one matrix (fp32 mode returns the parameter itself)."""
+        if dtype == torch.float32:
+            return p.detach()
+        return self.get((name, dtype), [p], lambda: ops.cast(p.detach().contiguous(), dtype))
+
+    def cat_rows(self, name: str, ps: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+        """[sum rows, K] working copy of several [rows_i, K] matrices stacked along dim 0."""
+        def build():
+            rows = sum(p.shape[0] for p in ps)
+            out = torch.empty((rows, ps[0].shape[1]), dtype=dtype, device=ps[0].device)
+            r = 0
+            for p in ps:
+                ops.cast(p.detach().contiguous(), dtype, out=out[r:r + p.shape[0]])
+                r += p.shape[0]
+            return out
+        return self.get((name, dtype), list(ps), build)
+
+    def cat_vec(self, name: str, ps: Sequence[Optional[torch.Tensor]], sizes: Sequence[int]) -> torch.Tensor:
+        """fp32 concatenation of bias vectors (None -> zeros)."""
+        real = [p for p in ps if p is not None]
+
+        def build():
+            out = torch.zeros(sum(sizes), dtype=torch.float32, device=real[0].device)
+            r = 0
+            for p, n in zip(ps, sizes):
+                if p is not None:
+                    ops.cast(p.detach().contiguous(), torch.float32, out=out[r:r + n])
+                r += n
+            return out
+        return self.get((name, "vec"), real, build)
+
+
+class DropoutSeeds:
+    """Per-forward dropout seeds: seed(site) = f(base, step, site).  The backward of a stage reuses
+    the seeds recorded by its forward, so masks are regenerated, never stored."""
+
+    _lock = threading.Lock()
+    _step = 0
+
+    def __init__(self, training: bool, p_hidden: float, p_attn: float) -> None:
+        self.active = bool(training)
+        self.p_hidden = float(p_hidden) if training else 0.0
+        self.p_attn = float(p_attn) if training else 0.0
+        with DropoutSeeds._lock:
+            DropoutSeeds._step += 1
+            step = DropoutSeeds._step
+        self.base = (int(torch.initial_seed()) * 0x9E3779B1 + step * 0x85EBCA6B) & 0xFFFFFFFF
+
+    def seed(self, site: int) -> int:
+        x = (self.base ^ (site * 0xC2B2AE35)) & 0xFFFFFFFF
+        x = ((x ^ (x >> 15)) * 0x2C1B3C6D) & 0xFFFFFFFF
+        x = ((x ^ (x >> 12)) * 0x297A2D39) & 0xFFFFFFFF
+        return (x ^ (x >> 15)) & 0xFFFFFFFF
+
+
+def zeros_like_param(p: torch.Tensor) -> torch.Tensor:
+    return torch.zeros(p.shape, dtype=torch.float32, device=p.device)

@@ -1,0 +1,421 @@
+"""LayoutLMv3 backbone on libpeneo_hip kernels.
+
+Module / parameter names reproduce the reference (model/backbone/layoutlmv3/modeling_layoutlmv3.py)
+so state dicts interchange (``backbone.embeddings.word_embeddings.weight``,
+``backbone.encoder.layer.{i}.attention.self.query.weight`` ...).  The ``nn.Module``s below only
+*hold* fp32 master parameters; the math runs in three kinds of autograd stages whose forward and
+backward are sequences of HIP kernel launches on the current stream:
+
+  _EmbedStage   K1 text gather+LN, K2 patch embed, K3 concat LN, K4 rel-pos bias (once per forward)
+  _LayerStage   K5 fused QKV GEMM, K6 flash attention with bias, K7/K8 GEMMs with fused
+                bias/GELU/residual(/dropout) epilogues + LayerNorm
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
+from .configuration_peneo import LayoutLMv3Config
+from .engine import DropoutSeeds, WeightCache, zeros_like_param
+from .relpos import bucket_lut, visual_xy
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names == reference)
+# ------------------------------------------------------------------------------------------------
+class _SelfAttentionParams(nn.Module):
+    def __init__(self, hidden: int):
+        super().__init__()
+        self.query = nn.Linear(hidden, hidden)
+        self.key = nn.Linear(hidden, hidden)
+        self.value = nn.Linear(hidden, hidden)
+
+
+class _DenseLN(nn.Module):
+    """RobertaSelfOutput / RobertaOutput: dense + LayerNorm (dropout has no parameters)."""
+
+    def __init__(self, fan_in: int, fan_out: int, eps: float):
+        super().__init__()
+        self.dense = nn.Linear(fan_in, fan_out)
+        self.LayerNorm = nn.LayerNorm(fan_out, eps=eps)
+
+
+class _Dense(nn.Module):
+    def __init__(self, fan_in: int, fan_out: int):
+        super().__init__()
+        self.dense = nn.Linear(fan_in, fan_out)
+
+
+class _AttentionParams(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self = _SelfAttentionParams(cfg.hidden_size)
+        self.output = _DenseLN(cfg.hidden_size, cfg.hidden_size, cfg.layer_norm_eps)
+
+
+class LayoutLMv3Layer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = _AttentionParams(cfg)
+        self.intermediate = _Dense(cfg.hidden_size, cfg.intermediate_size)
+        self.output = _DenseLN(cfg.intermediate_size, cfg.hidden_size, cfg.layer_norm_eps)
+
+
+class LayoutLMv3Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([LayoutLMv3Layer(cfg) for _ in range(cfg.num_hidden_layers)])
+        if cfg.has_relative_attention_bias:
+            self.rel_pos_bias = nn.Linear(cfg.rel_pos_bins, cfg.num_attention_heads, bias=False)
+        if cfg.has_spatial_attention_bias:
+            self.rel_pos_x_bias = nn.Linear(cfg.rel_2d_pos_bins, cfg.num_attention_heads, bias=False)
+            self.rel_pos_y_bias = nn.Linear(cfg.rel_2d_pos_bins, cfg.num_attention_heads, bias=False)
+
+
+class LayoutLMv3Embeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        H = cfg.hidden_size
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, H, padding_idx=cfg.pad_token_id)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, H)
+        self.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+        self.register_buffer("position_ids", torch.arange(cfg.max_position_embeddings).expand((1, -1)))
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, H, padding_idx=cfg.pad_token_id)
+        self.x_position_embeddings = nn.Embedding(cfg.max_2d_position_embeddings, cfg.coordinate_size)
+        self.y_position_embeddings = nn.Embedding(cfg.max_2d_position_embeddings, cfg.coordinate_size)
+        self.h_position_embeddings = nn.Embedding(cfg.max_2d_position_embeddings, cfg.shape_size)
+        self.w_position_embeddings = nn.Embedding(cfg.max_2d_position_embeddings, cfg.shape_size)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=16, stride=16)
+
+
+class _FwdState:
+    """Per-forward scratch shared by the stages (rel-pos bias, its gradient accumulator, seeds)."""
+
+    def __init__(self) -> None:
+        self.bias = None       # [B, nh, T, T] working dtype, already divided by sqrt(d)
+        self.g_bias = None     # fp32 accumulator of dS over the layers (training only)
+        self.buckets = (None, None, None)
+        self.key_mask = None   # int32 [B, T]
+        self.seeds: Optional[DropoutSeeds] = None
+        self.dtype = torch.float32
+        self.dims = None       # (B, S, T)
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 1: embeddings + relative-position bias
+# ------------------------------------------------------------------------------------------------
+class _EmbedStage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, st, input_ids, bbox, attention_mask, image, *params):
+        cfg, wc, dt = model.config, model.weight_cache, st.dtype
+        (word, type_w, pos_w, xw, yw, hw, ww, ln_g, ln_b, proj_w, proj_b, cls, pos_embed, norm_g, norm_b, LN_g, LN_b,
+         *rel) = params
+        B, S = input_ids.shape
+        H = cfg.hidden_size
+        dev = input_ids.device
+        seeds = st.seeds
+        has_img = image is not None
+        nv = 0
+        if has_img:
+            grid = image.shape[2] // 16
+            nv = grid * (image.shape[3] // 16) + 1
+            if nv != pos_embed.shape[1]:
+                raise ValueError(f"image gives {nv} visual tokens but pos_embed has {pos_embed.shape[1]}")
+        T = S + nv
+        st.dims = (B, S, T)
+        if int(bbox.min()) < 0 or int(bbox.max()) > 1023:
+            raise IndexError("The :obj:`bbox` coordinate values should be within 0-1000 range.")
+
+        pid = ops.position_ids(input_ids, cfg.pad_token_id)
+        x0 = torch.empty((B, S, H), dtype=dt, device=dev)
+        ops.embed_fwd(dt, x0, B, S, H, input_ids=input_ids, pos_ids=pid, bbox=bbox, word=word, type0=type_w[0],
+                      pos=pos_w, x=xw, y=yw, h=hw, w=ww, clip_hw=True)
+        cat = torch.empty((B, T, H), dtype=dt, device=dev)
+        # text rows: LayerNorm (+dropout) of the summed embeddings, written in place of the concat
+        _, m1, r1 = ops.layernorm_fwd(x0, ln_g, ln_b, cfg.layer_norm_eps, out=cat[:, :S],
+                                      drop_p=seeds.p_hidden, drop_seed=seeds.seed(1))
+        saved = dict(pid=pid, x0=x0, m1=m1, r1=r1, has_img=has_img)
+        if has_img:
+            patches = ops.im2col_patch16(image.contiguous(), dt)
+            wproj = wc.cast("patch_proj", proj_w.view(H, -1), dt)
+            proj = ops.gemm(patches, wproj, bias=proj_b)
+            vis0 = ops.visual_assemble_fwd(proj, cls.view(-1), pos_embed.view(-1, H), B)
+            _, mv, rv = ops.layernorm_fwd(vis0, norm_g, norm_b, 1e-6, out=cat[:, S:])
+            emb, m2, r2 = ops.layernorm_fwd(cat, LN_g, LN_b, cfg.layer_norm_eps,
+                                            drop_p=seeds.p_hidden, drop_seed=seeds.seed(2))
+            saved.update(patches=patches, vis0=vis0, mv=mv, rv=rv, cat=cat, m2=m2, r2=r2)
+        else:
+            emb = cat
+
+        # key mask over text + visual tokens (visual tokens are always attended: :1075-1080)
+        km = torch.ones((B, T), dtype=torch.int32, device=dev)
+        km[:, :S] = attention_mask.to(torch.int32)
+        st.key_mask = km
+
+        # K4: bucket maps + summed bias, shared by every layer
+        nh = cfg.num_attention_heads
+        d = H // nh
+        use1, use2 = cfg.has_relative_attention_bias, cfg.has_spatial_attention_bias
+        if use1 or use2:
+            pos_t = xs = ys = lut1 = lut2 = None
+            if use1:
+                p_text = torch.arange(S, dtype=torch.int32, device=dev)
+                p_vis = torch.arange(nv, dtype=torch.int32, device=dev)
+                pos_t = torch.cat([p_text, p_vis]).unsqueeze(0).expand(B, T).contiguous()
+                lut1 = model.lut("1d", cfg.rel_pos_bins, cfg.max_rel_pos, dev)
+            if use2:
+                vx, vy = model.visual_xy(dev, nv)
+                xs = torch.cat([bbox[:, :, 0].to(torch.int32), vx.unsqueeze(0).expand(B, nv)], dim=1).contiguous()
+                ys = torch.cat([bbox[:, :, 3].to(torch.int32), vy.unsqueeze(0).expand(B, nv)], dim=1).contiguous()
+                lut2 = model.lut("2d", cfg.rel_2d_pos_bins, cfg.max_rel_2d_pos, dev)
+            st.buckets = ops.relpos_buckets(pos_t, xs, ys, B, T, lut1, cfg.rel_pos_bins // 2, lut2, cfg.rel_2d_pos_bins // 2)
+            ri = iter(rel)
+            w1 = next(ri) if use1 else None
+            wx = next(ri) if use2 else None
+            wy = next(ri) if use2 else None
+            st.bias = ops.relpos_bias_fwd(dt, st.buckets[0], st.buckets[1], st.buckets[2], w1, wx, wy,
+                                          1.0 / math.sqrt(d), B, nh, T)
+        ctx.model, ctx.st, ctx.saved = model, st, saved
+        ctx.inputs = (input_ids, bbox)
+        ctx.params = params
+        return emb.view(B * T, H)
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        model, st, sv = ctx.model, ctx.st, ctx.saved
+        cfg, dt = model.config, st.dtype
+        (word, type_w, pos_w, xw, yw, hw, ww, ln_g, ln_b, proj_w, proj_b, cls, pos_embed, norm_g, norm_b, LN_g, LN_b,
+         *rel) = ctx.params
+        input_ids, bbox = ctx.inputs
+        B, S, T = st.dims
+        H = cfg.hidden_size
+        seeds = st.seeds
+        d_emb = d_emb.contiguous().view(B, T, H)
+        g = {id(p): zeros_like_param(p) for p in ctx.params}
+        if sv["has_img"]:
+            d_cat = ops.layernorm_bwd(d_emb, sv["cat"], LN_g, sv["m2"], sv["r2"], g[id(LN_g)], g[id(LN_b)],
+                                      drop_p=seeds.p_hidden, drop_seed=seeds.seed(2))
+            d_vis0 = torch.empty_like(sv["vis0"])
+            ops.layernorm_bwd(d_cat[:, S:], sv["vis0"], norm_g, sv["mv"], sv["rv"], g[id(norm_g)], g[id(norm_b)], dx=d_vis0)
+            d_proj = ops.visual_assemble_bwd(d_vis0, g[id(cls)].view(-1), g[id(pos_embed)].view(-1, H))
+            ops.colsum(d_proj, out=g[id(proj_b)], accumulate=True)
+            ops.gemm(d_proj, sv["patches"], a_kmajor=False, b_kmajor=False, out=g[id(proj_w)].view(H, -1), accumulate=True)
+        else:
+            d_cat = d_emb
+        d_x0 = torch.empty_like(sv["x0"])
+        ops.layernorm_bwd(d_cat[:, :S], sv["x0"], ln_g, sv["m1"], sv["r1"], g[id(ln_g)], g[id(ln_b)], dx=d_x0,
+                          drop_p=seeds.p_hidden, drop_seed=seeds.seed(1))
+        ops.embed_bwd(d_x0, B, S, H, input_ids=input_ids, pos_ids=sv["pid"], bbox=bbox, g_word=g[id(word)],
+                      g_pos=g[id(pos_w)], g_x=g[id(xw)], g_y=g[id(yw)], g_h=g[id(hw)], g_w=g[id(ww)], clip_hw=True,
+                      pad_id=cfg.pad_token_id)
+        ops.colsum(d_x0.view(B * S, H), out=g[id(type_w)][0], accumulate=True)
+        # rel-pos tables: every layer has accumulated its dS into st.g_bias by now
+        if st.g_bias is not None and rel:
+            use1, use2 = cfg.has_relative_attention_bias, cfg.has_spatial_attention_bias
+            ri = iter(rel)
+            w1 = next(ri) if use1 else None
+            wx = next(ri) if use2 else None
+            wy = next(ri) if use2 else None
+            d = H // cfg.num_attention_heads
+            ops.relpos_bias_bwd(st.g_bias, st.buckets[0], st.buckets[1], st.buckets[2],
+                                g[id(w1)] if w1 is not None else None, g[id(wx)] if wx is not None else None,
+                                g[id(wy)] if wy is not None else None, 1.0 / math.sqrt(d))
+            st.g_bias = None
+        grads = tuple(g[id(p)] if p.requires_grad else None for p in ctx.params)
+        return (None, None, None, None, None, None) + grads
+
+
+# ------------------------------------------------------------------------------------------------
+# stage 2: one encoder layer
+# ------------------------------------------------------------------------------------------------
+class _LayerStage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, st, idx, x, *params):
+        (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2) = params
+        cfg, wc, dt = model.config, model.weight_cache, st.dtype
+        B, S, T = st.dims
+        H, nh = cfg.hidden_size, cfg.num_attention_heads
+        d = H // nh
+        seeds = st.seeds
+        site = 16 * (idx + 1)
+        Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
+        bqkv = wc.get((f"L{idx}.bqkv",), [bq, bk, bv], lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]))
+        Wo, Wi, Wo2 = wc.cast(f"L{idx}.o", wo, dt), wc.cast(f"L{idx}.i", wi, dt), wc.cast(f"L{idx}.o2", wo2, dt)
+
+        qkv = ops.gemm(x, Wqkv, bias=bqkv)
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        att, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_mask,
+                                drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
+        h1 = ops.gemm(att, Wo, bias=bo, residual=x, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2))
+        a, m1, r1 = ops.layernorm_fwd(h1, g1, b1, cfg.layer_norm_eps)
+        zi = torch.empty((B * T, cfg.intermediate_size), dtype=dt, device=x.device)
+        inter = ops.gemm(a, Wi, bias=bi, act=ACT_GELU, preact=zi)
+        h2 = ops.gemm(inter, Wo2, bias=bo2, residual=a, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3))
+        out, m2, r2 = ops.layernorm_fwd(h2, g2, b2, cfg.layer_norm_eps)
+        ctx.model, ctx.st, ctx.idx = model, st, idx
+        ctx.saved = (x, qkv, att, lse, h1, m1, r1, a, zi, inter, h2, m2, r2)
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        model, st, idx = ctx.model, ctx.st, ctx.idx
+        (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2) = ctx.params
+        x, qkv, att, lse, h1, m1, r1, a, zi, inter, h2, m2, r2 = ctx.saved
+        cfg, wc, dt = model.config, model.weight_cache, st.dtype
+        B, S, T = st.dims
+        H, nh = cfg.hidden_size, cfg.num_attention_heads
+        d = H // nh
+        seeds = st.seeds
+        site = 16 * (idx + 1)
+        dev = x.device
+        Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
+        Wo, Wi, Wo2 = wc.cast(f"L{idx}.o", wo, dt), wc.cast(f"L{idx}.i", wi, dt), wc.cast(f"L{idx}.o2", wo2, dt)
+        f32 = lambda p: torch.zeros(p.shape, dtype=torch.float32, device=dev)
+        d_out = d_out.contiguous()
+
+        dg2, db2 = f32(g2), f32(b2)
+        d_h2 = ops.layernorm_bwd(d_out, h2, g2, m2, r2, dg2, db2)
+        d_dense2 = ops.copy2d(d_h2, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3)) if seeds.p_hidden > 0 else d_h2
+        dbo2 = ops.colsum(d_dense2)
+        dwo2 = ops.gemm(d_dense2, inter, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
+        dbi = ops.colsum(d_zi)
+        dwi = ops.gemm(d_zi, a, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
+
+        dg1, db1 = f32(g1), f32(b1)
+        d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1)
+        d_dense1 = ops.copy2d(d_h1, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2)) if seeds.p_hidden > 0 else d_h1
+        dbo = ops.colsum(d_dense1)
+        dwo = ops.gemm(d_dense1, att, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
+
+        if st.bias is not None and st.g_bias is None:
+            st.g_bias = torch.zeros(st.bias.shape, dtype=torch.float32, device=dev)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+        ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_mask, dqkv, st.g_bias,
+                     drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
+        dbqkv = ops.colsum(dqkv)
+        dwqkv = ops.gemm(dqkv, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
+        grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, db1,
+                 dwi, dbi, dwo2, dbo2, dg2, db2)
+        grads = tuple(gr if p.requires_grad else None for gr, p in zip(grads, ctx.params))
+        return (None, None, None, d_x) + grads
+
+
+def layer_params(layer: LayoutLMv3Layer) -> List[torch.Tensor]:
+    s, o = layer.attention.self, layer.attention.output
+    return [s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias, o.dense.weight,
+            o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias, layer.intermediate.dense.weight,
+            layer.intermediate.dense.bias, layer.output.dense.weight, layer.output.dense.bias,
+            layer.output.LayerNorm.weight, layer.output.LayerNorm.bias]
+
+
+# ------------------------------------------------------------------------------------------------
+# the backbone module
+# ------------------------------------------------------------------------------------------------
+class LayoutLMv3Model(nn.Module):
+    """Counterpart of the reference ``LayoutLMv3Model`` for the PEneo call pattern
+    (``forward(input_ids, bbox, attention_mask, image)`` -> ``(last_hidden_state [B, T, H],)``)."""
+
+    config_class = LayoutLMv3Config
+
+    def __init__(self, config: LayoutLMv3Config):
+        super().__init__()
+        self.config = config
+        H = config.hidden_size
+        if 4 * config.coordinate_size + 2 * config.shape_size != H:
+            raise ValueError("4 * coordinate_size + 2 * shape_size must equal hidden_size")
+        self.embeddings = LayoutLMv3Embeddings(config)
+        self.encoder = LayoutLMv3Encoder(config)
+        if config.visual_embed:
+            self.patch_embed = PatchEmbed(H)
+            size = int(config.input_size / 16)
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, H))
+            self.pos_embed = nn.Parameter(torch.zeros(1, size * size + 1, H))
+            self.LayerNorm = nn.LayerNorm(H, eps=config.layer_norm_eps)
+            self.norm = nn.LayerNorm(H, eps=1e-6)
+        self.weight_cache = WeightCache()
+        self.compute_dtype = torch.float32
+        self._luts = {}
+
+    # ---- small host-side constants ---------------------------------------------------------
+    def lut(self, kind: str, bins: int, max_dist: int, dev) -> torch.Tensor:
+        key = (kind, bins, max_dist, str(dev))
+        if key not in self._luts:
+            self._luts[key] = bucket_lut(bins, max_dist, 1024).to(dev)
+        return self._luts[key]
+
+    def visual_xy(self, dev, nv: int):
+        key = ("vxy", nv, str(dev))
+        if key not in self._luts:
+            grid = int(round(math.sqrt(nv - 1)))
+            vx, vy = visual_xy(grid)
+            self._luts[key] = (vx.to(dev), vy.to(dev))
+        return self._luts[key]
+
+    def _init_weights(self, module) -> None:
+        """Reference rule (modeling_layoutlmv3.py:260-274)."""
+        std = self.config.initializer_range
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def embed_params(self) -> List[torch.Tensor]:
+        e, cfg = self.embeddings, self.config
+        ps = [e.word_embeddings.weight, e.token_type_embeddings.weight, e.position_embeddings.weight,
+              e.x_position_embeddings.weight, e.y_position_embeddings.weight, e.h_position_embeddings.weight,
+              e.w_position_embeddings.weight, e.LayerNorm.weight, e.LayerNorm.bias]
+        if cfg.visual_embed:
+            ps += [self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.cls_token, self.pos_embed,
+                   self.norm.weight, self.norm.bias, self.LayerNorm.weight, self.LayerNorm.bias]
+        else:
+            raise PeneoHipError("LayoutLMv3 without visual_embed is not wired up (PEneo always has it)")
+        if cfg.has_relative_attention_bias:
+            ps.append(self.encoder.rel_pos_bias.weight)
+        if cfg.has_spatial_attention_bias:
+            ps += [self.encoder.rel_pos_x_bias.weight, self.encoder.rel_pos_y_bias.weight]
+        return ps
+
+    def forward(self, input_ids=None, bbox=None, attention_mask=None, image=None, **unused):
+        if input_ids is None:
+            raise ValueError("You have to specify input_ids")
+        if not input_ids.is_cuda:
+            raise PeneoHipError("peneo_amd runs on the GPU only: move the model and the batch to 'cuda' "
+                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+        cfg = self.config
+        B, S = input_ids.shape
+        if bbox is None:
+            bbox = torch.zeros((B, S, 4), dtype=torch.long, device=input_ids.device)
+        if attention_mask is None:
+            attention_mask = torch.ones((B, S), dtype=torch.long, device=input_ids.device)
+        st = _FwdState()
+        st.dtype = self.compute_dtype
+        st.seeds = DropoutSeeds(self.training, cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob)
+        x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(), attention_mask.contiguous(), image,
+                              *self.embed_params())
+        for i, layer in enumerate(self.encoder.layer):
+            x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
+        _, _, T = st.dims
+        return (x.view(B, T, cfg.hidden_size),)

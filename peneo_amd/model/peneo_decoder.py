@@ -1,0 +1,388 @@
+"""PEneo decoder on libpeneo_hip kernels (reference: model/peneo_decoder.py).
+
+``HandshakingTaggingScheme`` (label map <-> spots, :12-115), ``HandshakingKernel`` (:118-177),
+``PEneoOutput`` (:180-198) and ``PEneoDecoder`` (:201-443) keep the reference's names, parameter
+layout (``shrink_projection.{0,3}``, ``handshaking_kernel.combine_fc``, ``<head>_fc.{0,3}``,
+``link_loss.weight`` / ``le_loss.weight`` buffers) and outputs.  The forward never materialises the
+[B, P, D] pair tensor: K10 runs as two GEMMs with fused bias+SiLU(+dropout), K11+K12+K13 as the fused
+pair-heads kernel; the backward re-creates the pair activations chunk by chunk (rows of the
+triangle) so that its three GEMMs per chunk stay Infinity-Cache resident.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+from transformers.modeling_outputs import ModelOutput
+
+from .. import ops
+from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
+from .engine import DropoutSeeds, WeightCache
+
+HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
+TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
+              "line_grouping_head_rel_shaking_tag", "line_grouping_tail_rel_shaking_tag")
+HEAD_CLASSES = (2, 3, 3, 3, 3)
+
+
+class HandshakingTaggingScheme:
+    """Label-map <-> spot conversion (reference :12-115).  The packed index of pair (i, j), i <= j, of a
+    length-n sequence is p = i*n - i*(i-1)/2 + (j - i)."""
+
+    @staticmethod
+    def spots2shaking_tag(spots: List[Tuple], seq_len: int) -> torch.Tensor:
+        """NOTE: the reference builds an all-zero index map here, so every spot lands on p = 0
+        (:26-31); only ``spots2shaking_tag4batch`` is used by its collator.  Reproduced as is."""
+        tag = torch.zeros(seq_len * (seq_len + 1) // 2).long()
+        for sp in spots:
+            tag[0] = sp[2]
+        return tag
+
+    @staticmethod
+    def spots2shaking_tag4batch(batch_spots, shaking_ind2matrix_ind=None, matrix_ind2shaking_ind=None,
+                                seq_len: int = None) -> torch.Tensor:
+        if shaking_ind2matrix_ind is not None and matrix_ind2shaking_ind is not None:
+            seq_len = len(matrix_ind2shaking_ind)
+        elif seq_len is None:
+            raise ValueError("If shaking_ind2matrix_ind and matrix_ind2shaking_ind are not provided,seq_len must be given")
+        n = seq_len
+        out = torch.zeros(len(batch_spots), n * (n + 1) // 2).long()
+        for b, spots in enumerate(batch_spots):
+            for sp in spots:
+                i, j = sp[0], sp[1]
+                if matrix_ind2shaking_ind is not None:
+                    p = matrix_ind2shaking_ind[i][j]
+                else:
+                    p = i * n - i * (i - 1) // 2 + (j - i) if i <= j else 0  # reference's table is 0 below the diagonal
+                out[b][p] = sp[2]
+        return out
+
+    @staticmethod
+    def get_spots_from_shaking_tag(shaking_tag: torch.Tensor, shaking_ind2matrix_ind=None, seq_len: int = None):
+        """[P, C] logits (or [P] tags) -> [(i, j, tag, score)] in increasing p order (reference :76-115).
+        Device tensors go through the fused softmax/argmax/compaction kernel (K14) — one launch and one
+        copy instead of a Python loop with three ``.item()`` syncs per spot."""
+        if shaking_ind2matrix_ind is None and seq_len is None:
+            raise ValueError("If shaking_ind2matrix_ind and matrix_ind2shaking_ind are not provided,seq_len must be given")
+        P = shaking_tag.shape[0]
+        if seq_len is None:
+            seq_len = int(((8 * P + 1) ** 0.5 - 1) // 2)
+        n = seq_len
+        if shaking_tag.dim() > 1 and shaking_tag.shape[-1] > 1 and shaking_tag.is_cuda:
+            spots, scores = ops.spots_compact(shaking_tag.float().contiguous(), n)
+            sp, sc = spots.cpu().tolist(), scores.cpu().tolist()
+            return [(a, b, t, s) for (a, b, t), s in zip(sp, sc)]
+        if shaking_tag.dim() > 1 and shaking_tag.shape[-1] > 1:
+            prob = shaking_tag.softmax(-1)
+            pred, score = prob.argmax(-1), prob.max(-1)[0]
+        else:
+            pred, score = shaking_tag.view(-1), torch.ones_like(shaking_tag.view(-1), dtype=torch.float32)
+        out = []
+        for p in torch.nonzero(pred)[:, 0].tolist():
+            if shaking_ind2matrix_ind is not None:
+                i, j = shaking_ind2matrix_ind[p]
+            else:
+                i = int((2 * n + 1 - ((2 * n + 1) ** 2 - 8 * p) ** 0.5) // 2)
+                while i > 0 and i * n - i * (i - 1) // 2 > p:
+                    i -= 1
+                while i < n - 1 and (i + 1) * n - (i + 1) * i // 2 <= p:
+                    i += 1
+                j = i + p - (i * n - i * (i - 1) // 2)
+            out.append((i, j, int(pred[p]), float(score[p])))
+        return out
+
+
+@dataclass
+class PEneoOutput(ModelOutput):
+    loss: Optional[torch.Tensor] = None
+
+    line_extraction_loss: Optional[torch.Tensor] = None
+    ent_linking_h2h_loss: Optional[torch.Tensor] = None
+    ent_linking_t2t_loss: Optional[torch.Tensor] = None
+    line_grouping_h2h_loss: Optional[torch.Tensor] = None
+    line_grouping_t2t_loss: Optional[torch.Tensor] = None
+
+    line_extraction_shaking_outputs: Optional[torch.Tensor] = None
+    ent_linking_h2h_shaking_outputs: Optional[torch.Tensor] = None
+    ent_linking_t2t_shaking_outputs: Optional[torch.Tensor] = None
+    line_grouping_h2h_shaking_outputs: Optional[torch.Tensor] = None
+    line_grouping_t2t_shaking_outputs: Optional[torch.Tensor] = None
+
+    attentions: Optional[Tuple[torch.FloatTensor]] = None
+    hidden_states: Optional[Tuple[torch.FloatTensor]] = None
+    orig_bbox: Optional[torch.Tensor] = None
+
+
+class HandshakingKernel(nn.Module):
+    """Parameter holder for ``combine_fc`` (Linear(2D -> D)); the pair expansion itself is fused into the
+    pair-heads kernel via combine_fc(cat(h_i, h_j)) = W[:, :D] h_i + (W[:, D:] h_j + b)."""
+
+    def __init__(self, hidden_size: int) -> None:
+        super().__init__()
+        self.combine_fc = nn.Linear(hidden_size * 2, hidden_size)
+        self.activation = nn.SiLU()
+
+
+class _ClassWeightedCE(nn.Module):
+    """Holds the ``weight`` buffer of the reference's CrossEntropyLossOHEM (model/custom_loss.py:104-202)."""
+
+    def __init__(self, weight: torch.Tensor, num_hard_positive: int, num_hard_negative: int):
+        super().__init__()
+        self.register_buffer("weight", weight)
+        if num_hard_positive != -1 or num_hard_negative != -1:
+            raise NotImplementedError("OHEM (peneo_ohem_num_* != -1) is a 'next' row (SURVEY §8f.3); the shipped "
+                                      "default -1/-1 (plain class-weighted CE) is implemented")
+
+
+def _row_chunks(n: int, max_pairs: int) -> List[Tuple[int, int]]:
+    """Split rows 0..n of the pair triangle into [i0, i1) ranges of at most ~max_pairs pairs."""
+    out, i0, acc = [], 0, 0
+    for i in range(n):
+        row = n - i
+        if acc > 0 and acc + row > max_pairs:
+            out.append((i0, i))
+            i0, acc = i, 0
+        acc += row
+    out.append((i0, n))
+    return out
+
+
+class _DecoderStage(torch.autograd.Function):
+    """shrink MLP -> [a | b] projection -> fused pair heads (+ CE).  Inputs: cropped sequence output
+    [B*N, Hin]; outputs: total loss, 5 per-head losses, 5 logit maps."""
+
+    @staticmethod
+    def forward(ctx, dec, seq, B, N, tags, want_logits, need_grad, *params):
+        wc, dt = dec.weight_cache, seq.dtype
+        it = iter(params)
+        if dec.decoder_shrink:
+            w0, b0, w3, b3 = next(it), next(it), next(it), next(it)
+        wc_w, wc_b = next(it), next(it)
+        heads = [(next(it), next(it), next(it), next(it)) for _ in HEAD_NAMES]
+        D = wc_w.shape[0]
+        seeds = DropoutSeeds(dec.training, dec.dropout_p, 0.0)
+        dev = seq.device
+        saved = dict(seeds=seeds)
+        h = seq
+        if dec.decoder_shrink:
+            W0, W3 = wc.cast("dec.s0", w0, dt), wc.cast("dec.s3", w3, dt)
+            z1 = torch.empty((h.shape[0], w0.shape[0]), dtype=dt, device=dev)
+            s1 = ops.gemm(h, W0, bias=b0, act=ACT_SILU, preact=z1, drop_p=seeds.p_hidden, drop_seed=seeds.seed(901))
+            z2 = torch.empty((h.shape[0], w3.shape[0]), dtype=dt, device=dev)
+            s2 = ops.gemm(s1, W3, bias=b3, act=ACT_SILU, preact=z2, drop_p=seeds.p_hidden, drop_seed=seeds.seed(902))
+            saved.update(z1=z1, s1=s1, z2=z2)
+            h = s2
+        saved["s2"] = h
+        # [a | b] = h [Wc[:, :D]; Wc[:, D:]]^T + [0 | bc]
+        Wab = dec.stacked_combine_weight(wc_w, dt)
+        bab = wc.get(("dec.bab",), [wc_b], lambda: torch.cat([torch.zeros_like(wc_b.detach()), wc_b.detach()]))
+        ab = ops.gemm(h, Wab, bias=bab).view(B, N, 2 * D)
+        w1s, b1s = [hd[0] for hd in heads], [hd[1] for hd in heads]
+        w2s, b2s = [hd[2] for hd in heads], [hd[3] for hd in heads]
+        p1, p2 = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
+                                                                                 [w.detach() for w in w2s]))
+        b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
+        b2cat = wc.get(("dec.b2",), b2s, lambda: torch.cat([b.detach() for b in b2s]))
+        cws = [dec.le_loss.weight] + [dec.link_loss.weight] * 4 if tags is not None else None
+        logits, num, den, dlog, dls = ops.pair_heads_fwd(ab, p1, b1cat, p2, b2cat, HEAD_CLASSES, want_logits=want_logits,
+                                                         tags=tags, class_weights=cws,
+                                                         want_dlogits=need_grad and tags is not None)
+        outs = []
+        if tags is not None:
+            ratio = dec.loss_ratio_tensor(dev)
+            losses, scale = ops.loss_finish(num, den, ratio)
+            outs = [losses[5]] + [losses[i] for i in range(5)]
+            saved.update(scale=scale, dlog=dlog, dls=dls)
+        else:
+            outs = [None] * 6
+        saved.update(ab=ab, B=B, N=N, D=D, seq=seq)
+        ctx.dec, ctx.saved, ctx.params = dec, saved, params
+        ctx.has_loss = tags is not None
+        if logits is None:
+            logits = [None] * 5
+        for lg in logits:
+            if lg is not None:
+                ctx.mark_non_differentiable(lg)
+        return tuple(outs) + tuple(logits)
+
+    @staticmethod
+    def backward(ctx, d_loss, *unused):
+        dec, sv, params = ctx.dec, ctx.saved, ctx.params
+        if not ctx.has_loss:
+            raise PeneoHipError("backward through the PEneo decoder needs the five *_shaking_tag label maps")
+        wc = dec.weight_cache
+        it = iter(params)
+        if dec.decoder_shrink:
+            w0, b0, w3, b3 = next(it), next(it), next(it), next(it)
+        wc_w, wc_b = next(it), next(it)
+        heads = [(next(it), next(it), next(it), next(it)) for _ in HEAD_NAMES]
+        B, N, D = sv["B"], sv["N"], sv["D"]
+        ab, seeds = sv["ab"], sv["seeds"]
+        dt, dev = ab.dtype, ab.device
+        nh = len(HEAD_NAMES)
+        # dlogits are un-normalised: scale_h = ratio_h / den_h, times the incoming d(loss)
+        scale = sv["scale"] * d_loss.to(torch.float32)
+        w1s, b1s = [hd[0] for hd in heads], [hd[1] for hd in heads]
+        w2s, b2s = [hd[2] for hd in heads], [hd[3] for hd in heads]
+        W1cat = wc.cat_rows("dec.w1cat", w1s, dt)                      # [nh*D, D]
+        b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
+        dW1cat = torch.zeros((nh * D, D), dtype=torch.float32, device=dev)
+        db1cat = torch.zeros(nh * D, dtype=torch.float32, device=dev)
+        dw2 = [torch.zeros(w.shape, dtype=torch.float32, device=dev) for w in w2s]
+        d_ab = torch.zeros((B, N, 2 * D), dtype=torch.float32, device=dev)
+        P = N * (N + 1) // 2
+        chunks = _row_chunks(N, dec.bwd_chunk_pairs)
+        maxp = max((i1 * N - i1 * (i1 - 1) // 2) - (i0 * N - i0 * (i0 - 1) // 2) for i0, i1 in chunks)
+        xbuf = torch.empty((maxp, D), dtype=dt, device=dev)
+        zbuf = torch.empty((maxp, nh * D), dtype=dt, device=dev)
+        dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
+        w2d = [w.detach().contiguous() for w in w2s]
+        for b in range(B):
+            for (i0, i1) in chunks:
+                p0 = i0 * N - i0 * (i0 - 1) // 2
+                p1 = i1 * N - i1 * (i1 - 1) // 2
+                npairs = p1 - p0
+                x, z, dx = xbuf[:npairs], zbuf[:npairs], dxbuf[:npairs]
+                ops.pair_x_fwd(ab[b], i0, i1, x)
+                ops.gemm(x, W1cat, bias=b1cat, out=z)
+                ops.pair_dz(z, npairs, D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, dw2, db1cat, scale)
+                ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
+                ops.gemm(z, W1cat, b_kmajor=False, out=dx)
+                ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b])
+        db2cat = sv["dls"]
+        # back through the [a | b] projection and the shrink MLP
+        d_ab2 = ops.cast(d_ab.view(B * N, 2 * D), dt) if dt != torch.float32 else d_ab.view(B * N, 2 * D)
+        s2 = sv["s2"]
+        Wab = dec.stacked_combine_weight(wc_w, dt)
+        dWab = ops.gemm(d_ab2, s2, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)     # [2D, D]
+        d_wc = torch.cat([dWab[:D], dWab[D:]], dim=1)
+        d_bc = ops.colsum(d_ab2[:, D:])
+        grads = []
+        if dec.decoder_shrink:
+            W0, W3 = wc.cast("dec.s0", w0, dt), wc.cast("dec.s3", w3, dt)
+            d_z2 = ops.gemm(d_ab2, Wab, b_kmajor=False, grad_src=sv["z2"], grad_act=ACT_SILU,
+                            drop_p=seeds.p_hidden, drop_seed=seeds.seed(902))
+            dw3 = ops.gemm(d_z2, sv["s1"], a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+            db3 = ops.colsum(d_z2)
+            d_z1 = ops.gemm(d_z2, W3, b_kmajor=False, grad_src=sv["z1"], grad_act=ACT_SILU,
+                            drop_p=seeds.p_hidden, drop_seed=seeds.seed(901))
+            dw0 = ops.gemm(d_z1, sv["seq"], a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+            db0 = ops.colsum(d_z1)
+            d_seq = ops.gemm(d_z1, W0, b_kmajor=False)
+            grads += [dw0, db0, dw3, db3]
+        else:
+            d_seq = ops.gemm(d_ab2, Wab, b_kmajor=False)
+        grads += [d_wc, d_bc]
+        off = 0
+        for h in range(nh):
+            c = HEAD_CLASSES[h]
+            grads += [dW1cat[h * D:(h + 1) * D], db1cat[h * D:(h + 1) * D], dw2[h], db2cat[off:off + c] * scale[h]]
+            off += c
+        grads = tuple(g if p.requires_grad else None for g, p in zip(grads, params))
+        return (None, d_seq, None, None, None, None, None) + grads
+
+
+class PEneoDecoder(nn.Module):
+    """PEneo pair extraction downstream head (reference :201-443)."""
+
+    def __init__(self, config, input_size: int) -> None:
+        super().__init__()
+        self.decoder_shrink = config.peneo_decoder_shrink
+        hidden = config.backbone_config["hidden_size"]
+        self.dropout_p = config.backbone_config["hidden_dropout_prob"]
+        if config.peneo_classifier_num_layers != 2:
+            raise NotImplementedError("the fused pair-heads kernel implements the shipped 2-layer classifier "
+                                      "(peneo_classifier_num_layers == 2, tools/generate_peneo_weights.py:66)")
+        if self.decoder_shrink:
+            D = hidden // 2
+            self.shrink_projection = nn.Sequential(
+                nn.Linear(input_size, hidden), nn.SiLU(), nn.Dropout(self.dropout_p),
+                nn.Linear(hidden, D), nn.SiLU(), nn.Dropout(self.dropout_p))
+        else:
+            D = input_size
+        if D % 32 != 0:
+            raise ValueError(f"decoder hidden size {D} must be a multiple of 32 for the MFMA pair-heads kernel")
+        self.decoder_hidden_size = D
+        self.handshaking_kernel = HandshakingKernel(D)
+        self.inference_mode = config.inference_mode
+
+        def build_classifier(out_size: int) -> nn.Module:
+            return nn.Sequential(nn.Linear(D, D), nn.SiLU(), nn.Dropout(self.dropout_p), nn.Linear(D, out_size))
+
+        self.line_extraction_fc = build_classifier(2)
+        self.ent_linking_h2h_fc = build_classifier(3)
+        self.ent_linking_t2t_fc = build_classifier(3)
+        self.line_grouping_h2h_fc = build_classifier(3)
+        self.line_grouping_t2t_fc = build_classifier(3)
+
+        self.loss_ratio = config.peneo_loss_ratio
+        if self.loss_ratio is not None:
+            assert len(self.loss_ratio) == 5, "loss_ratio must be a list of 5 elements"
+        cw = config.peneo_category_weights
+        assert cw is not None and len(cw) == 3, "category_weights must be a list of 3 elements"
+        self.link_loss = _ClassWeightedCE(torch.tensor(cw).float(), config.peneo_ohem_num_positive,
+                                          config.peneo_ohem_num_negative)
+        self.le_loss = _ClassWeightedCE(torch.tensor(cw[:-1]).float(), config.peneo_ohem_num_positive,
+                                        config.peneo_ohem_num_negative)
+        self.weight_cache = WeightCache()
+        self.bwd_chunk_pairs = 32768
+        self._ratio = {}
+
+    def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+        """[Wc[:, :D]; Wc[:, D:]] as a [2D, D] working-precision matrix, so one GEMM yields [a | b]."""
+        D = wc_w.shape[0]
+        return self.weight_cache.get(("dec.ab", dt), [wc_w], lambda: ops.cast(
+            torch.cat([wc_w.detach()[:, :D], wc_w.detach()[:, D:]], dim=0).contiguous(), dt))
+
+    def loss_ratio_tensor(self, dev) -> torch.Tensor:
+        key = str(dev)
+        if key not in self._ratio:
+            r = self.loss_ratio if self.loss_ratio is not None else [1.0] * 5
+            self._ratio[key] = torch.tensor(r, dtype=torch.float32, device=dev)
+        return self._ratio[key]
+
+    def stage_params(self) -> List[torch.Tensor]:
+        ps: List[torch.Tensor] = []
+        if self.decoder_shrink:
+            ps += [self.shrink_projection[0].weight, self.shrink_projection[0].bias,
+                   self.shrink_projection[3].weight, self.shrink_projection[3].bias]
+        ps += [self.handshaking_kernel.combine_fc.weight, self.handshaking_kernel.combine_fc.bias]
+        for name in HEAD_NAMES:
+            fc = getattr(self, name + "_fc")
+            ps += [fc[0].weight, fc[0].bias, fc[3].weight, fc[3].bias]
+        return ps
+
+    def forward(self, sequence_output: torch.Tensor, orig_bbox: torch.Tensor = None, line_extraction_shaking_tag=None,
+                ent_linking_head_rel_shaking_tag=None, ent_linking_tail_rel_shaking_tag=None,
+                line_grouping_head_rel_shaking_tag=None, line_grouping_tail_rel_shaking_tag=None, **kwargs):
+        """``sequence_output``: [B, N, Hin] in the working dtype, already cropped (CLS / visual tokens removed)."""
+        B, N, Hin = sequence_output.shape
+        tags = [line_extraction_shaking_tag, ent_linking_head_rel_shaking_tag, ent_linking_tail_rel_shaking_tag,
+                line_grouping_head_rel_shaking_tag, line_grouping_tail_rel_shaking_tag]
+        P = N * (N + 1) // 2
+        if all(t is not None for t in tags):
+            for t in tags:
+                assert t.shape == (B, P), f"label map shape {tuple(t.shape)} != {(B, P)}"
+            tags = [t.contiguous() for t in tags]
+        elif self.inference_mode:
+            tags = None
+        else:
+            # the reference asserts on `pred.shape[:-1] == target.shape` with target None -> AttributeError
+            raise AssertionError("the five *_shaking_tag label maps are required unless config.inference_mode is set")
+        if self.inference_mode:
+            tags = None
+        params = self.stage_params()
+        # autograd is off inside Function.forward, so decide here whether the backward will need dlogits
+        need_grad = torch.is_grad_enabled() and (sequence_output.requires_grad or any(p.requires_grad for p in params))
+        res = _DecoderStage.apply(self, sequence_output.reshape(B * N, Hin), B, N, tags, True, need_grad, *params)
+        loss, l_le, l_elh, l_elt, l_lgh, l_lgt, o_le, o_elh, o_elt, o_lgh, o_lgt = res
+        if self.inference_mode:
+            # NB the reference's tuple order differs from the dataclass field order (:365-373)
+            return (o_le, o_elh, o_elt, o_lgh, o_lgt, orig_bbox)
+        return PEneoOutput(
+            loss=loss, line_extraction_loss=l_le, ent_linking_h2h_loss=l_elh, ent_linking_t2t_loss=l_elt,
+            line_grouping_h2h_loss=l_lgh, line_grouping_t2t_loss=l_lgt, line_extraction_shaking_outputs=o_le,
+            ent_linking_h2h_shaking_outputs=o_elh, ent_linking_t2t_shaking_outputs=o_elt,
+            line_grouping_h2h_shaking_outputs=o_lgh, line_grouping_t2t_shaking_outputs=o_lgt, orig_bbox=orig_bbox)

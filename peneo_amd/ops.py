@@ -103,6 +103,16 @@ def copy2d(src: torch.Tensor, out: Optional[torch.Tensor] = None, drop_p: float 
     return out
 
 
+def copy_rows(src: torch.Tensor, dst: torch.Tensor, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    """Copy between [B, R, C] views whose last dim is contiguous (either side may be a slice of a larger buffer)."""
+    assert src.dim() == 3 and dst.dim() == 3 and src.shape == dst.shape and src.dtype == dst.dtype
+    assert src.stride(2) == 1 and dst.stride(2) == 1
+    Bn, R, Cn = src.shape
+    check(lib().peneo_copy_rows(dtype_code(src.dtype), ptr(src), R, src.stride(0), src.stride(1), ptr(dst), R, dst.stride(0),
+                                dst.stride(1), Bn * R, Cn, drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_copy_rows")
+    return dst
+
+
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     assert x.dim() == 2 and x.stride(1) == 1
     if out is None:
