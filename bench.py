@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""docs/sec, forward + backward, LayoutLMv3-base seq 512 / 128 lines, on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + loss + backward of `--docs-per-gpu` synthetic RFUND-shaped documents per GPU in
+train mode (dropout on), bf16 MFMA inputs / fp32 accumulate, fp32 master weights re-cast every step, and
+for N > 1 the RCCL all-reduce of all 127 M gradients (DDP, bf16 buckets).  No optimizer step (the metric
+is fwd+bwd).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+
+FWD_GFLOP_PER_DOC = 334.7           # algorithmic, SURVEY §8(d) / BASELINE.md §3 (config 2)
+PAIR_HEADS_GFLOP_PER_DOC = 194.31   # heads L1 192.90 + L2 1.41: what one pair_heads_fwd launch computes per document
+PEAK_BF16_TFLOPS = 2500.0           # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(size: str, dtype):
+    from seeded import layoutlmv3_config, peneo_config
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config(size))
+    model = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"}))
+    return model, pcfg
+
+
+def cpu_baseline(pcfg, seq_len, n_lines, seed, max_seconds=40.0):
+    """The oracle (CPU restatement of the reference, as-executed form: materialised [N, N, 2D] handshaking and
+    one-hot bias GEMMs) timed on the host cores for ONE document, forward + backward."""
+    from oracle import peneo_oracle as O
+    from seeded import seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    torch.set_num_threads(os.cpu_count() or 1)
+    m = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"}))
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("_loss.weight") else v)
+          for k, v in m.state_dict().items()}
+    del m
+    batch = synthetic_rfund_batch(1, seq_len, n_lines, pcfg["backbone_config"]["vocab_size"], seed=seed)
+    t0 = time.perf_counter()
+    out = O.peneo_forward(sd, pcfg, batch, training=False, as_executed=True)
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "docs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 document seq{seq_len}/{n_lines} lines, fwd+bwd fp32, reference as-executed form "
+                      f"(materialised pair tensor, one-hot bias), single cold run {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--docs-per-gpu", type=int, default=8)
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--lines", type=int, default=128)
+    ap.add_argument("--size", default="base", choices=["tiny", "base", "large"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-forward", action="store_true", help="time eval forward only (reported as a side metric)")
+    args = ap.parse_args()
+
+    from peneo_amd import ops
+    from peneo_amd.data import synthetic_rfund_batch
+    from peneo_amd.parallel import init_distributed, max_over_ranks, wrap_data_parallel
+    import torch.distributed as dist
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(1234)
+    model, pcfg = build_model(args.size, dtype)
+    model = model.to(dev).set_compute_dtype(dtype).train()
+    model.backbone.check_inputs = False
+    net = wrap_data_parallel(model, device_ids=[local_rank]) if world > 1 else model
+    B = args.docs_per_gpu
+    vocab = pcfg["backbone_config"]["vocab_size"]
+
+    def make_batch(step):
+        b = synthetic_rfund_batch(B, args.seq_len, args.lines, vocab, seed=1000 * rank + step)
+        return {k: v.to(dev, non_blocking=True) for k, v in b.items()}
+
+    batches = [make_batch(s) for s in range(4)]     # inputs resident in HBM before the timed region
+
+    def step(i):
+        for p in model.parameters():
+            p.grad = None
+        out = net(**batches[i % len(batches)])
+        out["loss"].backward()
+        return out["loss"]
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.TIMER.reset(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, dev)
+    ph = ops.TIMER.durations_ms("pair_heads_fwd")
+    ops.TIMER.reset(False)
+    loss_val = float(loss.detach())
+
+    # side metric: eval forward only (the "encoder + pair-head forward" roofline target of BASELINE.md §5)
+    model.eval()
+    with torch.no_grad():
+        for i in range(2):
+            net_out = model(**batches[i])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nf = max(3, args.steps // 2)
+        for i in range(nf):
+            model(**batches[i % len(batches)])
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) * 1e3 / nf
+
+    if rank == 0:
+        docs = world * B * args.steps
+        ms_per_step = elapsed * 1e3 / args.steps
+        ph_ms = sum(ph) / max(1, len(ph))
+        achieved = PAIR_HEADS_GFLOP_PER_DOC * B / ph_ms if ph_ms > 0 else 0.0      # GFLOP / ms = TFLOP/s
+        res = {
+            "metric": "docs/sec fwd+bwd, LayoutLMv3-base seq512 L128",
+            "value": round(docs / elapsed, 2),
+            "unit": "docs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"LayoutLMv3-{args.size} PEneo, synthetic RFUND-shaped batch seq{args.seq_len}/"
+                                   f"{args.lines} lines, {B} docs/GPU, train mode (dropout 0.1), fwd+loss+bwd"
+                                   f"{' + RCCL grad all-reduce (DDP, bf16 buckets)' if world > 1 else ''}",
+                       "docs_per_gpu": B, "seq_len": args.seq_len, "lines": args.lines,
+                       "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
+            "roofline": {"bound": "mfma", "kernel": "pair_heads_fwd_kernel<bf16,24>" if args.dtype == "bf16" else "pair_heads_fwd_kernel<f32,24>",
+                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(ph_ms, 4), "launches": len(ph)},
+            "forward_only": {"ms_per_batch": round(fwd_ms, 3), "docs_per_s": round(B * 1e3 / fwd_ms, 1),
+                             "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
+                             "frac_of_mfma_peak": round(FWD_GFLOP_PER_DOC * B / fwd_ms / PEAK_BF16_TFLOPS, 4)},
+            "train_tflops_algorithmic": round(3 * FWD_GFLOP_PER_DOC * docs / elapsed / 1e3, 1),
+        }
+        if not args.no_cpu_baseline and world == 1 and args.size == "base":
+            res["cpu_baseline"] = cpu_baseline(pcfg, args.seq_len, args.lines, seed=7)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

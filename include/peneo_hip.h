@@ -168,31 +168,42 @@ int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const int32_t* y
                          const uint8_t* lut1, int lut1_len, int half1,
                          const uint8_t* lut2, int lut2_len, int half2,
                          uint8_t* bk1, uint8_t* bkx, uint8_t* bky, peneo_stream_t stream);
-/* bias[b,h,i,j] = scale * (w1[h,bk1] + wx[h,bkx] + wy[h,bky]); any of the three may be NULL */
+/* bias[b,h,i,j] = scale * (w1[h,bk1] + wx[h,bkx] + wy[h,bky]); any of the three may be NULL.
+ * Output layout [B, nh, T, Tp] with Tp = peneo_attn_padded_len(T); columns j >= T and keys with
+ * key_mask[b,j] == 0 (may be NULL) hold -1e30, which is how the attention kernels see the padding mask. */
 int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
                           const float* w1, int bins1, const float* wx, const float* wy, int bins2,
-                          float scale, int B, int nh, int T, void* bias, peneo_stream_t stream);
-/* dw*[h,bin] += scale * sum_{b,i,j in bin} g[b,h,i,j]  */
-int peneo_relpos_bias_bwd(const float* g, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
+                          float scale, int B, int nh, int T, int Tp, const int32_t* key_mask, void* bias,
+                          peneo_stream_t stream);
+/* dw*[h,bin] += scale * sum_{b,i,j in bin} g[b,h,i,j]   (g rows have stride ldg >= T) */
+int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
                           float* dw1, int bins1, float* dwx, float* dwy, int bins2,
                           float scale, int B, int nh, int T, peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K6 — attention core (modeling_layoutlmv3.py:365-404; the "cogview" softmax :308-321 is exactly
- * softmax).  q/k/v are rows of a [B*T, ld] matrix, head h at columns h*d..; scores =
- * scale * q.k + bias[b,h,i,j] ; keys with key_mask[b,j] == 0 get probability 0.
- * `lse` [B, nh, T] fp32 is the log-sum-exp per query row (saved for backward).
+ * softmax).  q/k/v are rows of a [B*T, ld] matrix, head h at columns h*d..;
+ *   scores = scale * q.k + bias[b,h,i,j] + key_bias[b,j]      (both optional; -1e30 = masked key)
+ * Operands whose reduction index must be contiguous are passed as per-head transposed copies
+ * [B, nh, DP, Tp] (DP = peneo_attn_padded_dim(d), Tp = peneo_attn_padded_len(T)) made by
+ * peneo_head_transpose: vt for the forward; kt, qt and dot (= d_out transposed) for the backward.
+ * `lse` [B, nh, T] fp32 is the per-row log-sum-exp in log2 units (an opaque forward->backward buffer).
  * ------------------------------------------------------------------------------------------ */
-int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv,
-                   int B, int nh, int T, int d, float scale, const void* bias, const int32_t* key_mask,
-                   void* out, int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed,
+int peneo_attn_padded_len(int T);
+int peneo_attn_padded_dim(int d);
+int peneo_head_transpose(int dtype, const void* src, int64_t ld, int B, int nh, int T, int d, void* dst,
+                         peneo_stream_t stream);
+int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const void* vt,
+                   int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
+                   const float* key_bias, void* out, int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed,
                    peneo_stream_t stream);
-/* dq/dk/dv share the q/k/v layout (ld_dqkv).  g_bias (fp32 [B,nh,T,T], may be NULL) is
+/* dq/dk/dv share the q/k/v layout (ld_dqkv).  g_bias (fp32 [B, nh, T, bias_ld], may be NULL) is
  * accumulated with dS so the bias-table gradient can be reduced once per step.
  * `delta` is a [B, nh, T] fp32 scratch. */
 int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv,
+                   const void* kt, const void* qt, const void* dot,
                    const void* out, const void* d_out, int64_t ld_out, const float* lse,
-                   int B, int nh, int T, int d, float scale, const void* bias, const int32_t* key_mask,
+                   int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias,
                    void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
                    float drop_p, uint32_t drop_seed, peneo_stream_t stream);
 
@@ -226,11 +237,12 @@ int peneo_pair_heads_pack_w2(int dtype, const float* const* w2, const int* class
 typedef struct peneo_pair_loss {
   const int64_t* tags[PENEO_MAX_HEADS];   /* [B, P] label maps (data/collator.py:170-204); NULL = no loss */
   const float* class_weight[PENEO_MAX_HEADS]; /* [classes[h]] fp32 device */
-  float* loss_num;                        /* [num_heads] sum_p w[tag] * nll   (accumulated, zero it first) */
-  float* loss_den;                        /* [num_heads] sum_p w[tag]         (accumulated, zero it first) */
+  float* partials;                        /* [peneo_pair_loss_partials(B, N)][32] fp32 workspace: one row per workgroup =
+                                             sum_p w[tag]*nll [8] | sum_p w[tag] [8] | sum_p dlogits [16]; reduced by
+                                             peneo_loss_finish (deterministic, no atomics) */
   float* dlogits[PENEO_MAX_HEADS];        /* optional [B, P, classes[h]] fp32: w[tag] * (softmax - onehot) (unnormalised) */
-  float* dl_sum;                          /* optional [sum classes] sum_p dlogits (accumulated): the second-layer bias gradient */
 } peneo_pair_loss;
+int64_t peneo_pair_loss_partials(int B, int N);
 
 /* logits[h] : [B, P, classes[h]] fp32, contiguous, P = N (N + 1) / 2 (may be NULL when only the loss is wanted) */
 int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
@@ -244,27 +256,31 @@ int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1
 /* du = dx * SiLU'(a_i + b_j);  d_ab_doc[i, :D] += sum_j du ; d_ab_doc[j, D:] += sum_i du   (fp32 [N, 2D]) */
 int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* dx, float* d_ab_doc,
                      peneo_stream_t stream);
-/* For the [npairs, nh*D] pre-activations z of all heads' first layers:
- *   y = SiLU(z);  dy[p, h*D+k] = sum_c dlogits_h[p, c] * w2_h[c, k];  dz = dy * SiLU'(z)  (written over z)
- *   dw2_h[c, k] += sum_p dlogits_h[p,c] * y[p, h*D+k];   db1[h*D+k] += sum_p dz
- * dlogits scale[h] (= loss_ratio_h / den_h) is applied on the fly. */
+/* For the [npairs, nh*D] pre-activations z of all heads' first layers (in place):
+ *   y = SiLU(z);  dy[p, h*D+k] = sum_c scale_h * dlogits_h[p, c] * w2_h[c, k];  dz = dy * SiLU'(z)  (written over z)
+ * and the reductions over pairs needed by the parameter gradients are accumulated into `workspace`
+ * [256][4 * nh*D] fp32 (zero it once per step; sum its 256 rows with peneo_colsum at the end):
+ *   row block c (c = 0..2): sum_p scale_h*dlogits_h[p,c] * y[p, :]   -> dW2_h[c, :] = block[c][h*D : (h+1)*D]
+ *   row block 3            : sum_p dz[p, :]                          -> db1
+ * scale[h] (= d(loss) * loss_ratio_h / den_h) is a device vector. */
 typedef struct peneo_pair_dz_args {
   int num_heads; int D; int classes[PENEO_MAX_HEADS];
   const float* dlogits[PENEO_MAX_HEADS];  /* [npairs, classes[h]] (already offset to the chunk) */
   const float* w2[PENEO_MAX_HEADS];       /* [classes[h], D] fp32 */
-  float* dw2[PENEO_MAX_HEADS];            /* [classes[h], D] fp32, accumulated */
-  float* db1;                             /* [num_heads * D] fp32, accumulated */
   const float* scale;                     /* [num_heads] device fp32 */
 } peneo_pair_dz_args;
-int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, peneo_stream_t stream);
+size_t peneo_pair_dz_workspace_bytes(int num_heads, int D);
+int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, float* workspace,
+                  peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * K13 helpers — loss finish:  loss_h = num_h / den_h ; total = sum_h ratio_h * loss_h ;
- * scale_h = ratio_h / den_h (the factor the backward applies to dlogits).
- * out: [num_heads + 1] = per-head losses then the total.
+ * K13 — loss finish: reduces the per-workgroup partial rows of peneo_pair_heads_fwd:
+ *   loss_h = num_h / den_h ; total = sum_h ratio_h * loss_h ; scale_h = ratio_h / den_h (the factor the
+ *   backward applies to the un-normalised dlogits) ; dl_sum[c] = sum_p dlogits[p, c] (second-layer bias grads).
+ * out: [num_heads + 1] = per-head losses then the total.  (model/peneo_decoder.py:315-336,375-428)
  * ------------------------------------------------------------------------------------------ */
-int peneo_loss_finish(const float* num, const float* den, const float* ratio, int num_heads, float* out,
-                      float* scale, peneo_stream_t stream);
+int peneo_loss_finish(const float* partials, int64_t n_partials, const float* ratio, int num_heads, int total_classes,
+                      float* out, float* scale, float* dl_sum, peneo_stream_t stream);
 /* stand-alone weighted CE on materialised logits [rows, C] (used by the unfused parity path) */
 int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* class_weight, int64_t rows, int C,
                       float* num, float* den, float* dlogits, peneo_stream_t stream);

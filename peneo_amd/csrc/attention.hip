@@ -11,31 +11,36 @@
 //   dQ      :  S^T, dP^T[key, q] = V . dO^T   dQ^T[d, q] = K^T . dS^T
 //   dK/dV   :  S[q, key] = Q . K^T, dP[q, key] = dO . V^T,  dV^T[d, key] = dO^T . P,  dK^T[d, key] = Q^T . dS
 //
-// scores = scale * q.k + bias[b, h, q, key]; keys with key_mask == 0 (and the tail beyond T) get
-// probability exactly 0 (reference adds finfo.min: modeling_layoutlmv3.py:383-389, 1126-1128).
+// The A-side operands that need the reduction index contiguous (V^T, K^T, Q^T, dO^T) come from
+// per-head transposed copies [B, nh, DP, Tp] made by peneo_head_transpose (one HBM-bound pass per
+// layer), so every LDS tile is filled with plain 16-byte row copies, prefetched into registers one
+// tile ahead of the MFMAs.  The additive bias [B, nh, T, Tp] (row stride Tp = T rounded up to 64,
+// padding and masked keys = -1e30) is staged through LDS the same way.  Soft-max runs in the exp2
+// domain in fp32.  scores = scale * q.k + bias (reference: modeling_layoutlmv3.py:365-389).
 #include "common.h"
 
 namespace peneo {
 
 constexpr int AQ = 128;   // rows of the "n" side per workgroup (4 waves x 32)
 constexpr int AK = 64;    // rows of the streamed side per tile
-constexpr float NEG_BIG = -3.0e38f;
+constexpr float MASKED = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+// raw v_exp_f32: arguments here are <= 0 (or hugely negative for masked keys), results in [0, 1]; no denormal fix-up needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <typename T> struct Sz { static constexpr int v = sizeof(T); };
-
-// ---- LDS tiles: row-major [rows][cols] of T, row pitch = cols*sizeof(T) + 16 bytes (odd number of
-//      16-byte slots => 16 consecutive rows hit 16 different slots: conflict-free b128 column reads)
+// ---- LDS tiles: row-major [rows][COLS] of T, pitch = COLS*sizeof(T) + 16 bytes (odd number of 16-byte
+//      slots => 16 consecutive rows hit 16 different slots: conflict-free b128 column reads)
 template <typename T, int COLS> struct Pitch { static constexpr int v = COLS * (int)sizeof(T) + 16; };
 
-// FragReader::straight : 8 consecutive elements starting at column c (c multiple of 8) -> MFMA fragment
 template <typename T, int COLS> struct FragReader;
 template <int COLS> struct FragReader<bf16_t, COLS> {
+  // 8 consecutive elements starting at column c (multiple of 8)
   __device__ static __forceinline__ Frag<bf16_t> straight(const char* tile, int row, int c) {
     Frag<bf16_t> f;
     f.v = *reinterpret_cast<const uint4*>(tile + row * Pitch<bf16_t, COLS>::v + c * 2);
     return f;
   }
-  // elements {c..c+3} and {c+8..c+11}
+  // elements {c..c+3} and {c+8..c+11} (c multiple of 4)
   __device__ static __forceinline__ Frag<bf16_t> perm(const char* tile, int row, int c) {
     const char* p = tile + row * Pitch<bf16_t, COLS>::v + c * 2;
     uint2 a = *reinterpret_cast<const uint2*>(p);
@@ -64,136 +69,232 @@ template <int COLS> struct FragReader<float, COLS> {
 
 // pack_frag8 of 8 accumulator registers (r0..r0+7) of a C-layout tile gives a fragment whose element t is row
 // 2*r0 + (t&3) + 8*(t>>2) + 4*(lane>>5): exactly what FragReader::perm(col = 2*r0 + 4*half) reads on the A side.
-template <typename T> __device__ __forceinline__ Frag<T> pack_acc(const float* v) { return pack_frag8<T>(v); }
 
-// ---- cooperative tile staging (256 threads) ---------------------------------------------------------
-// dst[r][c] = src[(r0 + r) * ld + c] for r < ROWS, c < COLS; zero where r0 + r >= rmax or c >= cmax
+// ---- register-staged tile copies -------------------------------------------------------------------
+// A [ROWS][COLS] tile of 16-byte vectors split over 256 threads; NV vectors per thread.
+template <typename T, int ROWS, int COLS> struct TileRegs {
+  static constexpr int VEC = Elem<T>::kVec;
+  static constexpr int VPR = COLS / VEC;                       // vectors per row
+  static constexpr int NV = (ROWS * VPR + 255) / 256;
+  uint4 v[NV];
+};
+
+// src rows r0.. (row stride ld elements), columns c0..c0+COLS; rows >= rmax or columns >= cmax read as zero.
+// `fast`: everything in bounds and 16-byte aligned (block-uniform).
 template <typename T, int ROWS, int COLS>
-__device__ __forceinline__ void stage_rowmajor(char* tile, const T* src, int64_t ld, int r0, int rmax, int cmax, int tid) {
-  constexpr int VEC = Elem<T>::kVec;
-  constexpr int VPR = COLS / VEC;
-  for (int v = tid; v < ROWS * VPR; v += 256) {
-    int r = v / VPR, c = (v % VPR) * VEC;
+__device__ __forceinline__ void tile_load(TileRegs<T, ROWS, COLS>& t, const T* src, int64_t ld, int r0, int rmax, int c0,
+                                          int cmax, int tid, bool fast) {
+  using TR = TileRegs<T, ROWS, COLS>;
+#pragma unroll
+  for (int i = 0; i < TR::NV; ++i) {
+    const int v = tid + 256 * i;
+    const int r = v / TR::VPR, c = (v % TR::VPR) * TR::VEC;
     uint4 val = make_uint4(0, 0, 0, 0);
-    if (r0 + r < rmax && c < cmax) {
-      const T* p = src + (int64_t)(r0 + r) * ld + c;
-      if (c + VEC <= cmax && (reinterpret_cast<uintptr_t>(p) & 15) == 0) val = *reinterpret_cast<const uint4*>(p);
-      else {
-        float f[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) f[e] = (c + e < cmax) ? Elem<T>::load(p + e) : 0.f;
-        val = pack16<T>(f);
-      }
-    }
-    *reinterpret_cast<uint4*>(tile + r * Pitch<T, COLS>::v + c * (int)sizeof(T)) = val;
-  }
-}
-// transposed: dst[c][r] = src[(r0 + r) * ld + c]; dst is a [COLS][ROWS] tile
-template <typename T, int ROWS, int COLS>
-__device__ __forceinline__ void stage_transposed(char* tile, const T* src, int64_t ld, int r0, int rmax, int cmax, int tid) {
-  constexpr int VEC = Elem<T>::kVec;
-  constexpr int VPR = COLS / VEC;
-  for (int v = tid; v < (ROWS / 4) * VPR; v += 256) {
-    int rg = v / VPR, c = (v % VPR) * VEC;
-    float f[4][VEC];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int r = r0 + rg * 4 + i;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) f[i][e] = 0.f;
-      if (r < rmax && c < cmax) {
-        const T* p = src + (int64_t)r * ld + c;
-        if (c + VEC <= cmax && (reinterpret_cast<uintptr_t>(p) & 15) == 0) unpack16<T>(*reinterpret_cast<const uint4*>(p), f[i]);
+    if (TR::NV * 256 == ROWS * TR::VPR || v < ROWS * TR::VPR) {
+      if (fast) {
+        val = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * ld + c0 + c);
+      } else if (r0 + r < rmax && c0 + c < cmax) {
+        const T* p = src + (int64_t)(r0 + r) * ld + c0 + c;
+        if (c0 + c + TR::VEC <= cmax && (reinterpret_cast<uintptr_t>(p) & 15) == 0) val = *reinterpret_cast<const uint4*>(p);
         else {
+          float f[TR::VEC];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) f[i][e] = (c + e < cmax) ? Elem<T>::load(p + e) : 0.f;
+          for (int e = 0; e < TR::VEC; ++e) f[e] = (c0 + c + e < cmax) ? Elem<T>::load(p + e) : 0.f;
+          val = pack16<T>(f);
         }
       }
     }
+    t.v[i] = val;
+  }
+}
+template <typename T, int ROWS, int COLS>
+__device__ __forceinline__ void tile_store(const TileRegs<T, ROWS, COLS>& t, char* tile, int tid) {
+  using TR = TileRegs<T, ROWS, COLS>;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      char* d = tile + (c + e) * Pitch<T, ROWS>::v + rg * 4 * (int)sizeof(T);
-      if (sizeof(T) == 2) *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(f[0][e], f[1][e]), pack_bf16x2(f[2][e], f[3][e]));
-      else *reinterpret_cast<uint4*>(d) = make_uint4(__float_as_uint(f[0][e]), __float_as_uint(f[1][e]),
-                                                      __float_as_uint(f[2][e]), __float_as_uint(f[3][e]));
-    }
+  for (int i = 0; i < TR::NV; ++i) {
+    const int v = tid + 256 * i;
+    const int r = v / TR::VPR, c = (v % TR::VPR) * TR::VEC;
+    if (TR::NV * 256 == ROWS * TR::VPR || v < ROWS * TR::VPR)
+      *reinterpret_cast<uint4*>(tile + r * Pitch<T, COLS>::v + c * (int)sizeof(T)) = t.v[i];
   }
 }
 
-// bias tile [AQ q][AK keys] -> fp32 LDS tile with pitch AK + 2 floats... kept in T with 8-byte pad
-template <typename T> struct BiasPitch { static constexpr int v = AK * (int)sizeof(T) + 8; };
+// bias tile [AQ q][AK keys]: pitch chosen for conflict-light 4-key reads by 32 consecutive rows
+template <typename T> struct BiasPitch { static constexpr int v = AK * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16); };
+template <typename T, int ROWS> struct BiasRegs {
+  static constexpr int VEC = Elem<T>::kVec;
+  static constexpr int VPR = AK / VEC;
+  static constexpr int NV = ROWS * VPR / 256;
+  uint4 v[NV];
+};
+// rows are clamped to rmax-1 (their results are discarded), the key range is always inside the padded row
+template <typename T, int ROWS>
+__device__ __forceinline__ void bias_load(BiasRegs<T, ROWS>& t, const T* src, int64_t ld, int r0, int rmax, int c0, int tid) {
+  using BR = BiasRegs<T, ROWS>;
+#pragma unroll
+  for (int i = 0; i < BR::NV; ++i) {
+    const int v = tid + 256 * i;
+    const int r = min(r0 + v / BR::VPR, rmax - 1), c = (v % BR::VPR) * BR::VEC;
+    t.v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c0 + c);
+  }
+}
+template <typename T, int ROWS>
+__device__ __forceinline__ void bias_store(const BiasRegs<T, ROWS>& t, char* tile, int tid) {
+  using BR = BiasRegs<T, ROWS>;
+#pragma unroll
+  for (int i = 0; i < BR::NV; ++i) {
+    const int v = tid + 256 * i;
+    const int r = v / BR::VPR, c = (v % BR::VPR) * BR::VEC;
+    char* d = tile + r * BiasPitch<T>::v + c * (int)sizeof(T);
+    if (sizeof(T) == 2) {
+      *reinterpret_cast<uint2*>(d) = make_uint2(t.v[i].x, t.v[i].y);
+      *reinterpret_cast<uint2*>(d + 8) = make_uint2(t.v[i].z, t.v[i].w);
+    } else {
+      *reinterpret_cast<uint4*>(d) = t.v[i];
+    }
+  }
+}
+// 4 consecutive bias values (fp32) at (row, col) of the staged tile, col multiple of 4
 template <typename T>
-__device__ __forceinline__ void stage_bias(char* tile, const T* bias_bh, int Tn, int q0, int k0, int tid) {
-  // element-granular (rows of the [T, T] map are not 16-byte aligned in general); 64 consecutive keys per row
-  for (int v = tid; v < AQ * AK; v += 256) {
-    int r = v / AK, c = v % AK;
-    T val = (T)0;
-    if (q0 + r < Tn && k0 + c < Tn) val = bias_bh[(int64_t)(q0 + r) * Tn + k0 + c];
-    *reinterpret_cast<T*>(tile + r * BiasPitch<T>::v + c * (int)sizeof(T)) = val;
+__device__ __forceinline__ void bias_read4(const char* tile, int row, int col, float* out) {
+  const char* p = tile + row * BiasPitch<T>::v + col * (int)sizeof(T);
+  if (sizeof(T) == 2) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    out[0] = __uint_as_float(u.x << 16); out[1] = __uint_as_float(u.x & 0xffff0000u);
+    out[2] = __uint_as_float(u.y << 16); out[3] = __uint_as_float(u.y & 0xffff0000u);
+  } else {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    out[0] = __uint_as_float(u.x); out[1] = __uint_as_float(u.y); out[2] = __uint_as_float(u.z); out[3] = __uint_as_float(u.w);
   }
 }
 
 struct AttnParams {
   const void* q; const void* k; const void* v; int64_t ld;
-  int B, nh, T, d; float scale;
-  const void* bias; const int32_t* mask;
+  const void* vt; const void* kt; const void* qt; const void* dot;  // [B, nh, DP, Tp] transposed copies
+  int B, nh, T, d, Tp; float scale;
+  const void* bias; int64_t bias_ld; const float* key_bias;       // bias [B, nh, T, bias_ld]; key_bias [B, Tp]
   void* out; int64_t ld_out; float* lse;
   float drop_p; uint32_t seed;
-  // backward only
   const void* d_out; void* dq; void* dk; void* dv; int64_t ld_d; float* g_bias; float* delta;
 };
+
+// 8 elements of row `row` starting at column c of a [rows, ld] matrix -> fragment (zero beyond rmax / cmax)
+template <typename T>
+__device__ __forceinline__ Frag<T> frag_from_global(const T* base, int64_t ld, int row, int rmax, int c, int cmax) {
+  float f[8];
+  const T* p = base + (int64_t)row * ld + c;
+  if (row < rmax && c + 8 <= cmax && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    if (sizeof(T) == 2) unpack16<T>(*reinterpret_cast<const uint4*>(p), f);
+    else { unpack16<T>(*reinterpret_cast<const uint4*>(p), f); unpack16<T>(*reinterpret_cast<const uint4*>(p + 4), f + 4); }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (row < rmax && c + e < cmax) ? Elem<T>::load(p + e) : 0.f;
+  }
+  return pack_frag8<T>(f);
+}
+
+// per-wave [32 rows][DP] fp32 tile in LDS -> rows of a [*, ld] matrix (16-byte stores when possible)
+template <typename T, int DP>
+__device__ __forceinline__ void store_rows(const float* myO, T* dst, int64_t ld, int row0, int rmax, int d, int lane) {
+  constexpr int VEC = Elem<T>::kVec;
+  const bool vec_ok = (d % VEC == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && ((ld * (int64_t)sizeof(T)) % 16 == 0);
+  if (vec_ok) {
+    const int vpr = d / VEC;
+    for (int v = lane; v < 32 * vpr; v += 64) {
+      const int r = v / vpr, c = (v % vpr) * VEC;
+      if (row0 + r < rmax) {
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = myO[r * (DP + 1) + c + e];
+        *reinterpret_cast<uint4*>(dst + (int64_t)(row0 + r) * ld + c) = pack16<T>(f);
+      }
+    }
+  } else {
+    for (int v = lane; v < 32 * d; v += 64) {
+      const int r = v / d, c = v % d;
+      if (row0 + r < rmax) Elem<T>::store(dst + (int64_t)(row0 + r) * ld + c, myO[r * (DP + 1) + c]);
+    }
+  }
+}
+
+// ================================================================================================
+// per-head transposed copy: dst[b, h, c, t] = src[(b*T + t) * ld + h*d + c]  (zero padded to DP x Tp)
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void head_transpose_kernel(const T* src, int64_t ld, int Tn, int d, int nh, T* dst, int DP, int Tp) {
+  __shared__ float tile[32][33];
+  const int bh = blockIdx.z, b = bh / nh, h = bh % nh;
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    tile[i][tx] = (t < Tn && c < d) ? Elem<T>::load(src + ((int64_t)b * Tn + t) * ld + h * d + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    if (c < DP && t < Tp) Elem<T>::store(dst + (((int64_t)bh * DP + c) * Tp + t), tile[tx][i]);
+  }
+}
 
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int DP>
+template <typename T, int DP, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KS = DP / 16;       // k-steps over the head dim
-  constexpr int DT = DP / 32;       // 32-row tiles of the head dim (output rows)
+  constexpr int KS = DP / 16, DT = DP / 32;
   char* sK = smem;                                   // [AK][DP]
   char* sVt = sK + AK * Pitch<T, DP>::v;             // [DP][AK]
   char* sB = sVt + DP * Pitch<T, AK>::v;             // [AQ][AK] bias
-  int* sValid = reinterpret_cast<int*>(sB + AQ * BiasPitch<T>::v);  // [AK] key validity
+  float* sKb = reinterpret_cast<float*>(sB + AQ * BiasPitch<T>::v);  // [AK] additive key bias (log2 units)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
-  const int Tn = p.T, d = p.d;
+  const int Tn = p.T, d = p.d, Tp = p.Tp;
   const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + h * d;
   const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * d;
-  const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + h * d;
-  const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * Tn : nullptr;
-  const int32_t* mask = p.mask ? p.mask + (int64_t)b * Tn : nullptr;
+  const T* Vt = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.nh + h) * DP * Tp;
+  const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
+  const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
+  const int qrow = wave * 32 + (lane & 31);
   const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float sc2 = p.scale * LOG2E;
+  const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
-  // Q fragments straight from global: lane (q, half) holds d-elements 16*ks + 8*half .. +8
   Frag<T> qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    float f[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = 16 * ks + 8 * half + e;
-      f[e] = (myq < Tn && c < d) ? Elem<T>::load(Q + (int64_t)myq * p.ld + c) : 0.f;
-    }
-    qf[ks] = pack_acc<T>(f);
-  }
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_from_global<T>(Q, p.ld, myq, Tn, 16 * ks + 8 * half, d);
 
   f32x16_t o[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
+  float m_run = MASKED, l_run = 0.f;
 
-  for (int k0 = 0; k0 < Tn; k0 += AK) {
+  TileRegs<T, AK, DP> rk;
+  TileRegs<T, DP, AK> rv;
+  BiasRegs<T, AQ> rb;
+  const int ntile = (Tn + AK - 1) / AK;
+#define FWD_PREFETCH(t_)                                                                 \
+  {                                                                                      \
+    const int k0_ = (t_) * AK;                                                           \
+    tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + AK <= Tn);       \
+    tile_load<T, DP, AK>(rv, Vt, Tp, 0, DP, k0_, Tp, tid, true);                         \
+    if (bias) bias_load<T, AQ>(rb, bias, p.bias_ld, q0, Tn, k0_, tid);                   \
+  }
+  FWD_PREFETCH(0)
+  for (int t = 0; t < ntile; ++t) {
+    const int k0 = t * AK;
     __syncthreads();  // previous tile fully consumed
-    stage_rowmajor<T, AK, DP>(sK, K, p.ld, k0, Tn, d, tid);
-    stage_transposed<T, AK, DP>(sVt, V, p.ld, k0, Tn, d, tid);
-    if (bias) stage_bias<T>(sB, bias, Tn, q0, k0, tid);
-    if (tid < AK) sValid[tid] = (k0 + tid < Tn && (!mask || mask[k0 + tid] != 0)) ? 1 : 0;
+    tile_store<T, AK, DP>(rk, sK, tid);
+    tile_store<T, DP, AK>(rv, sVt, tid);
+    if (bias) bias_store<T, AQ>(rb, sB, tid);
+    if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] * LOG2E : 0.f) : MASKED;
     __syncthreads();
+    FWD_PREFETCH(t + 1 < ntile ? t + 1 : t)   // unconditional: keeps the staging registers out of scratch
 
     // S^T[key, q] for the 64 keys of this tile
     f32x16_t s[2];
@@ -207,33 +308,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         mma_step(kf, qf[ks], s[kt]);
       }
     }
-    // scale + bias + mask, running max
-    float mt = NEG_BIG;
+    // log2-domain scores, running max
+    float mt = MASKED;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = kt * 32 + acc_row(r, lane);  // key within tile
-        const int key = k0 + kl;
-        float v = s[kt][r] * p.scale;
-        if (bias) v += Elem<T>::load(reinterpret_cast<const T*>(sB + (wave * 32 + (lane & 31)) * BiasPitch<T>::v) + kl);
-        (void)key;
-        v = sValid[kl] ? v : NEG_BIG;
-        s[kt][r] = v;
-        mt = fmaxf(mt, v);
+      for (int g = 0; g < 4; ++g) {
+        const int kl = kt * 32 + 8 * g + 4 * half;   // 4 consecutive keys: regs 4g .. 4g+3
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bias_read4<T>(sB, qrow, kl, bb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = fmaf(s[kt][4 * g + e], sc2, fmaf(bb[e], LOG2E, sKb[kl + e]));
+          s[kt][4 * g + e] = v;
+          mt = fmaxf(mt, v);
+        }
       }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = __expf(m_run - m_new);   // m_run = NEG_BIG first time: exp(-inf-ish) = 0 (l_run, o are 0 anyway)
+    const float alpha = fast_exp2(m_run - m_new);
     float ls = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = s[kt][r];
-        float e = (v <= NEG_BIG * 0.5f) ? 0.f : __expf(v - m_new);
+        float e = fast_exp2(s[kt][r] - m_new);
         ls += e;
-        if (p.drop_p > 0.f) {
+        if (DROP) {
           const int key = k0 + kt * 32 + acc_row(r, lane);
           uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)myq) * Tn + key;
           e = dropout_keep(p.seed, idx, thresh) ? e * keep_scale : 0.f;
@@ -244,41 +345,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     l_run = l_run * alpha + ls;
     m_run = m_new;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t2 = 0; t2 < DT; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
     // O^T[d, q] += V^T[d, key] . P^T[key, q]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       float pv[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) pv[t] = s[kk >> 1][8 * (kk & 1) + t];
-      Frag<T> pf = pack_acc<T>(pv);
+      for (int e = 0; e < 8; ++e) pv[e] = s[kk >> 1][8 * (kk & 1) + e];
+      Frag<T> pf = pack_frag8<T>(pv);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        Frag<T> vf = FragReader<T, AK>::perm(sVt, t * 32 + (lane & 31), 16 * kk + 4 * half);
-        mma_step(vf, pf, o[t]);
+      for (int t2 = 0; t2 < DT; ++t2) {
+        Frag<T> vf = FragReader<T, AK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+        mma_step(vf, pf, o[t2]);
       }
     }
   }
+#undef FWD_PREFETCH
 
-  // normalise and write O[q, d] through LDS (transpose to row-major rows of 16-byte vectors)
+  // normalise and write O[q, d] through LDS (transpose to row-major rows)
   __syncthreads();
-  float* sO = reinterpret_cast<float*>(smem);  // per wave [32 q][DP + 1] fp32
-  float* myO = sO + wave * 32 * (DP + 1);
-  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
+  const bool any = m_run > 0.5f * MASKED;
+  const float inv = (any && l_run > 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = o[t][r] * inv;
-  if (half == 0 && myq < Tn && p.lse) p.lse[((int64_t)b * p.nh + h) * Tn + myq] = (l_run > 0.f) ? m_run + __logf(l_run) : NEG_BIG;
+  if (half == 0 && myq < Tn && p.lse) p.lse[((int64_t)b * p.nh + h) * Tn + myq] = any ? m_run + log2f(l_run) : MASKED;  // log2 units
   __syncthreads();
   T* O = reinterpret_cast<T*>(p.out) + (int64_t)b * Tn * p.ld_out + h * d;
-  for (int v = lane; v < 32 * d; v += 64) {
-    int r = v / d, c = v % d;
-    int qq = q0 + wave * 32 + r;
-    if (qq < Tn) Elem<T>::store(O + (int64_t)qq * p.ld_out + c, myO[r * (DP + 1) + c]);
-  }
+  store_rows<T, DP>(myO, O, p.ld_out, q0 + wave * 32, Tn, d, lane);
 }
 
 // ================================================================================================
@@ -304,7 +402,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 // ================================================================================================
 // backward, part 1: dQ (and the accumulated bias gradient).  Workgroup = 128 queries, streams key tiles.
 // ================================================================================================
-template <typename T, int DP>
+template <typename T, int DP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DP / 16, DT = DP / 32;
@@ -312,38 +410,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   char* sV = sK + AK * Pitch<T, DP>::v;              // [AK][DP]
   char* sKt = sV + AK * Pitch<T, DP>::v;             // [DP][AK]
   char* sB = sKt + DP * Pitch<T, AK>::v;             // [AQ][AK] bias (T)
-  float* sG = reinterpret_cast<float*>(sB + AQ * BiasPitch<T>::v);  // [AQ][AK + 1] fp32 dS staging
-  int* sValid = reinterpret_cast<int*>(sG + AQ * (AK + 1));         // [AK] key validity
+  float* sKb = reinterpret_cast<float*>(sB + AQ * BiasPitch<T>::v);  // [AK]
+  float* sG = sKb + AK;                              // [AQ][AK + 4] fp32 dS staging
+  constexpr int GP = AK + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
-  const int Tn = p.T, d = p.d;
+  const int Tn = p.T, d = p.d, Tp = p.Tp;
   const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + h * d;
   const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * d;
   const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + h * d;
+  const T* Kt = reinterpret_cast<const T*>(p.kt) + ((int64_t)b * p.nh + h) * DP * Tp;
   const T* dO = reinterpret_cast<const T*>(p.d_out) + (int64_t)b * Tn * p.ld_out + h * d;
-  const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * Tn : nullptr;
-  float* G = p.g_bias ? p.g_bias + ((int64_t)b * p.nh + h) * Tn * Tn : nullptr;
-  const int32_t* mask = p.mask ? p.mask + (int64_t)b * Tn : nullptr;
+  const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
+  float* G = p.g_bias ? p.g_bias + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
+  const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
+  const int qrow = wave * 32 + (lane & 31);
   const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float sc2 = p.scale * LOG2E;
+  const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((reinterpret_cast<uintptr_t>(V) & 15) == 0) &&
+                    ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
   Frag<T> qf[KS], dof[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    float f[8], g[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = 16 * ks + 8 * half + e;
-      bool ok = myq < Tn && c < d;
-      f[e] = ok ? Elem<T>::load(Q + (int64_t)myq * p.ld + c) : 0.f;
-      g[e] = ok ? Elem<T>::load(dO + (int64_t)myq * p.ld_out + c) : 0.f;
-    }
-    qf[ks] = pack_acc<T>(f);
-    dof[ks] = pack_acc<T>(g);
+    qf[ks] = frag_from_global<T>(Q, p.ld, myq, Tn, 16 * ks + 8 * half, d);
+    dof[ks] = frag_from_global<T>(dO, p.ld_out, myq, Tn, 16 * ks + 8 * half, d);
   }
   const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + myq;
-  const float my_lse = myq < Tn ? p.lse[rowid] : 0.f;
+  const float my_lse = myq < Tn ? p.lse[rowid] : 0.f;      // log2 units
   const float my_delta = myq < Tn ? p.delta[rowid] : 0.f;
 
   f32x16_t dq[DT];
@@ -352,14 +448,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
 
-  for (int k0 = 0; k0 < Tn; k0 += AK) {
+  TileRegs<T, AK, DP> rk, rv;
+  TileRegs<T, DP, AK> rkt;
+  BiasRegs<T, AQ> rb;
+  const int ntile = (Tn + AK - 1) / AK;
+#define DQ_PREFETCH(t_)                                                                  \
+  {                                                                                      \
+    const int k0_ = (t_) * AK;                                                           \
+    const bool fast_ = k_al && k0_ + AK <= Tn;                                           \
+    tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, fast_);                        \
+    tile_load<T, AK, DP>(rv, V, p.ld, k0_, Tn, 0, d, tid, fast_);                        \
+    tile_load<T, DP, AK>(rkt, Kt, Tp, 0, DP, k0_, Tp, tid, true);                        \
+    if (bias) bias_load<T, AQ>(rb, bias, p.bias_ld, q0, Tn, k0_, tid);                   \
+  }
+  DQ_PREFETCH(0)
+  for (int t = 0; t < ntile; ++t) {
+    const int k0 = t * AK;
     __syncthreads();
-    stage_rowmajor<T, AK, DP>(sK, K, p.ld, k0, Tn, d, tid);
-    stage_rowmajor<T, AK, DP>(sV, V, p.ld, k0, Tn, d, tid);
-    stage_transposed<T, AK, DP>(sKt, K, p.ld, k0, Tn, d, tid);
-    if (bias) stage_bias<T>(sB, bias, Tn, q0, k0, tid);
-    if (tid < AK) sValid[tid] = (k0 + tid < Tn && (!mask || mask[k0 + tid] != 0)) ? 1 : 0;
+    tile_store<T, AK, DP>(rk, sK, tid);
+    tile_store<T, AK, DP>(rv, sV, tid);
+    tile_store<T, DP, AK>(rkt, sKt, tid);
+    if (bias) bias_store<T, AQ>(rb, sB, tid);
+    if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] * LOG2E : 0.f) : MASKED;
     __syncthreads();
+    DQ_PREFETCH(t + 1 < ntile ? t + 1 : t)
 
     f32x16_t s[2], dp[2];
 #pragma unroll
@@ -377,64 +489,69 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = kt * 32 + acc_row(r, lane);
-        const int key = k0 + kl;
-        float v = s[kt][r] * p.scale;
-        if (bias) v += Elem<T>::load(reinterpret_cast<const T*>(sB + (wave * 32 + (lane & 31)) * BiasPitch<T>::v) + kl);
-        const bool valid = sValid[kl] != 0 && myq < Tn;
-        float pr = valid ? __expf(v - my_lse) : 0.f;
-        float dpv = dp[kt][r];
-        if (p.drop_p > 0.f) {
-          uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)myq) * Tn + key;
-          dpv = dropout_keep(p.seed, idx, thresh) ? dpv * keep_scale : 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const int kl = kt * 32 + 8 * g + 4 * half;
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bias_read4<T>(sB, qrow, kl, bb);
+        float dsv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(s[kt][4 * g + e], sc2, fmaf(bb[e], LOG2E, sKb[kl + e]));
+          const float pr = (myq < Tn) ? fast_exp2(v - my_lse) : 0.f;
+          float dpv = dp[kt][4 * g + e];
+          if (DROP) {
+            uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)myq) * Tn + (k0 + kl + e);
+            dpv = dropout_keep(p.seed, idx, thresh) ? dpv * keep_scale : 0.f;
+          }
+          dsv[e] = pr * (dpv - my_delta);
+          s[kt][4 * g + e] = dsv[e];
         }
-        float ds = pr * (dpv - my_delta);
-        s[kt][r] = ds;
-        if (G) sG[(wave * 32 + (lane & 31)) * (AK + 1) + kl] = ds;
+        if (G) *reinterpret_cast<float4*>(sG + qrow * GP + kl) = make_float4(dsv[0], dsv[1], dsv[2], dsv[3]);
       }
     // dQ^T[d, q] += K^T[d, key] . dS^T[key, q]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       float pv[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) pv[t] = s[kk >> 1][8 * (kk & 1) + t];
-      Frag<T> pf = pack_acc<T>(pv);
+      for (int e = 0; e < 8; ++e) pv[e] = s[kk >> 1][8 * (kk & 1) + e];
+      Frag<T> pf = pack_frag8<T>(pv);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        Frag<T> kf = FragReader<T, AK>::perm(sKt, t * 32 + (lane & 31), 16 * kk + 4 * half);
-        mma_step(kf, pf, dq[t]);
+      for (int t2 = 0; t2 < DT; ++t2) {
+        Frag<T> kf = FragReader<T, AK>::perm(sKt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+        mma_step(kf, pf, dq[t2]);
       }
     }
-    if (G) {  // coalesced read-modify-write of the bias-gradient tile (this workgroup owns it)
+    if (G) {  // coalesced read-modify-write of the bias-gradient tile (this workgroup owns it); rows are 16-byte aligned
       __syncthreads();
-      for (int v = tid; v < AQ * AK; v += 256) {
-        int r = v / AK, c = v % AK;
-        if (q0 + r < Tn && k0 + c < Tn) G[(int64_t)(q0 + r) * Tn + k0 + c] += sG[r * (AK + 1) + c];
+      for (int v = tid; v < AQ * (AK / 4); v += 256) {
+        const int r = v / (AK / 4), c = (v % (AK / 4)) * 4;
+        if (q0 + r < Tn) {
+          float4* gp = reinterpret_cast<float4*>(G + (int64_t)(q0 + r) * p.bias_ld + k0 + c);
+          float4 a = *gp;
+          const float4 sgv = *reinterpret_cast<const float4*>(sG + r * GP + c);
+          a.x += sgv.x; a.y += sgv.y; a.z += sgv.z; a.w += sgv.w;
+          *gp = a;
+        }
       }
     }
   }
+#undef DQ_PREFETCH
 
   __syncthreads();
-  float* sO = reinterpret_cast<float*>(smem);
-  float* myO = sO + wave * 32 * (DP + 1);
+  float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = dq[t][r] * p.scale;
   __syncthreads();
   T* DQ = reinterpret_cast<T*>(p.dq) + (int64_t)b * Tn * p.ld_d + h * d;
-  for (int v = lane; v < 32 * d; v += 64) {
-    int r = v / d, c = v % d;
-    int qq = q0 + wave * 32 + r;
-    if (qq < Tn) Elem<T>::store(DQ + (int64_t)qq * p.ld_d + c, myO[r * (DP + 1) + c]);
-  }
+  store_rows<T, DP>(myO, DQ, p.ld_d, q0 + wave * 32, Tn, d, lane);
 }
 
 // ================================================================================================
 // backward, part 2: dK, dV.  Workgroup = 128 keys (lane = key), streams query tiles of 64.
 // ================================================================================================
-template <typename T, int DP>
+template <typename T, int DP, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DP / 16, DT = DP / 32;
@@ -444,35 +561,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   char* sdOt = sQt + DP * Pitch<T, AK>::v;            // [DP][AK q]
   float* sLse = reinterpret_cast<float*>(sdOt + DP * Pitch<T, AK>::v);  // [AK]
   float* sDelta = sLse + AK;                          // [AK]
-  char* sB = reinterpret_cast<char*>(sDelta + AK);    // bias^T staging: [AK q][AQ keys] T, pitch AQ*sizeof(T)+8
-  constexpr int BP = AQ * (int)sizeof(T) + 8;
+  char* sB = reinterpret_cast<char*>(sDelta + AK);    // bias: [AK q][AQ keys] T
+  constexpr int BP = AQ * (int)sizeof(T) + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * AQ;
-  const int Tn = p.T, d = p.d;
+  const int Tn = p.T, d = p.d, Tp = p.Tp;
   const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + h * d;
   const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * d;
   const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + h * d;
   const T* dO = reinterpret_cast<const T*>(p.d_out) + (int64_t)b * Tn * p.ld_out + h * d;
-  const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * Tn : nullptr;
-  const int32_t* mask = p.mask ? p.mask + (int64_t)b * Tn : nullptr;
+  const T* Qt = reinterpret_cast<const T*>(p.qt) + ((int64_t)b * p.nh + h) * DP * Tp;
+  const T* dOt = reinterpret_cast<const T*>(p.dot) + ((int64_t)b * p.nh + h) * DP * Tp;
+  const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
   const int mykey = key0 + wave * 32 + (lane & 31);
-  const bool key_valid = mykey < Tn && (!mask || mask[mykey] != 0);
+  const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] * LOG2E : 0.f) : MASKED;
   const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float sc2 = p.scale * LOG2E;
+  const bool q_al = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
+  const bool do_al = ((reinterpret_cast<uintptr_t>(dO) & 15) == 0) && ((p.ld_out * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
   Frag<T> kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    float f[8], g[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int c = 16 * ks + 8 * half + e;
-      bool ok = mykey < Tn && c < d;
-      f[e] = ok ? Elem<T>::load(K + (int64_t)mykey * p.ld + c) : 0.f;
-      g[e] = ok ? Elem<T>::load(V + (int64_t)mykey * p.ld + c) : 0.f;
-    }
-    kf[ks] = pack_acc<T>(f);
-    vf[ks] = pack_acc<T>(g);
+    kf[ks] = frag_from_global<T>(K, p.ld, mykey, Tn, 16 * ks + 8 * half, d);
+    vf[ks] = frag_from_global<T>(V, p.ld, mykey, Tn, 16 * ks + 8 * half, d);
   }
   f32x16_t dk[DT], dv[DT];
 #pragma unroll
@@ -480,27 +593,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
 
-  for (int q0 = 0; q0 < Tn; q0 += AK) {
+  TileRegs<T, AK, DP> rq, rdo;
+  TileRegs<T, DP, AK> rqt, rdot;
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int BNV = AK * (AQ / VEC) / 256;   // bias^T tile [AK q rows][AQ keys]
+  uint4 rbias[BNV];
+  const int ntile = (Tn + AK - 1) / AK;
+#define DKV_PREFETCH(t_)                                                                 \
+  {                                                                                      \
+    const int q0_ = (t_) * AK;                                                           \
+    tile_load<T, AK, DP>(rq, Q, p.ld, q0_, Tn, 0, d, tid, q_al && q0_ + AK <= Tn);       \
+    tile_load<T, AK, DP>(rdo, dO, p.ld_out, q0_, Tn, 0, d, tid, do_al && q0_ + AK <= Tn); \
+    tile_load<T, DP, AK>(rqt, Qt, Tp, 0, DP, q0_, Tp, tid, true);                        \
+    tile_load<T, DP, AK>(rdot, dOt, Tp, 0, DP, q0_, Tp, tid, true);                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < BNV; ++i_) {                                 \
+      const int v_ = tid + 256 * i_;                                                     \
+      const int r_ = min(q0_ + v_ / (AQ / VEC), Tn - 1), c_ = (v_ % (AQ / VEC)) * VEC;   \
+      const int cc_ = min(key0 + c_, (int)p.bias_ld - VEC);  /* window may pass the padded row end: masked anyway */ \
+      /* unconditional load (a predicated one sends rbias to scratch): without bias read a harmless valid address */ \
+      const T* bp_ = bias ? bias + (int64_t)r_ * p.bias_ld + cc_ : Qt;                   \
+      rbias[i_] = *reinterpret_cast<const uint4*>(bp_);                                  \
+    }                                                                                    \
+  }
+  DKV_PREFETCH(0)
+  for (int t = 0; t < ntile; ++t) {
+    const int q0 = t * AK;
     __syncthreads();
-    stage_rowmajor<T, AK, DP>(sQ, Q, p.ld, q0, Tn, d, tid);
-    stage_rowmajor<T, AK, DP>(sdO, dO, p.ld_out, q0, Tn, d, tid);
-    stage_transposed<T, AK, DP>(sQt, Q, p.ld, q0, Tn, d, tid);
-    stage_transposed<T, AK, DP>(sdOt, dO, p.ld_out, q0, Tn, d, tid);
+    tile_store<T, AK, DP>(rq, sQ, tid);
+    tile_store<T, AK, DP>(rdo, sdO, tid);
+    tile_store<T, DP, AK>(rqt, sQt, tid);
+    tile_store<T, DP, AK>(rdot, sdOt, tid);
     if (tid < AK) {
-      int qq = q0 + tid;
-      int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
+      const int qq = q0 + tid;
+      const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
       sLse[tid] = qq < Tn ? p.lse[rowid] : 0.f;
       sDelta[tid] = qq < Tn ? p.delta[rowid] : 0.f;
     }
     if (bias) {
-      for (int v = tid; v < AK * AQ; v += 256) {
-        int r = v / AQ, c = v % AQ;  // r: query within tile, c: key within workgroup (contiguous in memory)
-        T val = (T)0;
-        if (q0 + r < Tn && key0 + c < Tn) val = bias[(int64_t)(q0 + r) * Tn + key0 + c];
-        *reinterpret_cast<T*>(sB + r * BP + c * (int)sizeof(T)) = val;
+#pragma unroll
+      for (int i = 0; i < BNV; ++i) {
+        const int v = tid + 256 * i;
+        const int r = v / (AQ / VEC), c = (v % (AQ / VEC)) * VEC;
+        *reinterpret_cast<uint4*>(sB + r * BP + c * (int)sizeof(T)) = rbias[i];
       }
     }
     __syncthreads();
+    DKV_PREFETCH(t + 1 < ntile ? t + 1 : t)
 
     // S[q, key] and dP[q, key]: A = Q / dO tiles (rows = q), B = K / V fragments (lane = key)
     f32x16_t s[2], dp[2];
@@ -523,13 +661,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const int ql = qt * 32 + acc_row(r, lane);
         const int qq = q0 + ql;
-        float v = s[qt][r] * p.scale;
-        if (bias) v += Elem<T>::load(reinterpret_cast<const T*>(sB + ql * BP) + wave * 32 + (lane & 31));
-        const bool valid = key_valid && qq < Tn;
-        float pv = valid ? __expf(v - sLse[ql]) : 0.f;
+        float bv = 0.f;
+        if (bias) bv = Elem<T>::load(reinterpret_cast<const T*>(sB + ql * BP) + wave * 32 + (lane & 31));
+        const float v = fmaf(s[qt][r], sc2, fmaf(bv, LOG2E, my_kb));
+        const float pv = (qq < Tn) ? fast_exp2(v - sLse[ql]) : 0.f;
         float dpv = dp[qt][r];
         float pdrop = pv;
-        if (p.drop_p > 0.f) {
+        if (DROP) {
           uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)qq) * Tn + mykey;
           bool keep = dropout_keep(p.seed, idx, thresh);
           dpv = keep ? dpv * keep_scale : 0.f;
@@ -543,21 +681,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     for (int kk = 0; kk < 4; ++kk) {
       float a[8], c[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) { a[t] = pr[kk >> 1][8 * (kk & 1) + t]; c[t] = s[kk >> 1][8 * (kk & 1) + t]; }
-      Frag<T> pf = pack_acc<T>(a), dsf = pack_acc<T>(c);
+      for (int e = 0; e < 8; ++e) { a[e] = pr[kk >> 1][8 * (kk & 1) + e]; c[e] = s[kk >> 1][8 * (kk & 1) + e]; }
+      Frag<T> pf = pack_frag8<T>(a), dsf = pack_frag8<T>(c);
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        Frag<T> dot = FragReader<T, AK>::perm(sdOt, t * 32 + (lane & 31), 16 * kk + 4 * half);
-        mma_step(dot, pf, dv[t]);
-        Frag<T> qt_ = FragReader<T, AK>::perm(sQt, t * 32 + (lane & 31), 16 * kk + 4 * half);
-        mma_step(qt_, dsf, dk[t]);
+      for (int t2 = 0; t2 < DT; ++t2) {
+        Frag<T> dot = FragReader<T, AK>::perm(sdOt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+        mma_step(dot, pf, dv[t2]);
+        Frag<T> qt_ = FragReader<T, AK>::perm(sQt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+        mma_step(qt_, dsf, dk[t2]);
       }
     }
   }
+#undef DKV_PREFETCH
 
   __syncthreads();
-  float* sO = reinterpret_cast<float*>(smem);
-  float* myO = sO + wave * 32 * (DP + 1);
+  float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
   T* DK = reinterpret_cast<T*>(p.dk) + (int64_t)b * Tn * p.ld_d + h * d;
   T* DV = reinterpret_cast<T*>(p.dv) + (int64_t)b * Tn * p.ld_d + h * d;
 #pragma unroll
@@ -568,30 +706,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r)
         myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = which == 0 ? dk[t][r] * p.scale : dv[t][r];
     __syncthreads();
-    T* dst = which == 0 ? DK : DV;
-    for (int v = lane; v < 32 * d; v += 64) {
-      int r = v / d, c = v % d;
-      int kk = key0 + wave * 32 + r;
-      if (kk < Tn) Elem<T>::store(dst + (int64_t)kk * p.ld_d + c, myO[r * (DP + 1) + c]);
-    }
+    store_rows<T, DP>(myO, which == 0 ? DK : DV, p.ld_d, key0 + wave * 32, Tn, d, lane);
     __syncthreads();
   }
 }
 
 template <typename T, int DP> static size_t fwd_smem() {
-  size_t a = (size_t)AK * Pitch<T, DP>::v + (size_t)DP * Pitch<T, AK>::v + (size_t)AQ * BiasPitch<T>::v + AK * sizeof(int);
+  size_t a = (size_t)AK * Pitch<T, DP>::v + (size_t)DP * Pitch<T, AK>::v + (size_t)AQ * BiasPitch<T>::v + AK * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
 template <typename T, int DP> static size_t dq_smem() {
   size_t a = (size_t)2 * AK * Pitch<T, DP>::v + (size_t)DP * Pitch<T, AK>::v + (size_t)AQ * BiasPitch<T>::v +
-             (size_t)AQ * (AK + 1) * sizeof(float) + AK * sizeof(int);
+             AK * sizeof(float) + (size_t)AQ * (AK + 4) * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
 template <typename T, int DP> static size_t dkv_smem() {
   size_t a = (size_t)2 * AK * Pitch<T, DP>::v + (size_t)2 * DP * Pitch<T, AK>::v + 2 * AK * sizeof(float) +
-             (size_t)AK * (AQ * sizeof(T) + 8);
+             (size_t)AK * (AQ * sizeof(T) + 16);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
@@ -607,33 +740,41 @@ static int set_smem(KernelT kern, size_t bytes) {
   return PENEO_OK;
 }
 
-template <typename T, int DP>
-static int launch_fwd(const AttnParams& p, hipStream_t st) {
+template <typename T, int DP, bool DROP>
+static int launch_fwd_d(const AttnParams& p, hipStream_t st) {
   size_t sh = fwd_smem<T, DP>();
-  int rc = set_smem(attn_fwd_kernel<T, DP>, sh);
+  int rc = set_smem(attn_fwd_kernel<T, DP, DROP>, sh);
   if (rc) return rc;
   dim3 grid((p.T + AQ - 1) / AQ, p.nh, p.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DP>), grid, dim3(256), sh, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP>), grid, dim3(256), sh, st, p);
   return check_launch("peneo_attn_fwd");
 }
 template <typename T, int DP>
-static int launch_bwd(const AttnParams& p, hipStream_t st) {
+static int launch_fwd(const AttnParams& p, hipStream_t st) {
+  return p.drop_p > 0.f ? launch_fwd_d<T, DP, true>(p, st) : launch_fwd_d<T, DP, false>(p, st);
+}
+template <typename T, int DP, bool DROP>
+static int launch_bwd_d(const AttnParams& p, hipStream_t st) {
   int64_t rows = (int64_t)p.B * p.nh * p.T;
   hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   int rc = check_launch("peneo_attn_bwd(delta)");
   if (rc) return rc;
   dim3 grid((p.T + AQ - 1) / AQ, p.nh, p.B);
   size_t s1 = dq_smem<T, DP>();
-  rc = set_smem(attn_bwd_dq_kernel<T, DP>, s1);
+  rc = set_smem(attn_bwd_dq_kernel<T, DP, DROP>, s1);
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP>), grid, dim3(256), s1, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP, DROP>), grid, dim3(256), s1, st, p);
   rc = check_launch("peneo_attn_bwd(dq)");
   if (rc) return rc;
   size_t s2 = dkv_smem<T, DP>();
-  rc = set_smem(attn_bwd_dkv_kernel<T, DP>, s2);
+  rc = set_smem(attn_bwd_dkv_kernel<T, DP, DROP>, s2);
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP>), grid, dim3(256), s2, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP, DROP>), grid, dim3(256), s2, st, p);
   return check_launch("peneo_attn_bwd(dkv)");
+}
+template <typename T, int DP>
+static int launch_bwd(const AttnParams& p, hipStream_t st) {
+  return p.drop_p > 0.f ? launch_bwd_d<T, DP, true>(p, st) : launch_bwd_d<T, DP, false>(p, st);
 }
 
 template <typename T>
@@ -651,30 +792,62 @@ static int dispatch(const AttnParams& p, bool bwd, hipStream_t st) {
 }  // namespace peneo
 using namespace peneo;
 
-extern "C" int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv, int B, int nh, int T,
-                              int d, float scale, const void* bias, const int32_t* key_mask, void* out, int64_t ld_out,
-                              float* lse, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
-  PENEO_REQUIRE(dtype == PENEO_F32 || dtype == PENEO_BF16, "peneo_attn_fwd: bad dtype");
-  PENEO_REQUIRE(q && k && v && out && B > 0 && nh > 0 && T > 0 && d > 0, "peneo_attn_fwd: bad arguments");
-  PENEO_REQUIRE(ld_qkv >= (int64_t)nh * d && ld_out >= (int64_t)nh * d, "peneo_attn_fwd: leading dims too small");
+extern "C" int peneo_attn_padded_len(int T) { return (T + 63) / 64 * 64; }
+extern "C" int peneo_attn_padded_dim(int d) { return (d + 31) / 32 * 32; }
+
+extern "C" int peneo_head_transpose(int dtype, const void* src, int64_t ld, int B, int nh, int T, int d, void* dst,
+                                    peneo_stream_t stream) {
+  PENEO_REQUIRE(dtype == PENEO_F32 || dtype == PENEO_BF16, "peneo_head_transpose: bad dtype");
+  PENEO_REQUIRE(src && dst && B > 0 && nh > 0 && T > 0 && d > 0 && ld >= (int64_t)nh * d, "peneo_head_transpose: bad arguments");
+  const int DP = peneo_attn_padded_dim(d), Tp = peneo_attn_padded_len(T);
+  dim3 grid(Tp / 32, DP / 32, B * nh);
+  if (dtype == PENEO_BF16)
+    hipLaunchKernelGGL(head_transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld, T, d, nh, (bf16_t*)dst, DP, Tp);
+  else
+    hipLaunchKernelGGL(head_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld, T, d, nh, (float*)dst, DP, Tp);
+  return check_launch("peneo_head_transpose");
+}
+
+static int attn_common_check(const char* who, int dtype, int B, int nh, int T, int d, const void* bias, int64_t bias_ld) {
+  PENEO_REQUIRE(dtype == PENEO_F32 || dtype == PENEO_BF16, "%s: bad dtype", who);
+  PENEO_REQUIRE(B > 0 && nh > 0 && T > 0 && d > 0 && d <= 128, "%s: bad sizes", who);
+  if (bias) {
+    PENEO_REQUIRE(bias_ld == peneo_attn_padded_len(T), "%s: bias row stride must be peneo_attn_padded_len(T) = %d", who,
+                  peneo_attn_padded_len(T));
+    PENEO_REQUIRE((reinterpret_cast<uintptr_t>(bias) & 15) == 0, "%s: bias must be 16-byte aligned", who);
+  }
+  return PENEO_OK;
+}
+
+extern "C" int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const void* vt, int B, int nh, int T,
+                              int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias, void* out,
+                              int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+  int rc = attn_common_check("peneo_attn_fwd", dtype, B, nh, T, d, bias, bias_ld);
+  if (rc) return rc;
+  PENEO_REQUIRE(q && k && vt && out, "peneo_attn_fwd: null pointer");
+  PENEO_REQUIRE(ld_qk >= (int64_t)nh * d && ld_out >= (int64_t)nh * d, "peneo_attn_fwd: leading dims too small");
   PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_attn_fwd: drop_p out of range");
   AttnParams p = {};
-  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.B = B; p.nh = nh; p.T = T; p.d = d; p.scale = scale; p.bias = bias;
-  p.mask = key_mask; p.out = out; p.ld_out = ld_out; p.lse = lse; p.drop_p = drop_p; p.seed = drop_seed;
+  p.q = q; p.k = k; p.ld = ld_qk; p.vt = vt; p.B = B; p.nh = nh; p.T = T; p.d = d; p.Tp = peneo_attn_padded_len(T);
+  p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias; p.out = out; p.ld_out = ld_out; p.lse = lse;
+  p.drop_p = drop_p; p.seed = drop_seed;
   return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, false, (hipStream_t)stream) : dispatch<float>(p, false, (hipStream_t)stream);
 }
 
-extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv, const void* out,
-                              const void* d_out, int64_t ld_out, const float* lse, int B, int nh, int T, int d, float scale,
-                              const void* bias, const int32_t* key_mask, void* dq, void* dk, void* dv, int64_t ld_dqkv,
-                              float* g_bias, float* delta, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
-  PENEO_REQUIRE(dtype == PENEO_F32 || dtype == PENEO_BF16, "peneo_attn_bwd: bad dtype");
-  PENEO_REQUIRE(q && k && v && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
-  PENEO_REQUIRE(B > 0 && nh > 0 && T > 0 && d > 0, "peneo_attn_bwd: bad sizes");
+extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv, const void* kt,
+                              const void* qt, const void* dot, const void* out, const void* d_out, int64_t ld_out,
+                              const float* lse, int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
+                              const float* key_bias, void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
+                              float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+  int rc = attn_common_check("peneo_attn_bwd", dtype, B, nh, T, d, bias, bias_ld);
+  if (rc) return rc;
+  PENEO_REQUIRE(q && k && v && kt && qt && dot && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
   PENEO_REQUIRE(ld_qkv >= (int64_t)nh * d && ld_out >= (int64_t)nh * d && ld_dqkv >= (int64_t)nh * d, "peneo_attn_bwd: leading dims too small");
+  PENEO_REQUIRE(!g_bias || bias, "peneo_attn_bwd: g_bias needs bias (it shares its row stride)");
   AttnParams p = {};
-  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.B = B; p.nh = nh; p.T = T; p.d = d; p.scale = scale; p.bias = bias;
-  p.mask = key_mask; p.out = const_cast<void*>(out); p.ld_out = ld_out; p.lse = const_cast<float*>(lse);
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.kt = kt; p.qt = qt; p.dot = dot; p.B = B; p.nh = nh; p.T = T; p.d = d;
+  p.Tp = peneo_attn_padded_len(T); p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias;
+  p.out = const_cast<void*>(out); p.ld_out = ld_out; p.lse = const_cast<float*>(lse);
   p.drop_p = drop_p; p.seed = drop_seed; p.d_out = d_out; p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_dqkv;
   p.g_bias = g_bias; p.delta = delta;
   return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, true, (hipStream_t)stream) : dispatch<float>(p, true, (hipStream_t)stream);

@@ -44,10 +44,17 @@ __device__ __forceinline__ uint4 guarded_vec_load(const T* base, int64_t ld, int
 }
 
 // k-major operand: matrix [rows, K]; tile rows r0.., k from k0..; thread t owns vectors t + 256*i
+// `fast`: the whole tile is in bounds and every vector is 16-byte aligned (block-uniform) -> plain loads.
 template <typename T>
 __device__ __forceinline__ void load_kmajor(Stage<T>& s, const T* base, int64_t ld, int r0, int k0, int rmax, int kmax,
-                                            int tid) {
+                                            int tid, bool fast) {
   constexpr int VEC = Elem<T>::kVec;
+  if (fast) {
+    const T* p0 = base + (int64_t)(r0 + (tid >> 3)) * ld + k0 + (tid & 7) * VEC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.v[i] = *reinterpret_cast<const uint4*>(p0 + (int64_t)(32 * i) * ld);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int v = tid + 256 * i;
@@ -69,10 +76,16 @@ __device__ __forceinline__ void store_kmajor(const Stage<T>& s, char* tile, int 
 // 16-byte vector of tile-rows and writes them k-contiguous.
 template <typename T>
 __device__ __forceinline__ void load_mnmajor(Stage<T>& s, const T* base, int64_t ld, int r0, int k0, int rmax, int kmax,
-                                             int tid) {
+                                             int tid, bool fast) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int MG = GB / VEC;  // vectors along the tile-row dim: 16 (bf16) / 32 (fp32)
   int mg = tid % MG, kg = tid / MG;
+  if (fast) {
+    const T* p0 = base + (int64_t)(k0 + kg * 4) * ld + r0 + mg * VEC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.v[i] = *reinterpret_cast<const uint4*>(p0 + (int64_t)i * ld);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) s.v[i] = guarded_vec_load<T>(base, ld, k0 + kg * 4 + i, r0 + mg * VEC, kmax, rmax);
 }
@@ -150,6 +163,67 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   store_any(p.C, p.c_dtype, ci, v);
 }
 
+// 8 consecutive columns of one row; requires n + 8 <= N and 16-byte aligned rows of every operand involved
+__device__ __forceinline__ void load8_any(const void* p, int dtype, int64_t idx, float* f) {
+  if (dtype == PENEO_F32) {
+    const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p) + idx);
+    unpack16<float>(q[0], f); unpack16<float>(q[1], f + 4);
+  } else {
+    unpack16<bf16_t>(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p) + idx), f);
+  }
+}
+__device__ __forceinline__ void store8_any(void* p, int dtype, int64_t idx, const float* f) {
+  if (dtype == PENEO_F32) {
+    uint4* q = reinterpret_cast<uint4*>(reinterpret_cast<float*>(p) + idx);
+    q[0] = pack16<float>(f); q[1] = pack16<float>(f + 4);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p) + idx) = pack16<bf16_t>(f);
+  }
+}
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int n, float* v) {
+  const peneo_gemm_epilogue& e = p.ep;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  if (e.bias) {
+    float b[8];
+    load8_any(e.bias, PENEO_F32, n, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if (e.preact) store8_any(e.preact, p.c_dtype, (int64_t)m * e.ld_preact + n, v);
+  if (e.act != PENEO_ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_f(e.act, v[i]);
+  }
+  if (e.grad_src) {
+    float g[8];
+    load8_any(e.grad_src, p.c_dtype, (int64_t)m * e.ld_grad + n, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= act_grad_f(e.grad_act, g[i]);
+  }
+  if (e.drop_p > 0.f) {
+    const uint32_t thresh = (uint32_t)fminf(e.drop_p * 4294967296.0f, 4294967040.0f);
+    const float ks = 1.0f / (1.0f - e.drop_p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      v[i] = dropout_keep(e.drop_seed, (uint64_t)m * (uint64_t)p.N + n + i, thresh) ? v[i] * ks : 0.f;
+  }
+  if (e.residual) {
+    float r[8];
+    load8_any(e.residual, p.c_dtype, (int64_t)m * e.ld_res + n, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  const int64_t ci = (int64_t)m * p.ldc + n;
+  if (e.accumulate) {
+    float c[8];
+    load8_any(p.C, PENEO_F32, ci, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += c[i];
+  }
+  store8_any(p.C, p.c_dtype, ci, v);
+}
+
 template <typename T, bool AK, bool BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -179,11 +253,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // block-uniform fast-path predicates: tile rows in bounds, vectors 16-byte aligned
+  const bool alignA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((p.lda * (int64_t)sizeof(T)) % 16 == 0);
+  const bool alignB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((p.ldb * (int64_t)sizeof(T)) % 16 == 0);
+  const bool rowsA = m0 + GB <= p.M, rowsB = n0 + GB <= p.N;
   Stage<T> ra, rb;
   auto gload = [&](int kt) {
-    int k0 = kt * KT;
-    if (AK) load_kmajor<T>(ra, A, p.lda, m0, k0, p.M, p.K, tid); else load_mnmajor<T>(ra, A, p.lda, m0, k0, p.M, p.K, tid);
-    if (BK) load_kmajor<T>(rb, B, p.ldb, n0, k0, p.N, p.K, tid); else load_mnmajor<T>(rb, B, p.ldb, n0, k0, p.N, p.K, tid);
+    const int k0 = kt * KT;
+    const bool kfull = k0 + KT <= p.K;
+    const bool fa = alignA && rowsA && kfull, fb = alignB && rowsB && kfull;
+    if (AK) load_kmajor<T>(ra, A, p.lda, m0, k0, p.M, p.K, tid, fa); else load_mnmajor<T>(ra, A, p.lda, m0, k0, p.M, p.K, tid, fa);
+    if (BK) load_kmajor<T>(rb, B, p.ldb, n0, k0, p.N, p.K, tid, fb); else load_mnmajor<T>(rb, B, p.ldb, n0, k0, p.N, p.K, tid, fb);
   };
   auto lstore = [&](int buf) {
     if (AK) store_kmajor<T>(ra, sA + buf * TILE_BYTES, tid); else store_mnmajor<T>(ra, sA + buf * TILE_BYTES, tid);
@@ -230,12 +310,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         sC[(wm * 64 + i * 32 + acc_row(r, lane)) * GB + wn * 64 + j * 32 + acc_col(lane)] = acc[i][j][r];
   __syncthreads();
   const int mrem = min(GB, p.M - m0), nrem = min(GB, p.N - n0);
-  for (int idx = tid; idx < GB * GB; idx += 256) {
-    const int r = idx >> 7, c = idx & (GB - 1);
-    if (r < mrem && c < nrem) {
-      const float v = sC[idx];
-      if (p.split_k > 1) p.ws[((int64_t)blockIdx.z * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
-      else epilogue_store(p, m0 + r, n0 + c, v);
+  // vector path: 8 columns per thread per step (16 threads per row), when every row segment is 16-byte aligned
+  const peneo_gemm_epilogue& e = p.ep;
+  const int csz = p.c_dtype == PENEO_F32 ? 4 : 2;
+  auto al = [&](const void* ptr, int64_t ld, int esz) {
+    return ptr == nullptr || (((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && ((ld * esz) % 16 == 0));
+  };
+  const bool vec_ok = p.split_k <= 1 && nrem == GB && al(p.C, p.ldc, csz) && al(e.preact, e.ld_preact, csz) &&
+                      al(e.grad_src, e.ld_grad, csz) && al(e.residual, e.ld_res, csz) && al(e.bias, 0, 4);
+  if (vec_ok) {
+    for (int idx = tid; idx < GB * (GB / 8); idx += 256) {
+      const int r = idx >> 4, c = (idx & 15) * 8;
+      if (r < mrem) {
+        float v[8];
+        const uint4* q = reinterpret_cast<const uint4*>(sC + r * GB + c);
+        unpack16<float>(q[0], v); unpack16<float>(q[1], v + 4);
+        epilogue_store8(p, m0 + r, n0 + c, v);
+      }
+    }
+  } else {
+    for (int idx = tid; idx < GB * GB; idx += 256) {
+      const int r = idx >> 7, c = idx & (GB - 1);
+      if (r < mrem && c < nrem) {
+        const float v = sC[idx];
+        if (p.split_k > 1) p.ws[((int64_t)blockIdx.z * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
+        else epilogue_store(p, m0 + r, n0 + c, v);
+      }
     }
   }
 }

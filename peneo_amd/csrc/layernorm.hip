@@ -127,16 +127,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, con
       }
     }
   }
-  // parameter gradients: one atomic per column per wave
+  // parameter gradients: reduce the 4 waves of the block through LDS, then one atomic per column per block
+  __shared__ float red[2][3][LN_MAXNV * 64 * 8];   // [gamma|beta][waves 1..3][column slot]
+  const int wave = threadIdx.x >> 6;
+  if (wave > 0) {
 #pragma unroll
-  for (int k = 0; k < LN_MAXNV; ++k) {
-    int vi = lane + 64 * k;
-    if (vi < nvec) {
+    for (int k = 0; k < LN_MAXNV; ++k)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        int c = vi * VEC + e;
-        if (dgamma) atomicAdd(dgamma + c, ag[k][e]);
-        if (dbeta) atomicAdd(dbeta + c, ab[k][e]);
+        red[0][wave - 1][(k * VEC + e) * 64 + lane] = ag[k][e];
+        red[1][wave - 1][(k * VEC + e) * 64 + lane] = ab[k][e];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < LN_MAXNV; ++k) {
+      int vi = lane + 64 * k;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          int c = vi * VEC + e, sl = (k * VEC + e) * 64 + lane;
+          float a = ag[k][e] + red[0][0][sl] + red[0][1][sl] + red[0][2][sl];
+          float b = ab[k][e] + red[1][0][sl] + red[1][1][sl] + red[1][2][sl];
+          if (dgamma) atomicAdd(dgamma + c, a);
+          if (dbeta) atomicAdd(dbeta + c, b);
+        }
       }
     }
   }
@@ -188,7 +204,7 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
   if (rc) return rc;
   PENEO_REQUIRE(dy && x && dx && gamma && mean && rstd, "peneo_layernorm_bwd: null pointer");
   LnMap dym{dy_rpb, dy_bstride}, xm{x_rpb, x_bstride}, dxm{dx_rpb, dx_bstride};
-  dim3 grid(ln_grid(rows, 4));  // ~512 blocks: each wave reduces several rows before its atomics
+  dim3 grid(ln_grid(rows, 8));  // <= 256 blocks: each wave reduces several rows; one atomic per column per block
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dym,
                        (const bf16_t*)x, xm, (bf16_t*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed);

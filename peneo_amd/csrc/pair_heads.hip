@@ -78,7 +78,7 @@ struct PairFwdParams {
   float* logits[PENEO_MAX_HEADS];
   const int64_t* tags[PENEO_MAX_HEADS];
   const float* cw[PENEO_MAX_HEADS];
-  float* loss_num; float* loss_den; float* dl_sum;
+  float* partials;   // [B * gridDim.x][32]: num[8] | den[8] | dl_sum[16] per workgroup
   float* dlogits[PENEO_MAX_HEADS];
 };
 
@@ -253,21 +253,24 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_ke
       }
     }
   }
-  if (p.loss_num) {
+  if (p.partials) {
+    // one row of partial sums per workgroup (plain stores; peneo_loss_finish reduces them): contended atomics
+    // on a handful of addresses cost more than the whole MFMA phase
+    float* sRed = reinterpret_cast<float*>(smem);  // [4 waves][32] (the W1 buffers are dead)
+    __syncthreads();
 #pragma unroll
     for (int h = 0; h < PENEO_MAX_HEADS; ++h) {
-      if (h < p.num_heads && p.tags[h]) {
-        float a = wave_sum(num[h]), d2 = wave_sum(den[h]);
-        if (lane == 0) { atomicAdd(p.loss_num + h, a); atomicAdd(p.loss_den + h, d2); }
-      }
+      float a = wave_sum(num[h]), d2 = wave_sum(den[h]);
+      if (lane == 0) { sRed[wave * 32 + h] = a; sRed[wave * 32 + 8 + h] = d2; }
     }
-    if (p.dl_sum) {
 #pragma unroll
-      for (int c = 0; c < NCP; ++c) {
-        float a = wave_sum(dls[c]);
-        if (lane == 0 && c < p.total_classes) atomicAdd(p.dl_sum + c, a);
-      }
+    for (int c = 0; c < NCP; ++c) {
+      float a = wave_sum(dls[c]);
+      if (lane == 0) sRed[wave * 32 + 16 + c] = a;
     }
+    __syncthreads();
+    if (tid < 32)
+      p.partials[((int64_t)b * gridDim.x + blockIdx.x) * 32 + tid] = sRed[tid] + sRed[32 + tid] + sRed[64 + tid] + sRed[96 + tid];
   }
 }
 
@@ -293,90 +296,168 @@ __global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pb
   }
 }
 
-// d_a[i, k] += sum_{j >= i} dx[p(i,j)] * SiLU'(a_i + b_j): one block per row i, threads along k
+// d_a[i, k] += sum_{j >= i} dx[p(i,j), k] * SiLU'(a_i[k] + b_j[k]).  Rows of the triangle are contiguous runs of
+// dx rows; a 64-thread block owns (row i, one of JSPLIT slices of j), each thread 8 (bf16) / 4 (fp32) columns with
+// 16-byte loads, 4 rows in flight; the JSPLIT partial sums meet in fp32 atomics (JSPLIT * D per row: negligible).
+constexpr int JSPLIT = 4;
 template <typename T>
-__global__ void pair_x_bwd_a_kernel(const T* abd, int N, int D, int i0, int64_t pbase, const T* dx, float* d_ab) {
+__global__ __launch_bounds__(256) void pair_x_bwd_a_kernel(const T* abd, int N, int D, int i0, int64_t pbase, const T* dx,
+                                                          float* d_ab) {
+  constexpr int VEC = Elem<T>::kVec;
   const int i = i0 + blockIdx.x;
+  const int c = threadIdx.x * VEC;
+  if (c >= D) return;
+  const int len = N - i;
+  const int per = (len + JSPLIT - 1) / JSPLIT;
+  const int j0 = i + blockIdx.y * per, j1 = min(N, j0 + per);
+  if (j0 >= j1) return;
   const int64_t prow = pair_row_start(i, N) - pbase;
-  for (int k = threadIdx.x; k < D; k += blockDim.x) {
-    const float a = Elem<T>::load(abd + (int64_t)i * 2 * D + k);
-    float s = 0.f;
-    for (int j = i; j < N; ++j) {
-      const float u = a + Elem<T>::load(abd + (int64_t)j * 2 * D + D + k);
-      s += Elem<T>::load(dx + (prow + (j - i)) * D + k) * silu_grad_f(u);
+  float a[VEC], s[VEC];
+  unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)i * 2 * D + c), a);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  for (int j = j0; j < j1; j += 4) {
+    uint4 dv[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jj = min(j + u, j1 - 1);
+      dv[u] = *reinterpret_cast<const uint4*>(dx + (prow + (jj - i)) * D + c);
+      bv[u] = *reinterpret_cast<const uint4*>(abd + (int64_t)jj * 2 * D + D + c);
     }
-    d_ab[(int64_t)i * 2 * D + k] += s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j + u < j1) {
+        float d[VEC], bj[VEC];
+        unpack16<T>(dv[u], d);
+        unpack16<T>(bv[u], bj);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += d[e] * silu_grad_f(a[e] + bj[e]);
+      }
+    }
   }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) atomicAdd(d_ab + (int64_t)i * 2 * D + c + e, s[e]);
 }
-// d_b[j, k] += sum_{i0 <= i < i1, i <= j} dx[p(i,j)] * SiLU'(a_i + b_j): one block per column j
+// d_b[j, k] += sum_{i0 <= i < i1, i <= j} dx[p(i,j), k] * SiLU'(a_i[k] + b_j[k]): block = (column j, slice of i)
 template <typename T>
-__global__ void pair_x_bwd_b_kernel(const T* abd, int N, int D, int i0, int i1, int64_t pbase, const T* dx, float* d_ab) {
+__global__ __launch_bounds__(256) void pair_x_bwd_b_kernel(const T* abd, int N, int D, int i0, int i1, int64_t pbase, const T* dx,
+                                                          float* d_ab) {
+  constexpr int VEC = Elem<T>::kVec;
   const int j = i0 + blockIdx.x;  // columns below i0 have no pair in this chunk
+  const int c = threadIdx.x * VEC;
+  if (c >= D) return;
   const int iend = min(i1, j + 1);
-  for (int k = threadIdx.x; k < D; k += blockDim.x) {
-    const float bj = Elem<T>::load(abd + (int64_t)j * 2 * D + D + k);
-    float s = 0.f;
-    for (int i = i0; i < iend; ++i) {
-      const float u = Elem<T>::load(abd + (int64_t)i * 2 * D + k) + bj;
-      const int64_t pr = pair_row_start(i, N) + (j - i) - pbase;
-      s += Elem<T>::load(dx + pr * D + k) * silu_grad_f(u);
+  const int per = (iend - i0 + JSPLIT - 1) / JSPLIT;
+  const int ia = i0 + blockIdx.y * per, ib = min(iend, ia + per);
+  if (ia >= ib) return;
+  float bj[VEC], s[VEC];
+  unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)j * 2 * D + D + c), bj);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  for (int i = ia; i < ib; i += 4) {
+    uint4 dv[4], av[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ii = min(i + u, ib - 1);
+      dv[u] = *reinterpret_cast<const uint4*>(dx + (pair_row_start(ii, N) + (j - ii) - pbase) * D + c);
+      av[u] = *reinterpret_cast<const uint4*>(abd + (int64_t)ii * 2 * D + c);
     }
-    d_ab[(int64_t)j * 2 * D + D + k] += s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i + u < ib) {
+        float d[VEC], ai[VEC];
+        unpack16<T>(dv[u], d);
+        unpack16<T>(av[u], ai);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += d[e] * silu_grad_f(ai[e] + bj[e]);
+      }
+    }
   }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) atomicAdd(d_ab + (int64_t)j * 2 * D + D + c + e, s[e]);
 }
 
 struct DzParams {
   peneo_pair_dz_args a;
 };
-constexpr int DZ_ROWS = 256;  // pairs per block
-// grid.x = nh*D/blockDim column blocks (each inside one head), grid.y = row blocks; thread = one hidden column
+constexpr int DZ_SLOTS = 256;   // rows of the partial-sum workspace == max workgroups per launch
+// z -> dz in place; every thread owns one 16-byte column vector of the [npairs, nh*D] matrix for a strided set of rows and
+// keeps its dW2 / db1 partial sums in registers; one plain read-modify-write of the block's workspace row at the end
+// (workspace [DZ_SLOTS][4 * nh*D]: rows c*ncol.. hold sum_p dlogits[p,c]*y[p,:] for c = 0..2, row 3*ncol.. holds sum_p dz).
 template <typename T>
-__global__ __launch_bounds__(128) void pair_dz_kernel(T* z, int64_t npairs, DzParams pp) {
+__global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzParams pp, float* ws) {
+  constexpr int VEC = Elem<T>::kVec;
   const peneo_pair_dz_args& a = pp.a;
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;   // hidden column in [0, nh*D)
-  const int h = col / a.D, k = col - h * a.D;
-  const int C = a.classes[h];
   const int ncol = a.num_heads * a.D;
-  float w2[4], dw2[4];
+  const int nvec = ncol / VEC;
+  float* slot = ws + (int64_t)blockIdx.x * 4 * ncol;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    const int col = v * VEC;
+    const int h = col / a.D, k = col - h * a.D;
+    const int C = a.classes[h];
+    float w2[3][VEC], dw2[3][VEC], db1[VEC];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) { w2[c] = (c < C) ? a.w2[h][(int64_t)c * a.D + k] : 0.f; dw2[c] = 0.f; }
-  const float sc = a.scale[h];
-  float db1 = 0.f;
-  const int64_t r0 = (int64_t)blockIdx.y * DZ_ROWS, r1 = min(npairs, r0 + DZ_ROWS);
-  const float* dl = a.dlogits[h];
-  for (int64_t r = r0; r < r1; ++r) {
-    const float zv = Elem<T>::load(z + r * ncol + col);
-    const float sg = sigmoid_f(zv);
-    const float y = zv * sg;
-    float dy = 0.f;
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c < C) {
-        const float g = dl[r * C + c] * sc;
-        dy += g * w2[c];
-        dw2[c] += g * y;
+      for (int e = 0; e < VEC; ++e) { w2[c][e] = (c < C) ? a.w2[h][(int64_t)c * a.D + k + e] : 0.f; dw2[c][e] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) db1[e] = 0.f;
+    const float sc = a.scale[h];
+    const float* dl = a.dlogits[h];
+    for (int64_t r = blockIdx.x; r < npairs; r += gridDim.x) {
+      float zv[VEC], o[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(z + r * ncol + col), zv);
+      float g[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = (c < C) ? dl[r * C + c] * sc : 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float sg = sigmoid_f(zv[e]);
+        const float y = zv[e] * sg;
+        const float dy = g[0] * w2[0][e] + g[1] * w2[1][e] + g[2] * w2[2][e];
+        const float dz = dy * sg * (1.f + zv[e] * (1.f - sg));
+        dw2[0][e] += g[0] * y; dw2[1][e] += g[1] * y; dw2[2][e] += g[2] * y;
+        db1[e] += dz;
+        o[e] = dz;
       }
+      *reinterpret_cast<uint4*>(z + r * ncol + col) = pack16<T>(o);
     }
-    const float dz = dy * sg * (1.f + zv * (1.f - sg));
-    db1 += dz;
-    Elem<T>::store(z + r * ncol + col, dz);
-  }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) if (c < C) atomicAdd(a.dw2[h] + (int64_t)c * a.D + k, dw2[c]);
-  atomicAdd(a.db1 + col, db1);
+    for (int e = 0; e < VEC; ++e) {
+      slot[0 * ncol + col + e] += dw2[0][e];
+      slot[1 * ncol + col + e] += dw2[1][e];
+      slot[2 * ncol + col + e] += dw2[2][e];
+      slot[3 * ncol + col + e] += db1[e];
+    }
+  }
 }
 
-__global__ void loss_finish_kernel(const float* num, const float* den, const float* ratio, int nh, float* out, float* scale) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+// partials [n][32] (num[8] | den[8] | dl_sum[16]) -> per-head losses, total, backward scales, dl_sum
+__global__ __launch_bounds__(1024) void loss_finish_kernel(const float* partials, int64_t n, const float* ratio, int nh,
+                                                           int total_classes, float* out, float* scale, float* dl_sum) {
+  __shared__ float red[32][33];
+  const int col = threadIdx.x & 31, row = threadIdx.x >> 5;   // 32 x 32
+  float s = 0.f;
+  for (int64_t i = row; i < n; i += 32) s += partials[i * 32 + col];
+  red[row][col] = s;
+  __syncthreads();
+  if (row == 0) {
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += red[r][col];
+    red[0][col] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int h = 0; h < nh; ++h) {
-      float l = num[h] / den[h];
+      const float l = red[0][h] / red[0][8 + h];
       out[h] = l;
       tot += ratio[h] * l;
-      if (scale) scale[h] = ratio[h] / den[h];
+      if (scale) scale[h] = ratio[h] / red[0][8 + h];
     }
     out[nh] = tot;
   }
+  if (dl_sum && threadIdx.x < total_classes) dl_sum[threadIdx.x] = red[0][16 + threadIdx.x];
 }
 
 __global__ void weighted_ce_kernel(const float* logits, const int64_t* tags, const float* cw, int64_t rows, int C, float* num,
@@ -538,10 +619,10 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
     if (loss) { p.tags[h] = loss->tags[h]; p.cw[h] = loss->class_weight[h]; p.dlogits[h] = loss->dlogits[h]; }
   }
   if (loss) {
-    p.loss_num = loss->loss_num; p.loss_den = loss->loss_den; p.dl_sum = loss->dl_sum;
+    p.partials = loss->partials;
     bool any = false;
     for (int h = 0; h < desc->num_heads; ++h) any = any || loss->tags[h];
-    if (any) PENEO_REQUIRE(p.loss_num && p.loss_den, "peneo_pair_heads_fwd: loss accumulators missing");
+    if (any) PENEO_REQUIRE(p.partials, "peneo_pair_heads_fwd: loss->partials workspace missing");
   }
   return dtype == PENEO_BF16 ? dispatch_pair_fwd<bf16_t>(p, (hipStream_t)stream) : dispatch_pair_fwd<float>(p, (hipStream_t)stream);
 }
@@ -569,39 +650,54 @@ extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int
   int rc = chunk_check("peneo_pair_x_bwd", dtype, N, D, i0, i1);
   if (rc) return rc;
   PENEO_REQUIRE(ab_doc && dx && d_ab_doc, "peneo_pair_x_bwd: null pointer");
+  const int vec = dtype == PENEO_BF16 ? 8 : 4;
+  PENEO_REQUIRE(D % vec == 0 && D / vec <= 256, "peneo_pair_x_bwd: D must be a multiple of %d and <= %d", vec, 256 * vec);
+  const int threads = (D / vec + 63) / 64 * 64;
+  PENEO_REQUIRE((reinterpret_cast<uintptr_t>(ab_doc) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0,
+                "peneo_pair_x_bwd: pointers must be 16-byte aligned");
   const int64_t pbase = pair_row_start(i0, N);
   hipStream_t st = (hipStream_t)stream;
-  const int threads = D >= 256 ? 256 : (D >= 128 ? 128 : 64);
   if (dtype == PENEO_BF16) {
-    hipLaunchKernelGGL(pair_x_bwd_a_kernel<bf16_t>, dim3(i1 - i0), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, pbase, (const bf16_t*)dx, d_ab_doc);
-    hipLaunchKernelGGL(pair_x_bwd_b_kernel<bf16_t>, dim3(N - i0), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, i1, pbase, (const bf16_t*)dx, d_ab_doc);
+    hipLaunchKernelGGL(pair_x_bwd_a_kernel<bf16_t>, dim3(i1 - i0, JSPLIT), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, pbase, (const bf16_t*)dx, d_ab_doc);
+    hipLaunchKernelGGL(pair_x_bwd_b_kernel<bf16_t>, dim3(N - i0, JSPLIT), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, i1, pbase, (const bf16_t*)dx, d_ab_doc);
   } else {
-    hipLaunchKernelGGL(pair_x_bwd_a_kernel<float>, dim3(i1 - i0), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, pbase, (const float*)dx, d_ab_doc);
-    hipLaunchKernelGGL(pair_x_bwd_b_kernel<float>, dim3(N - i0), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, i1, pbase, (const float*)dx, d_ab_doc);
+    hipLaunchKernelGGL(pair_x_bwd_a_kernel<float>, dim3(i1 - i0, JSPLIT), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, pbase, (const float*)dx, d_ab_doc);
+    hipLaunchKernelGGL(pair_x_bwd_b_kernel<float>, dim3(N - i0, JSPLIT), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, i1, pbase, (const float*)dx, d_ab_doc);
   }
   return check_launch("peneo_pair_x_bwd");
 }
 
-extern "C" int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, peneo_stream_t stream) {
-  PENEO_REQUIRE(ok_dt(dtype) && z_inout && args && npairs > 0, "peneo_pair_dz: bad arguments");
-  PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D > 0 && args->D % 32 == 0,
-                "peneo_pair_dz: D must be a multiple of 32 (got %d)", args->D);
-  const int bs = args->D % 128 == 0 ? 128 : (args->D % 64 == 0 ? 64 : 32);
-  PENEO_REQUIRE(args->db1 && args->scale, "peneo_pair_dz: null db1/scale");
+extern "C" size_t peneo_pair_dz_workspace_bytes(int num_heads, int D) { return (size_t)DZ_SLOTS * 4 * num_heads * D * sizeof(float); }
+
+extern "C" int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, float* workspace,
+                             peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && z_inout && args && workspace && npairs > 0, "peneo_pair_dz: bad arguments");
+  const int vec = dtype == PENEO_BF16 ? 8 : 4;
+  PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D > 0 && args->D % vec == 0,
+                "peneo_pair_dz: D must be a multiple of %d (got %d)", vec, args->D);
+  PENEO_REQUIRE(args->scale, "peneo_pair_dz: null scale");
+  PENEO_REQUIRE((reinterpret_cast<uintptr_t>(z_inout) & 15) == 0, "peneo_pair_dz: z must be 16-byte aligned");
   for (int h = 0; h < args->num_heads; ++h)
-    PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->dw2[h] && args->classes[h] >= 1 && args->classes[h] <= 4,
-                  "peneo_pair_dz: head %d arguments invalid", h);
+    PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3,
+                  "peneo_pair_dz: head %d arguments invalid (classes must be 1..3)", h);
   DzParams pp; pp.a = *args;
-  dim3 grid(args->num_heads * args->D / bs, (unsigned)((npairs + DZ_ROWS - 1) / DZ_ROWS));
-  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_dz_kernel<bf16_t>, grid, dim3(bs), 0, (hipStream_t)stream, (bf16_t*)z_inout, npairs, pp);
-  else hipLaunchKernelGGL(pair_dz_kernel<float>, grid, dim3(bs), 0, (hipStream_t)stream, (float*)z_inout, npairs, pp);
+  const int blocks = (int)(npairs < DZ_SLOTS ? npairs : DZ_SLOTS);
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_dz_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)z_inout, npairs, pp, workspace);
+  else hipLaunchKernelGGL(pair_dz_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)z_inout, npairs, pp, workspace);
   return check_launch("peneo_pair_dz");
 }
 
-extern "C" int peneo_loss_finish(const float* num, const float* den, const float* ratio, int num_heads, float* out, float* scale,
-                                 peneo_stream_t stream) {
-  PENEO_REQUIRE(num && den && ratio && out && num_heads > 0 && num_heads <= PENEO_MAX_HEADS, "peneo_loss_finish: bad arguments");
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, num, den, ratio, num_heads, out, scale);
+extern "C" int64_t peneo_pair_loss_partials(int B, int N) {
+  const int64_t P = (int64_t)N * (N + 1) / 2;
+  return (int64_t)B * ((P + PH_PAIRS - 1) / PH_PAIRS);
+}
+
+extern "C" int peneo_loss_finish(const float* partials, int64_t n_partials, const float* ratio, int num_heads, int total_classes,
+                                 float* out, float* scale, float* dl_sum, peneo_stream_t stream) {
+  PENEO_REQUIRE(partials && n_partials > 0 && ratio && out && num_heads > 0 && num_heads <= PENEO_MAX_HEADS &&
+                total_classes >= 0 && total_classes <= NCP, "peneo_loss_finish: bad arguments");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, n_partials, ratio, num_heads,
+                     total_classes, out, scale, dl_sum);
   return check_launch("peneo_loss_finish");
 }
 

@@ -25,10 +25,14 @@ __global__ __launch_bounds__(256) void relpos_buckets_kernel(const int32_t* pos,
   }
 }
 
+// bias rows are padded to Tp columns; padding and keys with key_mask == 0 hold MASKED_BIAS so the attention
+// kernels need no mask logic of their own (the reference adds finfo.min: modeling_layoutlmv3.py:1126-1128)
+constexpr float MASKED_BIAS = -1.0e30f;
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
                                                               const float* w1, int bins1, const float* wx, const float* wy,
-                                                              int bins2, float scale, int nh, int Tn, T* bias) {
+                                                              int bins2, float scale, int nh, int Tn, int Tp,
+                                                              const int32_t* key_mask, T* bias) {
   extern __shared__ float tab[];  // [nh][bins1] [nh][bins2] [nh][bins2]
   float* t1 = tab;
   float* tx = t1 + nh * bins1;
@@ -38,14 +42,15 @@ __global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const uint8_t* bk1
   __syncthreads();
   const int64_t row = blockIdx.x;  // b * T + i
   const int64_t b = row / Tn, i = row % Tn;
-  for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
+  for (int j = threadIdx.x; j < Tp; j += blockDim.x) {
+    const bool valid = j < Tn && (!key_mask || key_mask[b * Tn + j] != 0);
     const int64_t o = row * Tn + j;
-    const int a = bk1 ? bk1[o] : 0, bx = bkx ? bkx[o] : 0, by = bky ? bky[o] : 0;
+    const int a = (valid && bk1) ? bk1[o] : 0, bx = (valid && bkx) ? bkx[o] : 0, by = (valid && bky) ? bky[o] : 0;
     for (int h = 0; h < nh; ++h) {
       float v = 0.f;
       if (bk1) v += t1[h * bins1 + a];
       if (bkx) v += tx[h * bins2 + bx] + ty[h * bins2 + by];
-      Elem<T>::store(bias + (((b * nh + h) * Tn + i) * Tn + j), v);
+      Elem<T>::store(bias + (((b * nh + h) * Tn + i) * (int64_t)Tp + j), valid ? v : MASKED_BIAS);
     }
   }
 }
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const uint8_t* bk1
 // one block per (b, h, 32-row slab): LDS histograms, then one global atomic per bin
 __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, const uint8_t* bk1, const uint8_t* bkx,
                                                               const uint8_t* bky, float* dw1, int bins1, float* dwx, float* dwy,
-                                                              int bins2, float scale, int nh, int Tn) {
+                                                              int bins2, float scale, int nh, int Tn, int64_t ldg) {
   extern __shared__ float hist[];  // [bins1] [bins2] [bins2]
   float* h1 = hist;
   float* hx = h1 + bins1;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, co
   const int64_t b = blockIdx.x / ((int64_t)slabs * nh);
   const int i0 = slab * 32, i1 = min(Tn, i0 + 32);
   for (int i = i0; i < i1; ++i) {
-    const float* grow = g + (((b * nh + h) * Tn + i) * (int64_t)Tn);
+    const float* grow = g + (((b * nh + h) * Tn + i) * ldg);
     const int64_t brow = (b * Tn + i) * (int64_t)Tn;
     for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
       const float v = grow[j];
@@ -98,7 +103,8 @@ extern "C" int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const
 
 extern "C" int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky, const float* w1,
                                      int bins1, const float* wx, const float* wy, int bins2, float scale, int B, int nh, int T,
-                                     void* bias, peneo_stream_t stream) {
+                                     int Tp, const int32_t* key_mask, void* bias, peneo_stream_t stream) {
+  PENEO_REQUIRE(Tp >= T, "peneo_relpos_bias_fwd: Tp < T");
   PENEO_REQUIRE((dtype == PENEO_F32 || dtype == PENEO_BF16) && bias && B > 0 && nh > 0 && T > 0, "peneo_relpos_bias_fwd: bad arguments");
   PENEO_REQUIRE((bk1 != nullptr) == (w1 != nullptr), "peneo_relpos_bias_fwd: bk1/w1 mismatch");
   PENEO_REQUIRE((bkx != nullptr) == (wx != nullptr) && (bky != nullptr) == (wy != nullptr) && (bkx != nullptr) == (bky != nullptr),
@@ -108,22 +114,23 @@ extern "C" int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_
   dim3 grid((unsigned)((int64_t)B * T));
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(relpos_bias_fwd_kernel<bf16_t>, grid, dim3(256), sh, (hipStream_t)stream, bk1, bkx, bky, w1, bins1, wx, wy,
-                       bins2, scale, nh, T, (bf16_t*)bias);
+                       bins2, scale, nh, T, Tp, key_mask, (bf16_t*)bias);
   else
     hipLaunchKernelGGL(relpos_bias_fwd_kernel<float>, grid, dim3(256), sh, (hipStream_t)stream, bk1, bkx, bky, w1, bins1, wx, wy,
-                       bins2, scale, nh, T, (float*)bias);
+                       bins2, scale, nh, T, Tp, key_mask, (float*)bias);
   return check_launch("peneo_relpos_bias_fwd");
 }
 
-extern "C" int peneo_relpos_bias_bwd(const float* g, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky, float* dw1,
-                                     int bins1, float* dwx, float* dwy, int bins2, float scale, int B, int nh, int T,
+extern "C" int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
+                                     float* dw1, int bins1, float* dwx, float* dwy, int bins2, float scale, int B, int nh, int T,
                                      peneo_stream_t stream) {
+  PENEO_REQUIRE(ldg >= T, "peneo_relpos_bias_bwd: ldg < T");
   PENEO_REQUIRE(g && B > 0 && nh > 0 && T > 0, "peneo_relpos_bias_bwd: bad arguments");
   PENEO_REQUIRE((bkx != nullptr) == (bky != nullptr), "peneo_relpos_bias_bwd: 2-D inputs mismatch");
   size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2);
   int slabs = (T + 31) / 32;
   dim3 grid((unsigned)((int64_t)B * nh * slabs));
   hipLaunchKernelGGL(relpos_bias_bwd_kernel, grid, dim3(256), sh, (hipStream_t)stream, g, bk1, bkx, bky, dw1, bins1, dwx, dwy,
-                     bins2, scale, nh, T);
+                     bins2, scale, nh, T, ldg);
   return check_launch("peneo_relpos_bias_bwd");
 }

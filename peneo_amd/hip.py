@@ -50,14 +50,13 @@ class PairHeadsDesc(C.Structure):
 
 
 class PairLoss(C.Structure):
-    _fields_ = [("tags", _vp * MAX_HEADS), ("class_weight", _vp * MAX_HEADS), ("loss_num", _vp), ("loss_den", _vp),
-                ("dlogits", _vp * MAX_HEADS), ("dl_sum", _vp)]
+    _fields_ = [("tags", _vp * MAX_HEADS), ("class_weight", _vp * MAX_HEADS), ("partials", _vp),
+                ("dlogits", _vp * MAX_HEADS)]
 
 
 class PairDzArgs(C.Structure):
     _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("dlogits", _vp * MAX_HEADS),
-                ("w2", _vp * MAX_HEADS), ("dw2", _vp * MAX_HEADS), ("db1", _vp),
-                ("scale", _vp)]
+                ("w2", _vp * MAX_HEADS), ("scale", _vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/peneo_hip.h appears here
@@ -82,11 +81,14 @@ SIGNATURES = {
     "peneo_visual_assemble_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "peneo_visual_assemble_bwd": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_relpos_buckets": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
-    "peneo_relpos_bias_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
-    "peneo_relpos_bias_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
-    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
-    "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
-                            _i64, _vp, _vp, _f, _u32, _vp]),
+    "peneo_relpos_bias_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "peneo_relpos_bias_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    "peneo_attn_padded_len": (_i, [_i]),
+    "peneo_attn_padded_dim": (_i, [_i]),
+    "peneo_head_transpose": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
+    "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp,
+                            _vp, _vp, _vp, _i64, _vp, _vp, _f, _u32, _vp]),
     "peneo_pair_heads_w1_packed_bytes": (_sz, [_i, _i, _i]),
     "peneo_pair_heads_w2_packed_bytes": (_sz, [_i, _i, _i]),
     "peneo_pair_heads_pack_w1": (_i, [_i, _vp, _i, _i, _vp, _vp]),
@@ -94,8 +96,10 @@ SIGNATURES = {
     "peneo_pair_heads_fwd": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp]),
     "peneo_pair_x_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "peneo_pair_x_bwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "peneo_pair_dz": (_i, [_i, _vp, _i64, C.POINTER(PairDzArgs), _vp]),
-    "peneo_loss_finish": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "peneo_pair_dz_workspace_bytes": (_sz, [_i, _i]),
+    "peneo_pair_dz": (_i, [_i, _vp, _i64, C.POINTER(PairDzArgs), _vp, _vp]),
+    "peneo_pair_loss_partials": (_i64, [_i, _i]),
+    "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
 }

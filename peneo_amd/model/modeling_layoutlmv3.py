@@ -106,6 +106,7 @@ class _FwdState:
         self.g_bias = None     # fp32 accumulator of dS over the layers (training only)
         self.buckets = (None, None, None)
         self.key_mask = None   # int32 [B, T]
+        self.key_bias = None   # fp32 [B, Tp] additive mask, only when there is no bias tensor
         self.seeds: Optional[DropoutSeeds] = None
         self.dtype = torch.float32
         self.dims = None       # (B, S, T)
@@ -133,7 +134,7 @@ class _EmbedStage(torch.autograd.Function):
                 raise ValueError(f"image gives {nv} visual tokens but pos_embed has {pos_embed.shape[1]}")
         T = S + nv
         st.dims = (B, S, T)
-        if int(bbox.min()) < 0 or int(bbox.max()) > 1023:
+        if getattr(model, "check_inputs", True) and (int(bbox.min()) < 0 or int(bbox.max()) > 1023):
             raise IndexError("The :obj:`bbox` coordinate values should be within 0-1000 range.")
 
         pid = ops.position_ids(input_ids, cfg.pad_token_id)
@@ -184,7 +185,12 @@ class _EmbedStage(torch.autograd.Function):
             wx = next(ri) if use2 else None
             wy = next(ri) if use2 else None
             st.bias = ops.relpos_bias_fwd(dt, st.buckets[0], st.buckets[1], st.buckets[2], w1, wx, wy,
-                                          1.0 / math.sqrt(d), B, nh, T)
+                                          1.0 / math.sqrt(d), B, nh, T, key_mask=km)   # padding mask folded in
+        else:
+            # no bias tensor: the padding mask travels as an additive per-key row
+            kb = torch.zeros((B, ops.attn_padded_len(T)), dtype=torch.float32, device=dev)
+            kb[:, :T].masked_fill_(km == 0, -1.0e30)
+            st.key_bias = kb
         ctx.model, ctx.st, ctx.saved = model, st, saved
         ctx.inputs = (input_ids, bbox)
         ctx.params = params
@@ -254,7 +260,7 @@ class _LayerStage(torch.autograd.Function):
 
         qkv = ops.gemm(x, Wqkv, bias=bqkv)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-        att, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_mask,
+        att, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias,
                                 drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
         h1 = ops.gemm(att, Wo, bias=bo, residual=x, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2))
         a, m1, r1 = ops.layernorm_fwd(h1, g1, b1, cfg.layer_norm_eps)
@@ -305,7 +311,7 @@ class _LayerStage(torch.autograd.Function):
             st.g_bias = torch.zeros(st.bias.shape, dtype=torch.float32, device=dev)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-        ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_mask, dqkv, st.g_bias,
+        ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv, st.g_bias,
                      drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
         dbqkv = ops.colsum(dqkv)
         dwqkv = ops.gemm(dqkv, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)

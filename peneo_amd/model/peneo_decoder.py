@@ -186,13 +186,13 @@ class _DecoderStage(torch.autograd.Function):
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         b2cat = wc.get(("dec.b2",), b2s, lambda: torch.cat([b.detach() for b in b2s]))
         cws = [dec.le_loss.weight] + [dec.link_loss.weight] * 4 if tags is not None else None
-        logits, num, den, dlog, dls = ops.pair_heads_fwd(ab, p1, b1cat, p2, b2cat, HEAD_CLASSES, want_logits=want_logits,
-                                                         tags=tags, class_weights=cws,
-                                                         want_dlogits=need_grad and tags is not None)
+        logits, partials, dlog = ops.pair_heads_fwd(ab, p1, b1cat, p2, b2cat, HEAD_CLASSES, want_logits=want_logits,
+                                                    tags=tags, class_weights=cws,
+                                                    want_dlogits=need_grad and tags is not None)
         outs = []
         if tags is not None:
             ratio = dec.loss_ratio_tensor(dev)
-            losses, scale = ops.loss_finish(num, den, ratio)
+            losses, scale, dls = ops.loss_finish(partials, ratio, sum(HEAD_CLASSES))
             outs = [losses[5]] + [losses[i] for i in range(5)]
             saved.update(scale=scale, dlog=dlog, dls=dls)
         else:
@@ -229,8 +229,7 @@ class _DecoderStage(torch.autograd.Function):
         W1cat = wc.cat_rows("dec.w1cat", w1s, dt)                      # [nh*D, D]
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         dW1cat = torch.zeros((nh * D, D), dtype=torch.float32, device=dev)
-        db1cat = torch.zeros(nh * D, dtype=torch.float32, device=dev)
-        dw2 = [torch.zeros(w.shape, dtype=torch.float32, device=dev) for w in w2s]
+        dz_ws = ops.pair_dz_workspace(nh, D, dev)
         d_ab = torch.zeros((B, N, 2 * D), dtype=torch.float32, device=dev)
         P = N * (N + 1) // 2
         chunks = _row_chunks(N, dec.bwd_chunk_pairs)
@@ -247,10 +246,11 @@ class _DecoderStage(torch.autograd.Function):
                 x, z, dx = xbuf[:npairs], zbuf[:npairs], dxbuf[:npairs]
                 ops.pair_x_fwd(ab[b], i0, i1, x)
                 ops.gemm(x, W1cat, bias=b1cat, out=z)
-                ops.pair_dz(z, npairs, D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, dw2, db1cat, scale)
+                ops.pair_dz(z, npairs, D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, dz_ws, scale)
                 ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
                 ops.gemm(z, W1cat, b_kmajor=False, out=dx)
                 ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b])
+        dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
         db2cat = sv["dls"]
         # back through the [a | b] projection and the shrink MLP
         d_ab2 = ops.cast(d_ab.view(B * N, 2 * D), dt) if dt != torch.float32 else d_ab.view(B * N, 2 * D)

@@ -16,6 +16,44 @@ from .hip import ACT_GELU, ACT_NONE, ACT_SILU, BF16, F32, check, dtype_code, lib
 _i64p = C.POINTER(C.c_int64)
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual launches on the current stream (bench.py's roofline leg).
+    ``with ops.kernel_timer("name"):`` brackets a launch with two events; ``durations_ms()`` after a
+    device synchronise gives the per-launch times."""
+
+    def __init__(self) -> None:
+        self.enabled = False
+        self.events = {}
+
+    def reset(self, enabled: bool) -> None:
+        self.enabled = enabled
+        self.events = {}
+
+    def durations_ms(self, name: str):
+        return [a.elapsed_time(b) for a, b in self.events.get(name, [])]
+
+
+TIMER = KernelTimer()
+
+
+class kernel_timer:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if TIMER.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMER.enabled:
+            self.b.record()
+            TIMER.events.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     if not t.is_contiguous():
         raise hip.PeneoHipError("tensor must be contiguous")
@@ -253,19 +291,30 @@ def relpos_buckets(pos: Optional[torch.Tensor], xs: Optional[torch.Tensor], ys: 
     return bk1, bkx, bky
 
 
-def relpos_bias_fwd(dtype: torch.dtype, bk1, bkx, bky, w1, wx, wy, scale: float, B: int, nh: int, T: int) -> torch.Tensor:
+def attn_padded_len(T: int) -> int:
+    return (T + 63) // 64 * 64
+
+
+def attn_padded_dim(d: int) -> int:
+    return (d + 31) // 32 * 32
+
+
+def relpos_bias_fwd(dtype: torch.dtype, bk1, bkx, bky, w1, wx, wy, scale: float, B: int, nh: int, T: int,
+                    key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> bias [B, nh, T, Tp] (Tp = T rounded up to 64); padding columns and masked keys hold -1e30."""
     dev = (bk1 if bk1 is not None else bkx).device
-    bias = torch.empty((B, nh, T, T), dtype=dtype, device=dev)
+    Tp = attn_padded_len(T)
+    bias = torch.empty((B, nh, T, Tp), dtype=dtype, device=dev)
     check(lib().peneo_relpos_bias_fwd(dtype_code(dtype), ptr(bk1), ptr(bkx), ptr(bky), ptr(w1),
                                       w1.shape[1] if w1 is not None else 0, ptr(wx), ptr(wy),
-                                      wx.shape[1] if wx is not None else 0, scale, B, nh, T, ptr(bias), stream()),
-          "peneo_relpos_bias_fwd")
+                                      wx.shape[1] if wx is not None else 0, scale, B, nh, T, Tp, ptr(key_mask), ptr(bias),
+                                      stream()), "peneo_relpos_bias_fwd")
     return bias
 
 
 def relpos_bias_bwd(g: torch.Tensor, bk1, bkx, bky, dw1, dwx, dwy, scale: float) -> None:
-    B, nh, T, _ = g.shape
-    check(lib().peneo_relpos_bias_bwd(ptr(_c(g)), ptr(bk1), ptr(bkx), ptr(bky), ptr(dw1),
+    B, nh, T, ldg = g.shape
+    check(lib().peneo_relpos_bias_bwd(ptr(_c(g)), ldg, ptr(bk1), ptr(bkx), ptr(bky), ptr(dw1),
                                       dw1.shape[1] if dw1 is not None else 0, ptr(dwx), ptr(dwy),
                                       dwx.shape[1] if dwx is not None else 0, scale, B, nh, T, stream()),
           "peneo_relpos_bias_bwd")
@@ -274,28 +323,45 @@ def relpos_bias_bwd(g: torch.Tensor, bk1, bkx, bky, dw1, dwx, dwy, scale: float)
 # ----------------------------------------------------------------------------------------------
 # attention
 # ----------------------------------------------------------------------------------------------
+def head_transpose(x: torch.Tensor, B: int, nh: int, T: int, d: int) -> torch.Tensor:
+    """x: 2-D view [B*T, nh*d] (row stride may be larger) -> [B, nh, DP, Tp] per-head transposed, zero padded."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty((B, nh, attn_padded_dim(d), attn_padded_len(T)), dtype=x.dtype, device=x.device)
+    check(lib().peneo_head_transpose(dtype_code(x.dtype), ptr(x), x.stride(0), B, nh, T, d, ptr(out), stream()),
+          "peneo_head_transpose")
+    return out
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int, T: int, d: int, scale: float,
-             bias: Optional[torch.Tensor], key_mask: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0):
-    """q/k/v: 2-D views [B*T, nh*d] with a common row stride (e.g. slices of a fused QKV buffer)."""
+             bias: Optional[torch.Tensor], key_bias: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
+             vt: Optional[torch.Tensor] = None):
+    """q/k/v: 2-D views [B*T, nh*d] with a common row stride (e.g. slices of a fused QKV buffer).
+    bias: [B, nh, T, Tp] from relpos_bias_fwd (masking folded in); key_bias: fp32 [B, Tp] additive (0 / -1e30)."""
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
+    if vt is None:
+        vt = head_transpose(v, B, nh, T, d)
     out = torch.empty((B * T, nh * d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
-    check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), B, nh, T, d, scale, ptr(bias),
-                               ptr(key_mask), ptr(out), out.stride(0), ptr(lse), drop_p, drop_seed & 0xFFFFFFFF, stream()),
-          "peneo_attn_fwd")
+    check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), q.stride(0), ptr(vt), B, nh, T, d, scale, ptr(bias),
+                               bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(out), out.stride(0), ptr(lse),
+                               drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_fwd")
     return out, lse
 
 
-def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_mask,
+def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_bias,
              dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations)."""
     H = nh * d
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     delta = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
     assert out.stride(0) == d_out.stride(0)
-    check(lib().peneo_attn_bwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(out), ptr(d_out),
-                               out.stride(0), ptr(lse), B, nh, T, d, scale, ptr(bias), ptr(key_mask), ptr(dq), ptr(dk),
-                               ptr(dv), dqkv.stride(0), ptr(g_bias), ptr(delta), drop_p, drop_seed & 0xFFFFFFFF, stream()),
+    kt = head_transpose(k, B, nh, T, d)
+    qt = head_transpose(q, B, nh, T, d)
+    dot = head_transpose(d_out, B, nh, T, d)
+    check(lib().peneo_attn_bwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(kt), ptr(qt), ptr(dot),
+                               ptr(out), ptr(d_out), out.stride(0), ptr(lse), B, nh, T, d, scale, ptr(bias),
+                               bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(dq), ptr(dk), ptr(dv),
+                               dqkv.stride(0), ptr(g_bias), ptr(delta), drop_p, drop_seed & 0xFFFFFFFF, stream()),
           "peneo_attn_bwd")
     return dqkv
 
@@ -328,7 +394,7 @@ def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence
 def pair_heads_fwd(ab: torch.Tensor, w1p: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
                    classes: Sequence[int], *, want_logits: bool = True, tags: Optional[Sequence[torch.Tensor]] = None,
                    class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False):
-    """ab: [B, N, 2D].  Returns (logits list | None, loss_num, loss_den, dlogits list | None, dl_sum)."""
+    """ab: [B, N, 2D].  Returns (logits list | None, loss partials [n, 32] | None, dlogits list | None)."""
     _c(ab)
     B, N, D2 = ab.shape
     D = D2 // 2
@@ -342,13 +408,11 @@ def pair_heads_fwd(ab: torch.Tensor, w1p: torch.Tensor, b1: torch.Tensor, w2p: t
     logits = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes] if want_logits else None
     lp = _ptr_list(logits) if logits is not None else None
     loss = None
-    num = den = dls = None
+    partials = None
     dlog = None
     if tags is not None:
         loss = hip.PairLoss()
-        num = torch.zeros(nh, dtype=torch.float32, device=ab.device)
-        den = torch.zeros(nh, dtype=torch.float32, device=ab.device)
-        dls = torch.zeros(sum(classes), dtype=torch.float32, device=ab.device)
+        partials = torch.empty((lib().peneo_pair_loss_partials(B, N), 32), dtype=torch.float32, device=ab.device)
         if want_dlogits:
             dlog = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes]
         for h in range(nh):
@@ -357,10 +421,11 @@ def pair_heads_fwd(ab: torch.Tensor, w1p: torch.Tensor, b1: torch.Tensor, w2p: t
             loss.class_weight[h] = ptr(class_weights[h]) if class_weights is not None else None
             if dlog is not None:
                 loss.dlogits[h] = ptr(dlog[h])
-        loss.loss_num, loss.loss_den, loss.dl_sum = ptr(num), ptr(den), ptr(dls)
-    check(lib().peneo_pair_heads_fwd(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
-                                     C.byref(loss) if loss is not None else None, stream()), "peneo_pair_heads_fwd")
-    return logits, num, den, dlog, dls
+        loss.partials = ptr(partials)
+    with kernel_timer("pair_heads_fwd"):
+        check(lib().peneo_pair_heads_fwd(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
+                                         C.byref(loss) if loss is not None else None, stream()), "peneo_pair_heads_fwd")
+    return logits, partials, dlog
 
 
 def pair_x_fwd(ab_doc: torch.Tensor, i0: int, i1: int, out: torch.Tensor) -> torch.Tensor:
@@ -377,23 +442,41 @@ def pair_x_bwd(ab_doc: torch.Tensor, i0: int, i1: int, dx: torch.Tensor, d_ab_do
                                  stream()), "peneo_pair_x_bwd")
 
 
+def pair_dz_workspace(nh: int, D: int, device) -> torch.Tensor:
+    """Zeroed [256, 4 * nh * D] fp32 accumulator for pair_dz (sum its rows with colsum at the end)."""
+    return torch.zeros((lib().peneo_pair_dz_workspace_bytes(nh, D) // (16 * nh * D), 4 * nh * D), dtype=torch.float32,
+                       device=device)
+
+
 def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor],
-            w2: Sequence[torch.Tensor], dw2: Sequence[torch.Tensor], db1: torch.Tensor, scale: torch.Tensor) -> None:
+            w2: Sequence[torch.Tensor], workspace: torch.Tensor, scale: torch.Tensor) -> None:
     a = hip.PairDzArgs()
     a.num_heads, a.D = len(classes), D
     for h, c in enumerate(classes):
         a.classes[h] = c
-        a.dlogits[h], a.w2[h], a.dw2[h] = ptr(dlogits[h]), ptr(w2[h]), ptr(dw2[h])
-    a.db1, a.scale = ptr(db1), ptr(scale)
-    check(lib().peneo_pair_dz(dtype_code(z.dtype), ptr(z), npairs, C.byref(a), stream()), "peneo_pair_dz")
+        a.dlogits[h], a.w2[h] = ptr(dlogits[h]), ptr(w2[h])
+    a.scale = ptr(scale)
+    check(lib().peneo_pair_dz(dtype_code(z.dtype), ptr(z), npairs, C.byref(a), ptr(workspace), stream()), "peneo_pair_dz")
 
 
-def loss_finish(num: torch.Tensor, den: torch.Tensor, ratio: torch.Tensor):
-    nh = num.numel()
-    out = torch.empty(nh + 1, dtype=torch.float32, device=num.device)
-    scale = torch.empty(nh, dtype=torch.float32, device=num.device)
-    check(lib().peneo_loss_finish(ptr(num), ptr(den), ptr(ratio), nh, ptr(out), ptr(scale), stream()), "peneo_loss_finish")
-    return out, scale
+def pair_dz_finish(workspace: torch.Tensor, nh: int, D: int, classes: Sequence[int]):
+    """-> (dw2 list of [C_h, D] fp32, db1 [nh * D] fp32) from the accumulated workspace."""
+    vec = colsum(workspace)                     # [4 * nh * D]
+    ncol = nh * D
+    blk = vec.view(4, ncol)
+    dw2 = [blk[:c, h * D:(h + 1) * D] for h, c in enumerate(classes)]
+    return dw2, blk[3]
+
+
+def loss_finish(partials: torch.Tensor, ratio: torch.Tensor, total_classes: int):
+    """-> (out [nh + 1] per-head losses then total, scale [nh] = ratio_h / den_h, dl_sum [total_classes])."""
+    nh = ratio.numel()
+    out = torch.empty(nh + 1, dtype=torch.float32, device=partials.device)
+    scale = torch.empty(nh, dtype=torch.float32, device=partials.device)
+    dls = torch.empty(total_classes, dtype=torch.float32, device=partials.device)
+    check(lib().peneo_loss_finish(ptr(partials), partials.shape[0], ptr(ratio), nh, total_classes, ptr(out), ptr(scale),
+                                  ptr(dls), stream()), "peneo_loss_finish")
+    return out, scale, dls
 
 
 def weighted_ce(logits: torch.Tensor, tags: torch.Tensor, cw: Optional[torch.Tensor], want_dlogits: bool = False):
