@@ -219,20 +219,16 @@ typedef struct peneo_pair_heads_desc {
   int num_heads;                       /* <= PENEO_MAX_HEADS */
   int D;                               /* decoder hidden size (multiple of 32) */
   int classes[PENEO_MAX_HEADS];        /* 2,3,3,3,3 */
-  const void* w1_packed;               /* from peneo_pair_heads_pack_w1 */
+  const void* w_packed;                /* from peneo_pair_heads_pack (both layers, MFMA fragment order) */
   const float* b1;                     /* [num_heads * D] */
-  const void* w2_packed;               /* from peneo_pair_heads_pack_w2 */
   const float* b2;                     /* [sum classes] */
 } peneo_pair_heads_desc;
 
-size_t peneo_pair_heads_w1_packed_bytes(int dtype, int num_heads, int D);
-size_t peneo_pair_heads_w2_packed_bytes(int dtype, int num_heads, int D);
-/* w1[h] : [D, D] row-major fp32 (nn.Linear weight), w2[h] : [classes[h], D] fp32 */
-/* w1 / w2 / classes are HOST arrays (of device pointers / ints) with num_heads entries */
-int peneo_pair_heads_pack_w1(int dtype, const float* const* w1, int num_heads, int D, void* packed,
-                             peneo_stream_t stream);
-int peneo_pair_heads_pack_w2(int dtype, const float* const* w2, const int* classes, int num_heads,
-                             int D, void* packed, peneo_stream_t stream);
+size_t peneo_pair_heads_packed_bytes(int dtype, int num_heads, int D);
+/* w1[h] : [D, D] row-major fp32 (nn.Linear weight), w2[h] : [classes[h], D] fp32;
+ * w1 / w2 / classes are HOST arrays (of device pointers / ints) with num_heads entries */
+int peneo_pair_heads_pack(int dtype, const float* const* w1, const float* const* w2, const int* classes,
+                          int num_heads, int D, void* packed, peneo_stream_t stream);
 
 typedef struct peneo_pair_loss {
   const int64_t* tags[PENEO_MAX_HEADS];   /* [B, P] label maps (data/collator.py:170-204); NULL = no loss */

@@ -77,7 +77,11 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE-division / denormal-safe library forms: an fp32 divide is
+// ~10 VALU instructions, and SiLU runs on every one of the nh*D hidden units of every token pair.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
   float s = sigmoid_f(x);

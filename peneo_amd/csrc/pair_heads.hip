@@ -16,65 +16,73 @@
 //   * finishes with soft-max cross-entropy per head (fp32) and writes only the 14 logits per pair
 //     (and, for training, the un-normalised dlogits and the loss partial sums).
 // HBM traffic per document is the 7.3 MB of logits; everything else is L2/LDS resident.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace peneo {
 
-constexpr int PH_PAIRS = 128;       // pairs per workgroup (4 waves x 32)
-constexpr int NCP = 16;             // padded class rows that are ever non-zero (<= 16)
+constexpr int PH_WAVES = 8;
+constexpr int PH_PAIRS = PH_WAVES * 32;   // pairs per workgroup (8 waves x 32)
+constexpr int NCP = 16;                   // padded class rows that are ever non-zero (<= 16)
 
 struct PackSrc {
-  const float* w[PENEO_MAX_HEADS];
+  const float* w1[PENEO_MAX_HEADS];
+  const float* w2[PENEO_MAX_HEADS];
   int classes[PENEO_MAX_HEADS];
   int num_heads;
   int D;
 };
 
-// packed W1: [(ht * KS + ks) * 64 + lane] * 8 + e  <-  W1cat[ht*32 + (lane&31)][16*ks + 8*(lane>>5) + e]
-template <typename T>
-__global__ void pack_w1_kernel(PackSrc s, T* out) {
-  const int D = s.D, KS = D / 16;
-  const int64_t total = (int64_t)s.num_heads * D * D;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int e = (int)(i & 7);
-    int lane = (int)((i >> 3) & 63);
-    int64_t blk = i >> 9;
-    int ks = (int)(blk % KS);
-    int ht = (int)(blk / KS);
-    int row = ht * 32 + (lane & 31);           // hidden unit in [0, nh*D)
-    int col = 16 * ks + 8 * (lane >> 5) + e;
-    int h = row / D;
-    Elem<T>::store(out + i, s.w[h][(int64_t)(row - h * D) * D + col]);
-  }
+// Packed weights, one contiguous block per 32-row slab of hidden units, in MFMA A-fragment order
+// (64 lanes x 8 elements per fragment):
+//   fragment ks < KS   : W1cat[slab*32 + (lane&31)][16*ks + 8*(lane>>5) + e]                       (first layer)
+//   fragment KS + kk   : W2full[class = lane&31][hidden = slab*32 + 16*kk + (e&3) + 8*(e>>2) + 4*(lane>>5)]
+// where W2full is the block-diagonal [sum classes (zero padded to 32), nh*D] second-layer matrix and the hidden
+// permutation is the one under which a C-layout accumulator tile is directly a B operand.
+// Slabs are padded to a whole number of 1 KiB DMA units per wave (slab_stride_elems elements per slab), so that
+// every wave of the forward kernel issues the same number of LDS-DMA instructions with immediate offsets.
+__host__ __device__ inline int64_t slab_stride_bytes(int D, int elem_bytes) {
+  const int64_t payload = (int64_t)(D / 16 + 2) * 512 * elem_bytes;
+  const int64_t quantum = (int64_t)PH_WAVES * 1024;
+  return (payload + quantum - 1) / quantum * quantum;
 }
-
-// packed W2: [(ht * 2 + kk) * 64 + lane] * 8 + t  <-  W2full[class = lane&31][hidden = ht*32 + 16*kk + (t&3) + 8*(t>>2) + 4*(lane>>5)]
-// where W2full is the block-diagonal [sum classes (padded to 32), nh*D] matrix.
 template <typename T>
-__global__ void pack_w2_kernel(PackSrc s, T* out) {
-  const int D = s.D;
-  const int64_t total = (int64_t)s.num_heads * D / 32 * 2 * 64 * 8;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int t = (int)(i & 7);
-    int lane = (int)((i >> 3) & 63);
-    int64_t blk = i >> 9;
-    int kk = (int)(blk & 1);
-    int ht = (int)(blk >> 1);
-    int cls = lane & 31;
-    int hidden = ht * 32 + 16 * kk + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
-    int h = hidden / D;
-    int off = 0;
-    for (int q = 0; q < h; ++q) off += s.classes[q];
+__global__ void pack_weights_kernel(PackSrc s, T* out) {
+  const int D = s.D, KS = D / 16, NF = KS + 2;
+  const int nslab = s.num_heads * D / 32;
+  const int64_t stride = slab_stride_bytes(D, (int)sizeof(T)) / (int64_t)sizeof(T);
+  const int64_t total = (int64_t)nslab * stride;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int slab = (int)(j / stride);
+    const int64_t i = j % stride;
+    if (i >= (int64_t)NF * 512) { Elem<T>::store(out + j, 0.f); continue; }
+    const int e = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    const int f = (int)(i >> 9);
     float v = 0.f;
-    if (cls >= off && cls < off + s.classes[h]) v = s.w[h][(int64_t)(cls - off) * D + (hidden - h * D)];
-    Elem<T>::store(out + i, v);
+    if (f < KS) {
+      const int row = slab * 32 + (lane & 31);
+      const int col = 16 * f + 8 * (lane >> 5) + e;
+      const int h = row / D;
+      v = s.w1[h][(int64_t)(row - h * D) * D + col];
+    } else {
+      const int kk = f - KS;
+      const int cls = lane & 31;
+      const int hidden = slab * 32 + 16 * kk + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      const int h = hidden / D;
+      int off = 0;
+      for (int q = 0; q < h; ++q) off += s.classes[q];
+      if (cls >= off && cls < off + s.classes[h]) v = s.w2[h][(int64_t)(cls - off) * D + (hidden - h * D)];
+    }
+    Elem<T>::store(out + j, v);
   }
 }
 
 struct PairFwdParams {
   const void* ab; int B, N, D; int64_t P;
   int num_heads; int classes[PENEO_MAX_HEADS]; int total_classes;
-  const void* w1p; const float* b1; const void* w2p; const float* b2;
+  const void* wp; const float* b1; const float* b2;
   float* logits[PENEO_MAX_HEADS];
   const int64_t* tags[PENEO_MAX_HEADS];
   const float* cw[PENEO_MAX_HEADS];
@@ -106,95 +114,29 @@ __device__ __forceinline__ Frag<T> load_frag_linear(const char* base, int frag_i
   return f;
 }
 
-template <typename T, int KS>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SLAB_BYTES = KS * 64 * FragBytes<T>::v;     // one 32-row slab of W1 in fragment order
-  constexpr int NV = SLAB_BYTES / 16;                       // 16-byte vectors per slab
-  constexpr int VPT = (NV + 255) / 256;                     // ... per thread
-  char* sW = smem;                                           // [2][SLAB_BYTES]
-  float* sB1 = reinterpret_cast<float*>(smem + 2 * SLAB_BYTES);  // [nh * D]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const int D = p.D, N = p.N;
-  const int b = blockIdx.y;
-  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
-  const int64_t mypair = p0 + wave * 32 + (lane & 31);
-  const bool pair_ok = mypair < p.P;
-  int pi, pj;
-  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
-  const int nslab = p.num_heads * D / 32;
-
-  for (int i = tid; i < p.num_heads * D; i += 256) sB1[i] = p.b1[i];
-
-  // ---- x = SiLU(a_i + b_j) as B-operand fragments (k = decoder dim), kept in registers ----
-  const T* abd = reinterpret_cast<const T*>(p.ab) + (int64_t)b * N * 2 * D;
-  const T* arow = abd + (int64_t)pi * 2 * D;
-  const T* brow = abd + (int64_t)pj * 2 * D + D;
-  Frag<T> xf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = 16 * ks + 8 * half;
-    float a[8], bb[8];
-    if constexpr (sizeof(T) == 2) {
-      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
-      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
-    } else {
-      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
-      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c + 4), a + 4);
-      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
-      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c + 4), bb + 4);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
-    if constexpr (sizeof(T) == 2) xf[ks].v = pack16<T>(a);
-    else { xf[ks].v[0] = pack16<T>(a); xf[ks].v[1] = pack16<T>(a + 4); }
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the count must be an immediate
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
+}
 
-  f32x16_t lg;  // logits^T[class, pair]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lg[r] = 0.f;
-
-  // ---- stream W1 slabs through LDS (register-staged double buffer) ----
-  const uint4* w1g = reinterpret_cast<const uint4*>(p.w1p);
-  uint4 stage[VPT];
-#define PH_GLOAD(slab_)                                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < VPT; ++i_) {                                       \
-    if (NV % 256 == 0 || tid + 256 * i_ < NV) stage[i_] = w1g[(int64_t)(slab_) * NV + tid + 256 * i_]; \
-  }
-#define PH_LSTORE(buf_)                                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < VPT; ++i_) {                                       \
-    if (NV % 256 == 0 || tid + 256 * i_ < NV)                                                 \
-      *reinterpret_cast<uint4*>(sW + (buf_) * SLAB_BYTES + (tid + 256 * i_) * 16) = stage[i_]; \
-  }
-  PH_GLOAD(0)
-  PH_LSTORE(0)
-  __syncthreads();
-  for (int slab = 0; slab < nslab; ++slab) {
-    const int buf = slab & 1;
-    const bool more = slab + 1 < nslab;
-    PH_GLOAD(more ? slab + 1 : slab)   // unconditional (a predicated refill sends `stage` to scratch)
-    // second-layer fragments for this slab (L2 resident, 2 KiB per wave)
-    Frag<T> w2f0 = load_frag_linear<T>(reinterpret_cast<const char*>(p.w2p), slab * 2 + 0, lane);
-    Frag<T> w2f1 = load_frag_linear<T>(reinterpret_cast<const char*>(p.w2p), slab * 2 + 1, lane);
-    f32x16_t z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    const char* wb = sW + buf * SLAB_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
-      mma_step(wf, xf[ks], z);
-    }
-    float y[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = silu_f(z[r] + sB1[slab * 32 + acc_row(r, lane)]);
-    Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
-    mma_step(w2f0, y0, lg);
-    mma_step(w2f1, y1, lg);
-    PH_LSTORE(buf ^ 1)
-    __syncthreads();
-  }
-
+// logits^T accumulator -> per-pair logits, soft-max CE, un-normalised dlogits and the workgroup's partial sums
+__device__ __forceinline__ void pair_epilogue(const PairFwdParams& p, const f32x16_t& lg, char* smem, int tid, int lane, int wave,
+                                              int half, int b, int64_t mypair, bool pair_ok) {
   // ---- logits: rows 0..15 of lg live in regs 0..7 (half 0: rows 0-3, 8-11; half 1: rows 4-7, 12-15) ----
   float mine[8], other[8];
 #pragma unroll
@@ -256,7 +198,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_ke
   if (p.partials) {
     // one row of partial sums per workgroup (plain stores; peneo_loss_finish reduces them): contended atomics
     // on a handful of addresses cost more than the whole MFMA phase
-    float* sRed = reinterpret_cast<float*>(smem);  // [4 waves][32] (the W1 buffers are dead)
+    float* sRed = reinterpret_cast<float*>(smem);  // [8 waves][32] (the weight ring is dead)
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < PENEO_MAX_HEADS; ++h) {
@@ -269,9 +211,262 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_ke
       if (lane == 0) sRed[wave * 32 + 16 + c] = a;
     }
     __syncthreads();
-    if (tid < 32)
-      p.partials[((int64_t)b * gridDim.x + blockIdx.x) * 32 + tid] = sRed[tid] + sRed[32 + tid] + sRed[64 + tid] + sRed[96 + tid];
+    if (tid < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < PH_WAVES; ++w) t += sRed[w * 32 + tid];
+      p.partials[((int64_t)b * gridDim.x + blockIdx.x) * 32 + tid] = t;
+    }
   }
+}
+
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// hand-issued LDS reads: hipcc neither counts them nor (crucially) drains the in-flight LDS-DMA ring in front of them;
+// the reader owns lgkmcnt (s_waitcnt + sched_barrier before the first consumer, guide §5.7 / rule 18)
+#define DS_READ_B128(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
+#define LGKM_WAIT(n_)                                         \
+  asm volatile("s_waitcnt lgkmcnt(" #n_ ")" ::: "memory");    \
+  __builtin_amdgcn_sched_barrier(0);
+
+__device__ __forceinline__ void mma_bf16(const u32x4_t& a, const Frag<bf16_t>& b, f32x16_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
+}
+
+template <int OFF> __device__ __forceinline__ void dsr128(u32x4_t& d, uint32_t a) { DS_READ_B128(d, a, OFF); }
+template <int G> __device__ __forceinline__ void rd4(u32x4_t (&f)[4], uint32_t wa) {
+  dsr128<(G * 4 + 0) * 1024>(f[0], wa); dsr128<(G * 4 + 1) * 1024>(f[1], wa);
+  dsr128<(G * 4 + 2) * 1024>(f[2], wa); dsr128<(G * 4 + 3) * 1024>(f[3], wa);
+}
+// software pipeline over the first-layer fragments of one slab: while group G feeds the matrix pipe, group G+1
+// (or the tail: second-layer fragments + bias) is already on its way out of LDS into the other register set
+template <int G, int NG4, int KS>
+__device__ __forceinline__ void slab_steps(u32x4_t (&cur)[4], u32x4_t (&nxt)[4], u32x4_t& w2a, u32x4_t& w2b, u32x4_t (&bq)[4],
+                                           uint32_t wa, uint32_t ba, const Frag<bf16_t> (&xf)[KS], f32x16_t& z) {
+  if constexpr (G + 1 < NG4) {
+    rd4<G + 1>(nxt, wa);
+    LGKM_WAIT(4)
+  } else {
+    dsr128<KS * 1024>(w2a, wa); dsr128<(KS + 1) * 1024>(w2b, wa);
+    dsr128<0>(bq[0], ba); dsr128<32>(bq[1], ba); dsr128<64>(bq[2], ba); dsr128<96>(bq[3], ba);
+    LGKM_WAIT(6)
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mma_bf16(cur[i], xf[G * 4 + i], z);
+  if constexpr (G + 1 < NG4) slab_steps<G + 1, NG4, KS>(nxt, cur, w2a, w2b, bq, wa, ba, xf, z);
+}
+
+// bf16 throughput variant (KS a multiple of 4): 3-deep LDS-DMA ring with counted vmcnt, and the A-fragment LDS reads
+// software-pipelined by hand in groups of 4 (two register sets), so the matrix pipe never waits on a just-issued ds_read.
+template <int KS>
+__global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_pipe_kernel(PairFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int NSTAGE = 3;
+  constexpr int NF = KS + 2;
+  constexpr int UPW = (NF + PH_WAVES - 1) / PH_WAVES;       // 1 KiB DMA units per wave per slab
+  constexpr int SLAB_BYTES = UPW * PH_WAVES * 1024;          // padded slab (== packed slab stride)
+  constexpr int NG4 = KS / 4;
+  char* sW = smem;
+  float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D, N = p.N;
+  const int b = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
+  const int64_t mypair = p0 + wave * 32 + (lane & 31);
+  const bool pair_ok = mypair < p.P;
+  int pi, pj;
+  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
+  const int nslab = p.num_heads * D / 32;
+
+  for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
+
+  const T* abd = reinterpret_cast<const T*>(p.ab) + (int64_t)b * N * 2 * D;
+  const T* arow = abd + (int64_t)pi * 2 * D;
+  const T* brow = abd + (int64_t)pj * 2 * D + D;
+  Frag<T> xf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = 16 * ks + 8 * half;
+    float a[8], bb[8];
+    unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+    unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+    xf[ks] = pack_frag8<T>(a);
+    if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep at most 8 gathers in flight (else the raw loads spill)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                          // sB1 visible
+
+  // this wave's UPW consecutive 1 KiB units of every slab: one per-lane pointer + immediate offsets
+  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
+  char* wdst = sW + wave * (UPW * 1024);
+#define PIPE_DMA(slab_, buf_)                                                                                 \
+  {                                                                                                           \
+    const __attribute__((address_space(1))) char* g_ =                                                        \
+        (const __attribute__((address_space(1))) char*)(wsrc + (int64_t)(slab_) * SLAB_BYTES);                \
+    __attribute__((address_space(3))) char* l_ = (__attribute__((address_space(3))) char*)(wdst + (buf_) * SLAB_BYTES); \
+    __builtin_amdgcn_global_load_lds(g_, l_, 16, 0, 0);                                                       \
+    if constexpr (UPW > 1) __builtin_amdgcn_global_load_lds(g_ + 1024, l_ + 1024, 16, 0, 0);                  \
+    if constexpr (UPW > 2) __builtin_amdgcn_global_load_lds(g_ + 2048, l_ + 2048, 16, 0, 0);                  \
+    if constexpr (UPW > 3) __builtin_amdgcn_global_load_lds(g_ + 3072, l_ + 3072, 16, 0, 0);                  \
+    if constexpr (UPW > 4) __builtin_amdgcn_global_load_lds(g_ + 4096, l_ + 4096, 16, 0, 0);                  \
+  }
+  static_assert(UPW <= 5, "slab too large");
+  PIPE_DMA(0, 0)
+  if (nslab > 1) PIPE_DMA(1, 1)
+
+  f32x16_t lg;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lg[r] = 0.f;
+  const uint32_t lbase = lds_addr(sW) + lane * 16;
+  const uint32_t bbase = lds_addr(sB1) + half * 16;          // + slab*128 bytes; the 4 groups are +0,+32,+64,+96
+
+  for (int slab = 0; slab < nslab; ++slab) {
+    // slab (and slab+1, unless this is the last) are in flight: wait for the older one only
+    if (slab + 1 < nslab) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(UPW) : "memory"); }
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (slab + 2 < nslab) PIPE_DMA(slab + 2, (slab + 2) % NSTAGE)
+    const uint32_t wa = lbase + (slab % NSTAGE) * SLAB_BYTES;
+    const uint32_t ba = bbase + slab * 128;
+
+    u32x4_t fa[4], fb[4], w2a, w2b, bq[4];
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    rd4<0>(fa, wa);
+    slab_steps<0, NG4, KS>(fa, fb, w2a, w2b, bq, wa, ba, xf, z);
+    LGKM_WAIT(0)
+    float y[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      y[4 * g + 0] = silu_f(z[4 * g + 0] + __uint_as_float(bq[g][0]));
+      y[4 * g + 1] = silu_f(z[4 * g + 1] + __uint_as_float(bq[g][1]));
+      y[4 * g + 2] = silu_f(z[4 * g + 2] + __uint_as_float(bq[g][2]));
+      y[4 * g + 3] = silu_f(z[4 * g + 3] + __uint_as_float(bq[g][3]));
+    }
+    Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
+    mma_bf16(w2a, y0, lg);
+    mma_bf16(w2b, y1, lg);
+  }
+#undef PIPE_DMA
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
+}
+
+// Weight slabs stream global (L2) -> LDS with the asynchronous LDS-DMA path (global_load_lds_dwordx4: 64 lanes x 16 B
+// = 1 KiB per wave-instruction, destination = wave-uniform LDS base + lane*16, which is exactly the packed fragment
+// order), into a ring of NSTAGE buffers, NSTAGE-1 slabs ahead of the MFMAs.  Ordering: each wave waits for its own
+// DMA pieces of the slab with a COUNTED s_waitcnt vmcnt (later slabs stay in flight), then a raw s_barrier makes every
+// wave's pieces visible (and proves every wave has finished reading the buffer that is refilled next).
+template <typename T, int KS, int NSTAGE>
+__global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NF = KS + 2;                                // fragments per slab (first layer KS, second layer 2)
+  constexpr int SLAB_BYTES = NF * 64 * FragBytes<T>::v;
+  constexpr int NU = SLAB_BYTES / 1024;                     // 1 KiB DMA units per slab
+  constexpr int UPW = (NU + PH_WAVES - 1) / PH_WAVES;       // units per wave (upper bound)
+  char* sW = smem;                                           // [NSTAGE][SLAB_BYTES]
+  float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES);  // [nh * D]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D, N = p.N;
+  const int b = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
+  const int64_t mypair = p0 + wave * 32 + (lane & 31);
+  const bool pair_ok = mypair < p.P;
+  int pi, pj;
+  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
+  const int nslab = p.num_heads * D / 32;
+  const int my_units = (NU - wave + PH_WAVES - 1) / PH_WAVES;   // DMA units this wave issues per slab (wave-uniform)
+
+  for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
+
+  // ---- x = SiLU(a_i + b_j) as B-operand fragments (k = decoder dim), kept in registers ----
+  const T* abd = reinterpret_cast<const T*>(p.ab) + (int64_t)b * N * 2 * D;
+  const T* arow = abd + (int64_t)pi * 2 * D;
+  const T* brow = abd + (int64_t)pj * 2 * D + D;
+  Frag<T> xf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = 16 * ks + 8 * half;
+    float a[8], bb[8];
+    if constexpr (sizeof(T) == 2) {
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+    } else {
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c + 4), a + 4);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c + 4), bb + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+    xf[ks] = pack_frag8<T>(a);
+  }
+  // every ordinary global load above has been consumed (its results are in xf): the vm counter now only sees DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const char* wg = reinterpret_cast<const char*>(p.wp);
+  const int64_t gstride = slab_stride_bytes(D, (int)sizeof(T));
+#define PH_DMA(slab_, buf_)                                                                                   \
+  _Pragma("unroll") for (int u_ = 0; u_ < UPW; ++u_) {                                                        \
+    const int unit_ = wave + PH_WAVES * u_;                                                                   \
+    if (unit_ < NU)                                                                                           \
+      __builtin_amdgcn_global_load_lds(                                                                       \
+          (const __attribute__((address_space(1))) void*)(wg + (int64_t)(slab_) * gstride + unit_ * 1024 + lane * 16), \
+          (__attribute__((address_space(3))) void*)(sW + (buf_) * SLAB_BYTES + unit_ * 1024), 16, 0, 0);      \
+  }
+  // prologue: NSTAGE-1 slabs in flight
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nslab) { PH_DMA(s0, s0) }
+
+  f32x16_t lg;  // logits^T[class, pair]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lg[r] = 0.f;
+
+  for (int slab = 0; slab < nslab; ++slab) {
+    // slabs slab .. slab+NSTAGE-2 are in flight (fewer near the end); leave all but the oldest outstanding
+    const int later = min(NSTAGE - 2, nslab - 1 - slab);
+    wait_vmcnt(later * my_units);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (slab + NSTAGE - 1 < nslab) { PH_DMA(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE) }
+    const char* wb = sW + (slab % NSTAGE) * SLAB_BYTES;
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
+      mma_step(wf, xf[ks], z);
+    }
+    Frag<T> w2f0 = load_frag_linear<T>(wb, KS, lane);
+    Frag<T> w2f1 = load_frag_linear<T>(wb, KS + 1, lane);
+    float y[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {   // accumulator rows 8g + 4*half + 0..3 -> one 16-byte bias read
+      const float4 bv = *reinterpret_cast<const float4*>(sB1 + slab * 32 + 8 * g + 4 * half);
+      y[4 * g + 0] = silu_f(z[4 * g + 0] + bv.x);
+      y[4 * g + 1] = silu_f(z[4 * g + 1] + bv.y);
+      y[4 * g + 2] = silu_f(z[4 * g + 2] + bv.z);
+      y[4 * g + 3] = silu_f(z[4 * g + 3] + bv.w);
+    }
+    Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
+    mma_step(w2f0, y0, lg);
+    mma_step(w2f1, y1, lg);
+  }
+#undef PH_DMA
+
+  pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
 }
 
 // ================================================================================================
@@ -522,17 +717,40 @@ __global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits
   if (threadIdx.x == 0) *count = base;
 }
 
-template <typename T, int KS>
-static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
-  size_t sh = (size_t)2 * KS * 64 * FragBytes<T>::v + (size_t)p.num_heads * p.D * sizeof(float);
+template <int KS>
+static int launch_pair_fwd_pipe(const PairFwdParams& p, hipStream_t st) {
+  size_t sh = 3 * (size_t)slab_stride_bytes(KS * 16, 2) + (size_t)p.num_heads * p.D * sizeof(float);
+  if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (sh > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_pipe_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
       set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
       return PENEO_ERR_LAUNCH;
     }
   }
   dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
-  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS>), grid, dim3(256), sh, st, p);
+  hipLaunchKernelGGL((pair_heads_fwd_pipe_kernel<KS>), grid, dim3(PH_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_heads_fwd");
+}
+
+template <typename T, int KS>
+static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && KS % 4 == 0) {
+    if (getenv("PENEO_PAIR_PIPE")) return launch_pair_fwd_pipe<KS>(p, st);  // hand-pipelined variant: opt-in (measured slower so far)
+  }
+  constexpr int NSTAGE = sizeof(T) == 2 ? 3 : 2;
+  constexpr size_t slab = (size_t)(KS + 2) * 64 * FragBytes<T>::v;
+  static_assert(slab % 1024 == 0, "slab must be a whole number of 1 KiB DMA units");
+  size_t sh = NSTAGE * slab + (size_t)p.num_heads * p.D * sizeof(float);
+  if (sh < (size_t)PH_WAVES * 32 * sizeof(float)) sh = (size_t)PH_WAVES * 32 * sizeof(float);
+  if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
+  if (sh > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
+      return PENEO_ERR_LAUNCH;
+    }
+  }
+  dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
+  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS, NSTAGE>), grid, dim3(PH_WAVES * 64), sh, st, p);
   return check_launch("peneo_pair_heads_fwd");
 }
 template <typename T>
@@ -560,45 +778,27 @@ static inline unsigned cap_blocks(int64_t n, int per = 256, int64_t cap = 8192) 
 }
 static int total_classes(const int* classes, int nh) { int t = 0; for (int h = 0; h < nh; ++h) t += classes[h]; return t; }
 
-extern "C" size_t peneo_pair_heads_w1_packed_bytes(int dtype, int num_heads, int D) {
-  return (size_t)num_heads * D * D * (dtype == PENEO_BF16 ? 2 : 4);
-}
-extern "C" size_t peneo_pair_heads_w2_packed_bytes(int dtype, int num_heads, int D) {
-  return (size_t)num_heads * D / 32 * 2 * 64 * 8 * (dtype == PENEO_BF16 ? 2 : 4);
+extern "C" size_t peneo_pair_heads_packed_bytes(int dtype, int num_heads, int D) {
+  return (size_t)(num_heads * D / 32) * (size_t)slab_stride_bytes(D, dtype == PENEO_BF16 ? 2 : 4);
 }
 
-static int fill_pack_src(PackSrc& s, const float* const* w, const int* classes, int num_heads, int D, const char* who) {
-  PENEO_REQUIRE(num_heads > 0 && num_heads <= PENEO_MAX_HEADS, "%s: num_heads out of range", who);
-  PENEO_REQUIRE(D > 0 && D % 32 == 0, "%s: D must be a multiple of 32", who);
+extern "C" int peneo_pair_heads_pack(int dtype, const float* const* w1, const float* const* w2, const int* classes,
+                                     int num_heads, int D, void* packed, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && w1 && w2 && classes && packed, "peneo_pair_heads_pack: bad arguments");
+  PENEO_REQUIRE(num_heads > 0 && num_heads <= PENEO_MAX_HEADS, "peneo_pair_heads_pack: num_heads out of range");
+  PENEO_REQUIRE(D > 0 && D % 32 == 0, "peneo_pair_heads_pack: D must be a multiple of 32");
+  PENEO_REQUIRE(total_classes(classes, num_heads) <= NCP, "peneo_pair_heads_pack: more than %d classes in total", NCP);
+  PackSrc s = {};
   s.num_heads = num_heads; s.D = D;
-  for (int h = 0; h < PENEO_MAX_HEADS; ++h) { s.w[h] = h < num_heads ? w[h] : nullptr; s.classes[h] = (classes && h < num_heads) ? classes[h] : 0; }
-  for (int h = 0; h < num_heads; ++h) PENEO_REQUIRE(s.w[h] != nullptr, "%s: null weight pointer for head %d", who, h);
-  return PENEO_OK;
-}
-
-extern "C" int peneo_pair_heads_pack_w1(int dtype, const float* const* w1, int num_heads, int D, void* packed, peneo_stream_t stream) {
-  PENEO_REQUIRE(ok_dt(dtype) && w1 && packed, "peneo_pair_heads_pack_w1: bad arguments");
-  PackSrc s;
-  int rc = fill_pack_src(s, w1, nullptr, num_heads, D, "peneo_pair_heads_pack_w1");
-  if (rc) return rc;
-  int64_t total = (int64_t)num_heads * D * D;
-  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pack_w1_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)packed);
-  else hipLaunchKernelGGL(pack_w1_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (float*)packed);
-  return check_launch("peneo_pair_heads_pack_w1");
-}
-
-extern "C" int peneo_pair_heads_pack_w2(int dtype, const float* const* w2, const int* classes, int num_heads, int D, void* packed,
-                                        peneo_stream_t stream) {
-  PENEO_REQUIRE(ok_dt(dtype) && w2 && classes && packed, "peneo_pair_heads_pack_w2: bad arguments");
-  PackSrc s;
-  int rc = fill_pack_src(s, w2, classes, num_heads, D, "peneo_pair_heads_pack_w2");
-  if (rc) return rc;
-  PENEO_REQUIRE(total_classes(classes, num_heads) <= NCP, "peneo_pair_heads_pack_w2: more than %d classes in total", NCP);
-  for (int h = 0; h < num_heads; ++h) PENEO_REQUIRE(classes[h] >= 1 && classes[h] <= 4, "peneo_pair_heads_pack_w2: classes[%d] must be 1..4", h);
-  int64_t total = (int64_t)num_heads * D / 32 * 2 * 64 * 8;
-  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pack_w2_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)packed);
-  else hipLaunchKernelGGL(pack_w2_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (float*)packed);
-  return check_launch("peneo_pair_heads_pack_w2");
+  for (int h = 0; h < num_heads; ++h) {
+    PENEO_REQUIRE(w1[h] && w2[h], "peneo_pair_heads_pack: null weight pointer for head %d", h);
+    PENEO_REQUIRE(classes[h] >= 1 && classes[h] <= 4, "peneo_pair_heads_pack: classes[%d] must be 1..4", h);
+    s.w1[h] = w1[h]; s.w2[h] = w2[h]; s.classes[h] = classes[h];
+  }
+  const int64_t total = (int64_t)(num_heads * D / 32) * (slab_stride_bytes(D, dtype == PENEO_BF16 ? 2 : 4) / (dtype == PENEO_BF16 ? 2 : 4));
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)packed);
+  else hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, s, (float*)packed);
+  return check_launch("peneo_pair_heads_pack");
 }
 
 extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
@@ -606,12 +806,14 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
   PENEO_REQUIRE(ok_dt(dtype) && ab && desc && B > 0 && N > 0, "peneo_pair_heads_fwd: bad arguments");
   PENEO_REQUIRE(desc->num_heads > 0 && desc->num_heads <= PENEO_MAX_HEADS, "peneo_pair_heads_fwd: num_heads out of range");
   PENEO_REQUIRE(desc->D > 0 && desc->D % 32 == 0, "peneo_pair_heads_fwd: D must be a multiple of 32");
-  PENEO_REQUIRE(desc->w1_packed && desc->b1 && desc->w2_packed && desc->b2, "peneo_pair_heads_fwd: null weights");
+  PENEO_REQUIRE(desc->w_packed && desc->b1 && desc->b2, "peneo_pair_heads_fwd: null weights");
+  PENEO_REQUIRE((reinterpret_cast<uintptr_t>(desc->w_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(ab) & 15) == 0,
+                "peneo_pair_heads_fwd: ab / packed weights must be 16-byte aligned");
   PairFwdParams p = {};
   p.ab = ab; p.B = B; p.N = N; p.D = desc->D; p.P = (int64_t)N * (N + 1) / 2; p.num_heads = desc->num_heads;
   p.total_classes = total_classes(desc->classes, desc->num_heads);
   PENEO_REQUIRE(p.total_classes <= NCP, "peneo_pair_heads_fwd: more than %d classes in total", NCP);
-  p.w1p = desc->w1_packed; p.b1 = desc->b1; p.w2p = desc->w2_packed; p.b2 = desc->b2;
+  p.wp = desc->w_packed; p.b1 = desc->b1; p.b2 = desc->b2;
   for (int h = 0; h < desc->num_heads; ++h) {
     PENEO_REQUIRE(desc->classes[h] >= 1 && desc->classes[h] <= 4, "peneo_pair_heads_fwd: classes[%d] must be 1..4", h);
     p.classes[h] = desc->classes[h];

@@ -45,8 +45,7 @@ class EmbedGrads(C.Structure):
 
 
 class PairHeadsDesc(C.Structure):
-    _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("w1_packed", _vp), ("b1", _vp),
-                ("w2_packed", _vp), ("b2", _vp)]
+    _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("w_packed", _vp), ("b1", _vp), ("b2", _vp)]
 
 
 class PairLoss(C.Structure):
@@ -89,10 +88,8 @@ SIGNATURES = {
     "peneo_attn_fwd": (_i, [_i, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
     "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp,
                             _vp, _vp, _vp, _i64, _vp, _vp, _f, _u32, _vp]),
-    "peneo_pair_heads_w1_packed_bytes": (_sz, [_i, _i, _i]),
-    "peneo_pair_heads_w2_packed_bytes": (_sz, [_i, _i, _i]),
-    "peneo_pair_heads_pack_w1": (_i, [_i, _vp, _i, _i, _vp, _vp]),
-    "peneo_pair_heads_pack_w2": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),
+    "peneo_pair_heads_packed_bytes": (_sz, [_i, _i, _i]),
+    "peneo_pair_heads_pack": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "peneo_pair_heads_fwd": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp]),
     "peneo_pair_x_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "peneo_pair_x_bwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

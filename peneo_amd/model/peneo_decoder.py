@@ -181,12 +181,12 @@ class _DecoderStage(torch.autograd.Function):
         ab = ops.gemm(h, Wab, bias=bab).view(B, N, 2 * D)
         w1s, b1s = [hd[0] for hd in heads], [hd[1] for hd in heads]
         w2s, b2s = [hd[2] for hd in heads], [hd[3] for hd in heads]
-        p1, p2 = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
-                                                                                 [w.detach() for w in w2s]))
+        wp = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
+                                                                             [w.detach() for w in w2s]))
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         b2cat = wc.get(("dec.b2",), b2s, lambda: torch.cat([b.detach() for b in b2s]))
         cws = [dec.le_loss.weight] + [dec.link_loss.weight] * 4 if tags is not None else None
-        logits, partials, dlog = ops.pair_heads_fwd(ab, p1, b1cat, p2, b2cat, HEAD_CLASSES, want_logits=want_logits,
+        logits, partials, dlog = ops.pair_heads_fwd(ab, wp, b1cat, b2cat, HEAD_CLASSES, want_logits=want_logits,
                                                     tags=tags, class_weights=cws,
                                                     want_dlogits=need_grad and tags is not None)
         outs = []

@@ -376,22 +376,19 @@ def _ptr_list(ts: Sequence[Optional[torch.Tensor]]):
     return arr
 
 
-def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence[torch.Tensor]):
-    """w1[h]: [D, D] fp32, w2[h]: [C_h, D] fp32 -> (w1_packed, w2_packed) byte buffers."""
+def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence[torch.Tensor]) -> torch.Tensor:
+    """w1[h]: [D, D] fp32, w2[h]: [C_h, D] fp32 -> one packed byte buffer (both layers, MFMA fragment order)."""
     nh, D = len(w1), w1[0].shape[1]
     dc = dtype_code(dtype)
     dev = w1[0].device
-    p1 = torch.empty(lib().peneo_pair_heads_w1_packed_bytes(dc, nh, D), dtype=torch.uint8, device=dev)
-    p2 = torch.empty(lib().peneo_pair_heads_w2_packed_bytes(dc, nh, D), dtype=torch.uint8, device=dev)
+    packed = torch.empty(lib().peneo_pair_heads_packed_bytes(dc, nh, D), dtype=torch.uint8, device=dev)
     classes = (C.c_int * nh)(*[w.shape[0] for w in w2])
-    check(lib().peneo_pair_heads_pack_w1(dc, _ptr_list([_c(w) for w in w1]), nh, D, ptr(p1), stream()),
-          "peneo_pair_heads_pack_w1")
-    check(lib().peneo_pair_heads_pack_w2(dc, _ptr_list([_c(w) for w in w2]), classes, nh, D, ptr(p2), stream()),
-          "peneo_pair_heads_pack_w2")
-    return p1, p2
+    check(lib().peneo_pair_heads_pack(dc, _ptr_list([_c(w) for w in w1]), _ptr_list([_c(w) for w in w2]), classes, nh, D,
+                                      ptr(packed), stream()), "peneo_pair_heads_pack")
+    return packed
 
 
-def pair_heads_fwd(ab: torch.Tensor, w1p: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
+def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor,
                    classes: Sequence[int], *, want_logits: bool = True, tags: Optional[Sequence[torch.Tensor]] = None,
                    class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False):
     """ab: [B, N, 2D].  Returns (logits list | None, loss partials [n, 32] | None, dlogits list | None)."""
@@ -404,7 +401,7 @@ def pair_heads_fwd(ab: torch.Tensor, w1p: torch.Tensor, b1: torch.Tensor, w2p: t
     desc.num_heads, desc.D = nh, D
     for h, c in enumerate(classes):
         desc.classes[h] = c
-    desc.w1_packed, desc.b1, desc.w2_packed, desc.b2 = ptr(w1p), ptr(b1), ptr(w2p), ptr(b2)
+    desc.w_packed, desc.b1, desc.b2 = ptr(wp), ptr(b1), ptr(b2)
     logits = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes] if want_logits else None
     lp = _ptr_list(logits) if logits is not None else None
     loss = None

@@ -380,11 +380,11 @@ def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
     b2 = [0.1 * torch.randn(c, generator=g).to(DEV) for c in classes]
     rd = lambda t: t.to(dtype).float()
     ref, _ = _pair_ref(ab.float(), [rd(w) for w in w1], b1, [rd(w) for w in w2], b2)
-    p1, p2 = ops.pair_heads_pack(dtype, w1, w2)
+    wp = ops.pair_heads_pack(dtype, w1, w2)
     P = N * (N + 1) // 2
     tags = [torch.randint(0, c, (B, P), generator=g).to(DEV) for c in classes]
     cw = [torch.tensor([1.0, 10.0, 10.0][:c], device=DEV) for c in classes]
-    logits, partials, dlog = ops.pair_heads_fwd(ab, p1, torch.cat(b1), p2, torch.cat(b2), classes, tags=tags,
+    logits, partials, dlog = ops.pair_heads_fwd(ab, wp, torch.cat(b1), torch.cat(b2), classes, tags=tags,
                                                 class_weights=cw, want_dlogits=True)
     tot = partials.sum(0)
     num, den = tot[:5], tot[8:13]
@@ -401,7 +401,7 @@ def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
     assert rel_err(dls, torch.cat([d.sum((0, 1)) for d in dlog])) < 1e-3
     assert abs(float(out[5]) - float((num / den).sum())) < 1e-4 and rel_err(scale, 1.0 / den) < 1e-5
     # loss-only call (no logits written) agrees
-    _, part2, _ = ops.pair_heads_fwd(ab, p1, torch.cat(b1), p2, torch.cat(b2), classes, want_logits=False,
+    _, part2, _ = ops.pair_heads_fwd(ab, wp, torch.cat(b1), torch.cat(b2), classes, want_logits=False,
                                      tags=tags, class_weights=cw)
     assert rel_err(part2.sum(0)[:5], num) < 1e-5
 

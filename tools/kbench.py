@@ -85,14 +85,14 @@ def main():
         w1 = [torch.randn(D, D, device=dev) / math.sqrt(D) for _ in classes]
         w2 = [torch.randn(c, D, device=dev) / math.sqrt(D) for c in classes]
         b1, b2 = torch.zeros(5 * D, device=dev), torch.zeros(14, device=dev)
-        p1, p2 = ops.pair_heads_pack(dt, w1, w2)
+        wp = ops.pair_heads_pack(dt, w1, w2)
         P = N * (N + 1) // 2
         fl = B * P * (2.0 * D * 5 * D + 2.0 * 5 * D * 14 / 5 * 5)
-        ms = timeit(lambda: ops.pair_heads_fwd(ab, p1, b1, p2, b2, classes))
+        ms = timeit(lambda: ops.pair_heads_fwd(ab, wp, b1, b2, classes))
         print(f"pair_heads_fwd (logits):      {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s")
         tags = [torch.zeros(B, P, dtype=torch.int64, device=dev) for _ in classes]
         cw = [torch.ones(c, device=dev) for c in classes]
-        ms = timeit(lambda: ops.pair_heads_fwd(ab, p1, b1, p2, b2, classes, tags=tags, class_weights=cw, want_dlogits=True))
+        ms = timeit(lambda: ops.pair_heads_fwd(ab, wp, b1, b2, classes, tags=tags, class_weights=cw, want_dlogits=True))
         print(f"pair_heads_fwd (+CE+dlogits): {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s")
     if "ln" in what:
         x = torch.randn(M, H, device=dev).to(dt)

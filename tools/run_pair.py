@@ -1,0 +1,15 @@
+import math, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from peneo_amd import ops
+B, N, D = 8, 511, 384
+dt = torch.bfloat16
+classes = [2, 3, 3, 3, 3]
+ab = torch.randn(B, N, 2 * D, device="cuda").to(dt)
+w1 = [torch.randn(D, D, device="cuda") / math.sqrt(D) for _ in classes]
+w2 = [torch.randn(c, D, device="cuda") / math.sqrt(D) for c in classes]
+b1, b2 = torch.zeros(5 * D, device="cuda"), torch.zeros(14, device="cuda")
+wp = ops.pair_heads_pack(dt, w1, w2)
+for _ in range(3):
+    ops.pair_heads_fwd(ab, wp, b1, b2, classes)
+torch.cuda.synchronize()
