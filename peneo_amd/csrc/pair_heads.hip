@@ -80,6 +80,7 @@ __global__ void pack_weights_kernel(PackSrc s, T* out) {
 }
 
 struct PairFwdParams {
+  unsigned long long* dbg;   // optional [gridDim][4] s_memtime stamps (tools/ only)
   const void* ab; int B, N, D; int64_t P;
   int num_heads; int classes[PENEO_MAX_HEADS]; int total_classes;
   const void* wp; const float* b1; const float* b2;
@@ -361,20 +362,45 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_pipe_kernel(P
   pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
 }
 
-// Weight slabs stream global (L2) -> LDS with the asynchronous LDS-DMA path (global_load_lds_dwordx4: 64 lanes x 16 B
-// = 1 KiB per wave-instruction, destination = wave-uniform LDS base + lane*16, which is exactly the packed fragment
-// order), into a ring of NSTAGE buffers, NSTAGE-1 slabs ahead of the MFMAs.  Ordering: each wave waits for its own
-// DMA pieces of the slab with a COUNTED s_waitcnt vmcnt (later slabs stay in flight), then a raw s_barrier makes every
-// wave's pieces visible (and proves every wave has finished reading the buffer that is refilled next).
-template <typename T, int KS, int NSTAGE>
+// One 1 KiB LDS-DMA piece (global_load_lds_dwordx4: 64 lanes x 16 B; LDS destination = M0 base + offset + lane*16),
+// issued from inline asm on purpose: hipcc drains the whole vm counter (s_waitcnt vmcnt(0)) in front of every ds_read
+// while an LDS-DMA *it knows about* is in flight, which would serialise the weight stream with the MFMAs.  Hidden in
+// asm, the DMA is ours to order: counted s_waitcnt vmcnt + s_barrier before the slab is read (cdna guide §5.7).
+template <int OFF>
+__device__ __forceinline__ void lds_dma_1k(const char* gsrc_lane, uint32_t lds_base_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_base_uniform), "n"(OFF) : "memory");
+}
+template <int U, int UPW>
+__device__ __forceinline__ void lds_dma_units(const char* gsrc_lane, uint32_t lds_base_uniform) {
+  if constexpr (U < UPW) {
+    lds_dma_1k<(U % 4) * 1024>(gsrc_lane + (U / 4) * 4096, lds_base_uniform + (U / 4) * 4096);
+    lds_dma_units<U + 1, UPW>(gsrc_lane, lds_base_uniform);
+  }
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// Generic kernel (bf16 and fp32).  Per workgroup: 8 waves x 32 pairs.  Weight slabs (32 hidden rows: KS first-layer
+// fragments + 2 second-layer fragments, padded to UPW KiB per wave) stream L2 -> LDS through a ring of NSTAGE buffers,
+// NSTAGE-1 slabs ahead; one s_barrier per slab publishes them.  VARIANT bits (A/B-tested on the GPU):
+//   1: LDS-DMA issued from inline asm with counted vmcnt (else the builtin, which hipcc drains before every ds_read)
+//   2: bias + SiLU + second layer of slab s-1 software-pipelined into the first-layer MFMA stream of slab s
+//   4: two independent first-layer accumulator chains (even / odd k-steps)
+template <typename T, int KS, int NSTAGE, int VARIANT>
 __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NF = KS + 2;                                // fragments per slab (first layer KS, second layer 2)
-  constexpr int SLAB_BYTES = NF * 64 * FragBytes<T>::v;
-  constexpr int NU = SLAB_BYTES / 1024;                     // 1 KiB DMA units per slab
-  constexpr int UPW = (NU + PH_WAVES - 1) / PH_WAVES;       // units per wave (upper bound)
-  char* sW = smem;                                           // [NSTAGE][SLAB_BYTES]
-  float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES);  // [nh * D]
+  constexpr bool ASM_DMA = (VARIANT & 1) != 0, PIPE_EPI = (VARIANT & 2) != 0, DUAL = (VARIANT & 4) != 0;
+  constexpr bool SGB = (VARIANT & 16) != 0;       // sched_group_barrier interleave: 1 MFMA : 1 ds_read : few VALU
+  constexpr bool NOSTREAM = (VARIANT & 8) != 0;
+  constexpr bool NO_EPI = (VARIANT & 32) != 0, NO_LDS = (VARIANT & 64) != 0;   // ablations (wrong results)   // timing experiment only (wrong results): no DMA / barrier in the loop
+  constexpr int NF = KS + 2;
+  constexpr int PAYLOAD = NF * 64 * FragBytes<T>::v;
+  constexpr int UPW = (PAYLOAD / 1024 + PH_WAVES - 1) / PH_WAVES;   // 1 KiB DMA pieces per wave per slab
+  constexpr int SLAB_BYTES = UPW * PH_WAVES * 1024;                 // == packed slab stride
+  static_assert(UPW <= 12, "slab too large");
+  char* sW = smem;                                                   // [NSTAGE][SLAB_BYTES]
+  float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES); // [nh * D]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.D, N = p.N;
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
   int pi, pj;
   pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
   const int nslab = p.num_heads * D / 32;
-  const int my_units = (NU - wave + PH_WAVES - 1) / PH_WAVES;   // DMA units this wave issues per slab (wave-uniform)
+  const unsigned long long t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
 
   for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
 
@@ -410,63 +436,112 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
     xf[ks] = pack_frag8<T>(a);
+    if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep few gathers in flight (else the raw loads spill)
   }
-  // every ordinary global load above has been consumed (its results are in xf): the vm counter now only sees DMA
+  // every ordinary global load above has been consumed: from here on the vm counter only sees our DMA pieces
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                          // sB1 visible
 
-  const char* wg = reinterpret_cast<const char*>(p.wp);
-  const int64_t gstride = slab_stride_bytes(D, (int)sizeof(T));
-#define PH_DMA(slab_, buf_)                                                                                   \
-  _Pragma("unroll") for (int u_ = 0; u_ < UPW; ++u_) {                                                        \
-    const int unit_ = wave + PH_WAVES * u_;                                                                   \
-    if (unit_ < NU)                                                                                           \
-      __builtin_amdgcn_global_load_lds(                                                                       \
-          (const __attribute__((address_space(1))) void*)(wg + (int64_t)(slab_) * gstride + unit_ * 1024 + lane * 16), \
-          (__attribute__((address_space(3))) void*)(sW + (buf_) * SLAB_BYTES + unit_ * 1024), 16, 0, 0);      \
-  }
+  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
+  const uint32_t wdst = lds_addr(sW) + wave * (UPW * 1024);
+  char* wdst_p = sW + wave * (UPW * 1024);
+  auto dma = [&](int slab_, int buf_) {
+    if constexpr (ASM_DMA) {
+      lds_dma_units<0, UPW>(wsrc + (int64_t)slab_ * SLAB_BYTES, wdst + buf_ * SLAB_BYTES);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UPW; ++u)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wsrc + (int64_t)slab_ * SLAB_BYTES + u * 1024),
+            (__attribute__((address_space(3))) void*)(wdst_p + buf_ * SLAB_BYTES + u * 1024), 16, 0, 0);
+    }
+  };
+  const unsigned long long t1 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   // prologue: NSTAGE-1 slabs in flight
 #pragma unroll
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-    if (s0 < nslab) { PH_DMA(s0, s0) }
+    if (s0 < nslab) dma(s0, s0);
 
-  f32x16_t lg;  // logits^T[class, pair]
+  f32x16_t lg, zp;   // logits^T[class, pair]; first-layer accumulator of the previous slab
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lg[r] = 0.f;
-
-  for (int slab = 0; slab < nslab; ++slab) {
-    // slabs slab .. slab+NSTAGE-2 are in flight (fewer near the end); leave all but the oldest outstanding
-    const int later = min(NSTAGE - 2, nslab - 1 - slab);
-    wait_vmcnt(later * my_units);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (slab + NSTAGE - 1 < nslab) { PH_DMA(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE) }
-    const char* wb = sW + (slab % NSTAGE) * SLAB_BYTES;
-    f32x16_t z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
-      mma_step(wf, xf[ks], z);
-    }
-    Frag<T> w2f0 = load_frag_linear<T>(wb, KS, lane);
-    Frag<T> w2f1 = load_frag_linear<T>(wb, KS + 1, lane);
+  for (int r = 0; r < 16; ++r) { lg[r] = 0.f; zp[r] = 0.f; }
+  Frag<T> w2p0, w2p1;  // second-layer fragments of the previous slab (zero for the dummy slab -1)
+  {
+    float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    w2p0 = pack_frag8<T>(zero); w2p1 = w2p0;
+  }
+  auto second_layer = [&](const f32x16_t& zz, int bias_slab, const Frag<T>& wa_, const Frag<T>& wb_) {
     float y[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {   // accumulator rows 8g + 4*half + 0..3 -> one 16-byte bias read
-      const float4 bv = *reinterpret_cast<const float4*>(sB1 + slab * 32 + 8 * g + 4 * half);
-      y[4 * g + 0] = silu_f(z[4 * g + 0] + bv.x);
-      y[4 * g + 1] = silu_f(z[4 * g + 1] + bv.y);
-      y[4 * g + 2] = silu_f(z[4 * g + 2] + bv.z);
-      y[4 * g + 3] = silu_f(z[4 * g + 3] + bv.w);
+      if constexpr (NO_EPI) {
+        y[4 * g + 0] = zz[4 * g + 0]; y[4 * g + 1] = zz[4 * g + 1]; y[4 * g + 2] = zz[4 * g + 2]; y[4 * g + 3] = zz[4 * g + 3];
+      } else {
+        const float4 bv = *reinterpret_cast<const float4*>(sB1 + bias_slab * 32 + 8 * g + 4 * half);
+        y[4 * g + 0] = silu_f(zz[4 * g + 0] + bv.x);
+        y[4 * g + 1] = silu_f(zz[4 * g + 1] + bv.y);
+        y[4 * g + 2] = silu_f(zz[4 * g + 2] + bv.z);
+        y[4 * g + 3] = silu_f(zz[4 * g + 3] + bv.w);
+      }
     }
     Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
-    mma_step(w2f0, y0, lg);
-    mma_step(w2f1, y1, lg);
-  }
-#undef PH_DMA
+    mma_step(wa_, y0, lg);
+    mma_step(wb_, y1, lg);
+  };
+  Frag<T> fixed = load_frag_linear<T>(sW, 0, lane);
 
+  for (int slab = 0; slab < nslab; ++slab) {
+    if constexpr (NOSTREAM) {
+    } else if constexpr (ASM_DMA) {
+      // slabs slab .. slab+NSTAGE-2 are in flight (only `slab` itself at the very end): wait for the oldest one
+      if (NSTAGE > 2 && slab + 1 < nslab) wait_vm<(NSTAGE - 2) * UPW>(); else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      __syncthreads();   // hipcc places s_waitcnt vmcnt(0) in front of it while a DMA it knows of is in flight
+    }
+    if (!NOSTREAM && slab + NSTAGE - 1 < nslab) dma(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE);
+    const char* wb = sW + (slab % NSTAGE) * SLAB_BYTES;
+    if constexpr (PIPE_EPI) second_layer(zp, slab > 0 ? slab - 1 : 0, w2p0, w2p1);
+    f32x16_t z, z2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { z[r] = 0.f; z2[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag<T> wf = NO_LDS ? fixed : load_frag_linear<T>(wb, ks, lane);
+      if (DUAL && (ks & 1)) mma_step(wf, xf[ks], z2); else mma_step(wf, xf[ks], z);
+    }
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] += z2[r];
+    }
+    if constexpr (SGB) {
+      // ask the scheduler for a fixed interleave inside this block: the VALU of the pipelined epilogue (and the LDS
+      // reads) are spread between the MFMAs instead of being issued as one burst while the matrix pipe idles
+#pragma unroll
+      for (int i = 0; i < KS + 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // up to 7 VALU
+      }
+    }
+    if constexpr (PIPE_EPI) {
+      w2p0 = load_frag_linear<T>(wb, KS, lane);
+      w2p1 = load_frag_linear<T>(wb, KS + 1, lane);
+      zp = z;
+    } else {
+      Frag<T> w2a = load_frag_linear<T>(wb, KS, lane), w2b = load_frag_linear<T>(wb, KS + 1, lane);
+      second_layer(z, slab, w2a, w2b);
+    }
+  }
+  if constexpr (PIPE_EPI) second_layer(zp, nslab - 1, w2p0, w2p1);
+  if constexpr (!ASM_DMA) __syncthreads();
+  const unsigned long long t2 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
+  if (p.dbg && tid == 0) {
+    unsigned long long* d = p.dbg + ((int64_t)b * gridDim.x + blockIdx.x) * 4;
+    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = __builtin_amdgcn_s_memtime();
+  }
 }
 
 // ================================================================================================
@@ -732,27 +807,56 @@ static int launch_pair_fwd_pipe(const PairFwdParams& p, hipStream_t st) {
   return check_launch("peneo_pair_heads_fwd");
 }
 
-template <typename T, int KS>
-static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
-  if constexpr (sizeof(T) == 2 && KS % 4 == 0) {
-    if (getenv("PENEO_PAIR_PIPE")) return launch_pair_fwd_pipe<KS>(p, st);  // hand-pipelined variant: opt-in (measured slower so far)
-  }
+template <typename T, int KS, int VARIANT>
+static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
   constexpr int NSTAGE = sizeof(T) == 2 ? 3 : 2;
-  constexpr size_t slab = (size_t)(KS + 2) * 64 * FragBytes<T>::v;
-  static_assert(slab % 1024 == 0, "slab must be a whole number of 1 KiB DMA units");
+  const size_t slab = (size_t)slab_stride_bytes(KS * 16, (int)sizeof(T));
   size_t sh = NSTAGE * slab + (size_t)p.num_heads * p.D * sizeof(float);
   if (sh < (size_t)PH_WAVES * 32 * sizeof(float)) sh = (size_t)PH_WAVES * 32 * sizeof(float);
   if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (sh > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS, NSTAGE, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
       set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
       return PENEO_ERR_LAUNCH;
     }
   }
   dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
-  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS, NSTAGE>), grid, dim3(PH_WAVES * 64), sh, st, p);
+  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS, NSTAGE, VARIANT>), grid, dim3(PH_WAVES * 64), sh, st, p);
   return check_launch("peneo_pair_heads_fwd");
 }
+
+constexpr int PH_DEFAULT_VARIANT = 0;
+template <typename T, int KS>
+static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
+  const char* ev = getenv("PENEO_PAIR_VARIANT");
+  if constexpr (sizeof(T) == 2 && KS == 24) {   // the headline shape carries the A/B variants
+    if (getenv("PENEO_PAIR_PIPE")) return launch_pair_fwd_pipe<KS>(p, st);
+    switch (ev ? atoi(ev) : PH_DEFAULT_VARIANT) {
+      case 0: return launch_pair_fwd_v<T, KS, 0>(p, st);
+      case 1: return launch_pair_fwd_v<T, KS, 1>(p, st);
+      case 2: return launch_pair_fwd_v<T, KS, 2>(p, st);
+      case 3: return launch_pair_fwd_v<T, KS, 3>(p, st);
+      case 4: return launch_pair_fwd_v<T, KS, 4>(p, st);
+      case 5: return launch_pair_fwd_v<T, KS, 5>(p, st);
+      case 6: return launch_pair_fwd_v<T, KS, 6>(p, st);
+      case 7: return launch_pair_fwd_v<T, KS, 7>(p, st);
+      case 8: return launch_pair_fwd_v<T, KS, 8>(p, st);
+      case 12: return launch_pair_fwd_v<T, KS, 12>(p, st);
+      case 14: return launch_pair_fwd_v<T, KS, 14>(p, st);
+      case 18: return launch_pair_fwd_v<T, KS, 18>(p, st);
+      case 19: return launch_pair_fwd_v<T, KS, 19>(p, st);
+      case 22: return launch_pair_fwd_v<T, KS, 22>(p, st);
+      case 23: return launch_pair_fwd_v<T, KS, 23>(p, st);
+      case 40: return launch_pair_fwd_v<T, KS, 40>(p, st);    // no stream, no epilogue
+      case 72: return launch_pair_fwd_v<T, KS, 72>(p, st);    // no stream, no LDS reads
+      case 104: return launch_pair_fwd_v<T, KS, 104>(p, st);  // no stream, no epilogue, no LDS reads: MFMA only
+      case 108: return launch_pair_fwd_v<T, KS, 108>(p, st);   // ... with dual chains
+      default: return launch_pair_fwd_v<T, KS, 108>(p, st);
+    }
+  }
+  return launch_pair_fwd_v<T, KS, PH_DEFAULT_VARIANT>(p, st);
+}
+
 template <typename T>
 static int dispatch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
   switch (p.D / 16) {
@@ -810,6 +914,7 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
   PENEO_REQUIRE((reinterpret_cast<uintptr_t>(desc->w_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(ab) & 15) == 0,
                 "peneo_pair_heads_fwd: ab / packed weights must be 16-byte aligned");
   PairFwdParams p = {};
+  if (const char* dv = getenv("PENEO_PAIR_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(dv, nullptr, 0));
   p.ab = ab; p.B = B; p.N = N; p.D = desc->D; p.P = (int64_t)N * (N + 1) / 2; p.num_heads = desc->num_heads;
   p.total_classes = total_classes(desc->classes, desc->num_heads);
   PENEO_REQUIRE(p.total_classes <= NCP, "peneo_pair_heads_fwd: more than %d classes in total", NCP);
