@@ -92,6 +92,14 @@ int peneo_copy2d(int dtype, const void* src, int64_t ld_src, void* dst, int64_t 
 int peneo_copy_rows(int dtype, const void* src, int64_t src_rpb, int64_t src_bstride, int64_t ld_src,
                     void* dst, int64_t dst_rpb, int64_t dst_bstride, int64_t ld_dst, int64_t rows, int64_t cols,
                     float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+/* LiLT (modeling_lilt.py:269-429) sums text and layout attention scores (BiACM).  With per-head concatenation
+ *   out[r, h*(da+db) + c] = c < da ? scale_a * a[r, h*da + c] : scale_b * b[r, h*db + (c - da)]
+ * of q (pre-scaled by 1/sqrt(d), 1/sqrt(d_l)), k and v, one attention call over head dim da+db yields both
+ * context streams; peneo_head_split is the inverse (used for the context and for dq/dk/dv). */
+int peneo_head_concat(int dtype, const void* a, int64_t lda, int da, float scale_a, const void* b, int64_t ldb, int db,
+                      float scale_b, void* out, int64_t ldo, int64_t rows, int nh, peneo_stream_t stream);
+int peneo_head_split(int dtype, const void* in, int64_t ldi, void* a, int64_t lda, int da, float scale_a, void* b,
+                     int64_t ldb, int db, float scale_b, int64_t rows, int nh, peneo_stream_t stream);
 /* out[n] (+)= sum_m x[m, n]   (bias gradients) */
 int peneo_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,
                  peneo_stream_t stream);

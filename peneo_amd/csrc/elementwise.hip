@@ -64,6 +64,33 @@ __global__ void copy_rows_kernel(int dt, const void* src, int64_t s_rpb, int64_t
   }
 }
 
+// per-head concat / split of two [rows, nh*d] matrices (LiLT's BiACM: one attention call over [text | layout] heads)
+__global__ void head_concat_kernel(int dt, const void* a, int64_t lda, int da, float sa, const void* b, int64_t ldb, int db,
+                                   float sb, void* out, int64_t ldo, int64_t rows, int nh) {
+  const int dc = da + db;
+  const int64_t total = rows * nh * dc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dc);
+    const int h = (int)((i / dc) % nh);
+    const int64_t r = i / ((int64_t)dc * nh);
+    const float v = c < da ? ld_any(a, dt, r * lda + h * da + c) * sa : ld_any(b, dt, r * ldb + h * db + (c - da)) * sb;
+    st_any(out, dt, r * ldo + h * dc + c, v);
+  }
+}
+__global__ void head_split_kernel(int dt, const void* in, int64_t ldi, void* a, int64_t lda, int da, float sa, void* b,
+                                  int64_t ldb, int db, float sb, int64_t rows, int nh) {
+  const int dc = da + db;
+  const int64_t total = rows * nh * dc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dc);
+    const int h = (int)((i / dc) % nh);
+    const int64_t r = i / ((int64_t)dc * nh);
+    const float v = ld_any(in, dt, r * ldi + h * dc + c);
+    if (c < da) st_any(a, dt, r * lda + h * da + c, v * sa);
+    else st_any(b, dt, r * ldb + h * db + (c - da), v * sb);
+  }
+}
+
 // block = 64 columns x 4 row lanes; each block reduces ROWS_PER_BLOCK rows and adds into out.
 constexpr int CS_ROWS = 512;
 __global__ __launch_bounds__(256) void colsum_kernel(int dt, const void* x, int64_t ldx, int64_t M, int64_t N, float* out) {
@@ -123,6 +150,28 @@ extern "C" int peneo_copy_rows(int dtype, const void* src, int64_t src_rpb, int6
   hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dtype, src, src_rpb,
                      src_bstride, ld_src, dst, dst_rpb, dst_bstride, ld_dst, rows, cols, drop_p, drop_seed);
   return check_launch("peneo_copy_rows");
+}
+
+extern "C" int peneo_head_concat(int dtype, const void* a, int64_t lda, int da, float scale_a, const void* b, int64_t ldb, int db,
+                                 float scale_b, void* out, int64_t ldo, int64_t rows, int nh, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && a && b && out && rows > 0 && nh > 0 && da > 0 && db > 0, "peneo_head_concat: bad arguments");
+  PENEO_REQUIRE(lda >= (int64_t)nh * da && ldb >= (int64_t)nh * db && ldo >= (int64_t)nh * (da + db), "peneo_head_concat: leading dims too small");
+  int64_t blocks = (rows * nh * (da + db) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(head_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dtype, a, lda, da, scale_a, b,
+                     ldb, db, scale_b, out, ldo, rows, nh);
+  return check_launch("peneo_head_concat");
+}
+
+extern "C" int peneo_head_split(int dtype, const void* in, int64_t ldi, void* a, int64_t lda, int da, float scale_a, void* b,
+                                int64_t ldb, int db, float scale_b, int64_t rows, int nh, peneo_stream_t stream) {
+  PENEO_REQUIRE(ok_dt(dtype) && a && b && in && rows > 0 && nh > 0 && da > 0 && db > 0, "peneo_head_split: bad arguments");
+  PENEO_REQUIRE(lda >= (int64_t)nh * da && ldb >= (int64_t)nh * db && ldi >= (int64_t)nh * (da + db), "peneo_head_split: leading dims too small");
+  int64_t blocks = (rows * nh * (da + db) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(head_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dtype, in, ldi, a, lda, da,
+                     scale_a, b, ldb, db, scale_b, rows, nh);
+  return check_launch("peneo_head_split");
 }
 
 extern "C" int peneo_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,

@@ -68,6 +68,8 @@ SIGNATURES = {
     "peneo_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     "peneo_copy2d": (_i, [_i, _vp, _i64, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
     "peneo_copy_rows": (_i, [_i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f, _u32, _vp]),
+    "peneo_head_concat": (_i, [_i, _vp, _i64, _i, _f, _vp, _i64, _i, _f, _vp, _i64, _i64, _i, _vp]),
+    "peneo_head_split": (_i, [_i, _vp, _i64, _vp, _i64, _i, _f, _vp, _i64, _i, _f, _i64, _i, _vp]),
     "peneo_colsum": (_i, [_i, _vp, _i64, _i64, _i64, _vp, _i, _vp]),
     "peneo_layernorm_fwd": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _i64, _i, _f, _u32, _vp]),
     "peneo_layernorm_bwd": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64,

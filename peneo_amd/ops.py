@@ -151,6 +151,23 @@ def copy_rows(src: torch.Tensor, dst: torch.Tensor, drop_p: float = 0.0, drop_se
     return dst
 
 
+def head_concat(a: torch.Tensor, b: torch.Tensor, nh: int, out: torch.Tensor, scale_a: float = 1.0, scale_b: float = 1.0):
+    """out[r, h*(da+db) + c] = [scale_a * a_h | scale_b * b_h]; a, b, out are 2-D views with unit column stride."""
+    da, db = a.shape[1] // nh, b.shape[1] // nh
+    assert out.shape[1] == nh * (da + db) and a.shape[0] == b.shape[0] == out.shape[0]
+    check(lib().peneo_head_concat(dtype_code(a.dtype), ptr(a), a.stride(0), da, scale_a, ptr(b), b.stride(0), db, scale_b,
+                                  ptr(out), out.stride(0), a.shape[0], nh, stream()), "peneo_head_concat")
+    return out
+
+
+def head_split(x: torch.Tensor, nh: int, a: torch.Tensor, b: torch.Tensor, scale_a: float = 1.0, scale_b: float = 1.0):
+    da, db = a.shape[1] // nh, b.shape[1] // nh
+    assert x.shape[1] == nh * (da + db) and a.shape[0] == b.shape[0] == x.shape[0]
+    check(lib().peneo_head_split(dtype_code(x.dtype), ptr(x), x.stride(0), ptr(a), a.stride(0), da, scale_a, ptr(b),
+                                 b.stride(0), db, scale_b, x.shape[0], nh, stream()), "peneo_head_split")
+    return a, b
+
+
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     assert x.dim() == 2 and x.stride(1) == 1
     if out is None:

@@ -47,8 +47,9 @@ def lilt_config(size: str = "tiny") -> dict:
         is_decoder=False, add_cross_attention=False, chunk_size_feed_forward=0,
     )
     if size == "tiny":
-        common.update(vocab_size=1000, hidden_size=96, num_hidden_layers=2, num_attention_heads=4,
-                      intermediate_size=192, max_position_embeddings=66)
+        # H/2 = 96 (decoder width, multiple of 32 for the MFMA pair heads); d = 48, d_layout = 12
+        common.update(vocab_size=1000, hidden_size=192, num_hidden_layers=2, num_attention_heads=4,
+                      intermediate_size=384, max_position_embeddings=66)
     elif size == "base":
         common.update(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                       intermediate_size=3072, max_position_embeddings=514)

@@ -359,6 +359,26 @@ def test_head_transpose(ops):
     assert float(xt[:, :, d:].abs().max()) == 0 and float(xt[..., T:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_concat_split(ops, dtype):
+    """LiLT's [text | layout] per-head packing and its inverse, on strided slices of fused buffers."""
+    R, nh, da, db = 77, 4, 48, 12
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(R, 3 * nh * da, generator=g).to(DEV).to(dtype)
+    b = torch.randn(R, 3 * nh * db, generator=g).to(DEV).to(dtype)
+    out = torch.zeros(R, 2 * nh * (da + db), device=DEV, dtype=dtype)
+    av, bv = a[:, nh * da:2 * nh * da], b[:, nh * db:2 * nh * db]
+    ops.head_concat(av, bv, nh, out[:, nh * (da + db):], 0.5, 2.0)
+    ref = torch.cat([0.5 * av.float().view(R, nh, da), 2.0 * bv.float().view(R, nh, db)], dim=2).reshape(R, -1)
+    assert torch.equal(out[:, nh * (da + db):].float(), ref.to(dtype).float())
+    assert float(out[:, :nh * (da + db)].abs().max()) == 0
+    a2 = torch.zeros(R, nh * da + 8, device=DEV, dtype=dtype)
+    b2 = torch.zeros(R, nh * db, device=DEV, dtype=dtype)
+    ops.head_split(out[:, nh * (da + db):], nh, a2[:, :nh * da], b2, 2.0, 0.5)
+    assert torch.equal(a2[:, :nh * da], av) and torch.equal(b2, bv)
+    assert float(a2[:, nh * da:].abs().max()) == 0
+
+
 # ---------------------------------------------------------------------------------------------- pair heads
 def _pair_ref(ab, w1, b1, w2, b2):
     B, N, D2 = ab.shape

@@ -26,7 +26,7 @@ def maxdiff(a, b):
     return float((a.float().cpu() - b.float().cpu()).abs().max())
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny"])
 def test_fp32_forward_matches_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"]).eval()
@@ -44,7 +44,7 @@ def test_fp32_forward_matches_reference(name):
     assert torch.equal(out["orig_bbox"].cpu(), ref["orig_bbox"])
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny"])
 def test_fp32_gradients_match_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"]).eval()   # eval: dropout off, like the fixture
@@ -62,7 +62,7 @@ def test_fp32_gradients_match_reference(name):
     assert checked == len(fx["grads"])
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
 def test_bf16_forward_close_to_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()
