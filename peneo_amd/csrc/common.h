@@ -156,6 +156,21 @@ template <> __device__ __forceinline__ Frag<float> pack_frag8<float>(const float
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
 
+// ---------------------------------------------------------------- LDS-DMA (global -> LDS without VGPRs)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// One 1 KiB piece (global_load_lds_dwordx4: 64 lanes x 16 B; LDS destination = M0 base + OFF + lane*16, global source =
+// the lane's own pointer + OFF).  Issued from inline asm on purpose: hipcc drains the whole vm counter in front of every
+// ds_read while an LDS-DMA *it knows about* is in flight.  The caller orders it: counted s_waitcnt vmcnt + barrier.
+template <int OFF>
+__device__ __forceinline__ void lds_dma_1k(const char* gsrc_lane, uint32_t lds_base_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_base_uniform), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
 // ---------------------------------------------------------------- packed upper-triangular pair index
 // p(i, j) = i*n - i(i-1)/2 + (j - i),  0 <= i <= j < n   (reference: model/peneo_decoder.py:129-147)
 __device__ __host__ __forceinline__ int64_t pair_row_start(int64_t i, int64_t n) { return i * n - i * (i - 1) / 2; }

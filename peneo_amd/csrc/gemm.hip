@@ -5,6 +5,7 @@
 // (mn-major tiles are transposed in registers on their way to LDS), which gives forward
 // (x W^T), dgrad (dy W) and wgrad (dy^T x) from one template.  bf16 -> v_mfma_f32_32x32x16_bf16,
 // fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32; the parity mode).
+#include <cstdlib>
 #include "common.h"
 
 namespace peneo {
@@ -224,6 +225,51 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
   store8_any(p.C, p.c_dtype, ci, v);
 }
 
+// epilogue: park the accumulators in LDS (the staging buffers are dead now), then walk the tile
+// row-major so that consecutive lanes own consecutive columns (coalesced C / residual traffic)
+// and the fused epilogue stays a compact rolled loop.
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&acc)[2][2], char* smem, int m0, int n0, int tid,
+                                              int lane, int wm, int wn) {
+  float* sC = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sC[(wm * 64 + i * 32 + acc_row(r, lane)) * GB + wn * 64 + j * 32 + acc_col(lane)] = acc[i][j][r];
+  __syncthreads();
+  const int mrem = min(GB, p.M - m0), nrem = min(GB, p.N - n0);
+  // vector path: 8 columns per thread per step (16 threads per row), when every row segment is 16-byte aligned
+  const peneo_gemm_epilogue& e = p.ep;
+  const int csz = p.c_dtype == PENEO_F32 ? 4 : 2;
+  auto al = [&](const void* ptr, int64_t ld, int esz) {
+    return ptr == nullptr || (((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && ((ld * esz) % 16 == 0));
+  };
+  const bool vec_ok = p.split_k <= 1 && nrem == GB && al(p.C, p.ldc, csz) && al(e.preact, e.ld_preact, csz) &&
+                      al(e.grad_src, e.ld_grad, csz) && al(e.residual, e.ld_res, csz) && al(e.bias, 0, 4);
+  if (vec_ok) {
+    for (int idx = tid; idx < GB * (GB / 8); idx += 256) {
+      const int r = idx >> 4, c = (idx & 15) * 8;
+      if (r < mrem) {
+        float v[8];
+        const uint4* q = reinterpret_cast<const uint4*>(sC + r * GB + c);
+        unpack16<float>(q[0], v); unpack16<float>(q[1], v + 4);
+        epilogue_store8(p, m0 + r, n0 + c, v);
+      }
+    }
+  } else {
+    for (int idx = tid; idx < GB * GB; idx += 256) {
+      const int r = idx >> 7, c = idx & (GB - 1);
+      if (r < mrem && c < nrem) {
+        const float v = sC[idx];
+        if (p.split_k > 1) p.ws[((int64_t)blockIdx.z * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
+        else epilogue_store(p, m0 + r, n0 + c, v);
+      }
+    }
+  }
+}
+
 template <typename T, bool AK, bool BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,47 +343,181 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // epilogue: park the accumulators in LDS (the staging buffers are dead now), then walk the tile
-  // row-major so that consecutive lanes own consecutive columns (coalesced C / residual traffic)
-  // and the fused epilogue stays a compact rolled loop.
-  float* sC = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn);
+}
+
+// ================================================================================================
+// bf16 fast path: operand tiles go global -> LDS by LDS-DMA (no VGPR staging, no ds_write pass), two
+// 32 KiB stages (2 workgroups per CU), one barrier per k-tile.
+//   k-major operand  [rows][K]: LDS image = the register-staged kernel's (row pitch 128 B, 16-byte slot s of row r at
+//                     slot s ^ ((r >> 1) & 7)); the swizzle is applied to the SOURCE address of each DMA lane, the
+//                     destination is lane-linear (1 KiB piece = 8 rows).  Fragments by ds_read_b128.
+//   mn-major operand [K][rows]: 1 KiB pieces of [8 k][64 rows] (full 128-byte lines from memory), the two 64-byte
+//                     halves of a line swapped when (k >> 1) & 1; fragments by the hardware transpose read
+//                     ds_read_b64_tr_b16 (each 16-lane group reads a [4 k][16 rows] block, conflict-free with that swap).
+// Requirements (checked by the launcher, else the register-staged kernel runs): 16-byte aligned bases and row strides,
+// extents along the contiguous dimension multiples of 8.  Ragged M/N edges read clamped rows (results discarded),
+// the k tail reads a zero line.
+// ================================================================================================
+__device__ __attribute__((aligned(16))) uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+struct DmaSrc { const char* p[4]; };
+
+// source pointers of this wave's 4 pieces of a k-major tile at k-tile `kt` (guard: zero-fill chunks beyond K)
+__device__ __forceinline__ void dma_src_kmajor(DmaSrc& s, const bf16_t* X, int64_t ld, int r0, int rmax, int K, int kt,
+                                               int wave, int lane, bool guard) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 8 + (lane >> 3);
+    const int sg = (lane & 7) ^ ((row >> 1) & 7);
+    const int k = kt * 64 + sg * 8;
+    const int r = min(r0 + row, rmax - 1);
+    const char* q = reinterpret_cast<const char*>(X + (int64_t)r * ld + k);
+    if (guard && k >= K) q = reinterpret_cast<const char*>(g_zero_line);
+    s.p[j] = q;
+  }
+}
+__device__ __forceinline__ void dma_src_mnmajor(DmaSrc& s, const bf16_t* X, int64_t ld, int r0, int rmax, int K, int kt,
+                                                int wave, int lane, bool guard) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pc = wave * 4 + j;
+    const int kr = lane >> 3;
+    const int k = kt * 64 + (pc >> 1) * 8 + kr;
+    const int cg = (lane & 7) ^ (((kr >> 1) & 1) << 2);
+    const int col = min(r0 + (pc & 1) * 64 + cg * 8, rmax - 8);
+    const char* q = reinterpret_cast<const char*>(X + (int64_t)k * ld + col);
+    if (guard && k >= K) q = reinterpret_cast<const char*>(g_zero_line);
+    s.p[j] = q;
+  }
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 2 * TILE_BYTES;            // A tile + B tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous band of tiles
+  // (n fastest) so that its L2 sees one slice of A and streams B, instead of every L2 seeing everything.
+  const int gx = gridDim.x, total = gx * gridDim.y;
+  const int lin = blockIdx.y * gx + blockIdx.x;
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
+  const int tile = xcd * q8 + min(xcd, r8) + slot;
+  const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  const int ktiles = (p.K + 63) / 64;
+  int kt_begin = 0, kt_end = ktiles;
+  if (p.split_k > 1) {
+    kt_begin = blockIdx.z * p.kt_per_split;
+    kt_end = min(ktiles, kt_begin + p.kt_per_split);
+  }
+  const bool ragged_k = (p.K & 63) != 0;
+
+  f32x16_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[(wm * 64 + i * 32 + acc_row(r, lane)) * GB + wn * 64 + j * 32 + acc_col(lane)] = acc[i][j][r];
-  __syncthreads();
-  const int mrem = min(GB, p.M - m0), nrem = min(GB, p.N - n0);
-  // vector path: 8 columns per thread per step (16 threads per row), when every row segment is 16-byte aligned
-  const peneo_gemm_epilogue& e = p.ep;
-  const int csz = p.c_dtype == PENEO_F32 ? 4 : 2;
-  auto al = [&](const void* ptr, int64_t ld, int esz) {
-    return ptr == nullptr || (((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && ((ld * esz) % 16 == 0));
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lbase = lds_addr(smem) + wave * 4096;   // this wave's 4 pieces inside a 16 KiB tile
+  const int64_t stepA = AK ? 128 : (int64_t)64 * p.lda * 2, stepB = BK ? 128 : (int64_t)64 * p.ldb * 2;
+  DmaSrc sa, sb;
+  auto sources = [&](int kt) {
+    const bool guard = ragged_k && kt == ktiles - 1;
+    if (AK) dma_src_kmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
+    else dma_src_mnmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
+    if (BK) dma_src_kmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
+    else dma_src_mnmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
   };
-  const bool vec_ok = p.split_k <= 1 && nrem == GB && al(p.C, p.ldc, csz) && al(e.preact, e.ld_preact, csz) &&
-                      al(e.grad_src, e.ld_grad, csz) && al(e.residual, e.ld_res, csz) && al(e.bias, 0, 4);
-  if (vec_ok) {
-    for (int idx = tid; idx < GB * (GB / 8); idx += 256) {
-      const int r = idx >> 4, c = (idx & 15) * 8;
-      if (r < mrem) {
-        float v[8];
-        const uint4* q = reinterpret_cast<const uint4*>(sC + r * GB + c);
-        unpack16<float>(q[0], v); unpack16<float>(q[1], v + 4);
-        epilogue_store8(p, m0 + r, n0 + c, v);
-      }
+  auto issue = [&](int buf) {
+    const uint32_t d = lbase + buf * STAGE;
+    lds_dma_1k<0>(sa.p[0], d);
+    lds_dma_1k<0>(sa.p[1], d + 1024);
+    lds_dma_1k<0>(sa.p[2], d + 2048);
+    lds_dma_1k<0>(sa.p[3], d + 3072);
+    lds_dma_1k<0>(sb.p[0], d + TILE_BYTES);
+    lds_dma_1k<0>(sb.p[1], d + TILE_BYTES + 1024);
+    lds_dma_1k<0>(sb.p[2], d + TILE_BYTES + 2048);
+    lds_dma_1k<0>(sb.p[3], d + TILE_BYTES + 3072);
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sa.p[j] += stepA; sb.p[j] += stepB; }
+  };
+
+  // per-lane fragment addresses (constant over the k loop)
+  //   k-major: row*128 + ((2ks + (lane >> 5)) ^ ((row >> 1) & 7)) * 16
+  //   mn-major: piece (kblock = 2ks + (lane >> 5), nhalf) * 1024 + kr * 128 + ((n & 63) * 2 ^ swap), kr = 4 sub + ((lane & 15) >> 2)
+  int fa_off[2], fb_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (AK) fa_off[i] = (wm * 64 + i * 32 + (lane & 31)) * ROWB;
+    else {
+      const int n = wm * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+      fa_off[i] = ((lane >> 5) * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
     }
-  } else {
-    for (int idx = tid; idx < GB * GB; idx += 256) {
-      const int r = idx >> 7, c = idx & (GB - 1);
-      if (r < mrem && c < nrem) {
-        const float v = sC[idx];
-        if (p.split_k > 1) p.ws[((int64_t)blockIdx.z * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
-        else epilogue_store(p, m0 + r, n0 + c, v);
-      }
+    if (BK) fb_off[i] = (wn * 64 + i * 32 + (lane & 31)) * ROWB;
+    else {
+      const int n = wn * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+      fb_off[i] = ((lane >> 5) * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
     }
   }
+  const int swzA = ((wm * 64 + (lane & 31)) >> 1) & 7;   // rows i*32 apart share (row >> 1) & 7
+  const int swzB = ((wn * 64 + (lane & 31)) >> 1) & 7;
+  auto frag = [&](const char* tile, bool kmajor, int off, int swz, int ks) -> Frag<bf16_t> {
+    Frag<bf16_t> f;
+    if (kmajor) {
+      f.v = *reinterpret_cast<const uint4*>(tile + off + (((2 * ks + (lane >> 5)) ^ swz) << 4));
+    } else {
+      typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
+      const char* q = tile + off + ks * 4096;
+      s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q));
+      s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q + 512));
+      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    }
+    return f;
+  };
+
+  if (kt_begin < kt_end) {
+    sources(kt_begin);
+    issue(0);
+  }
+  wait_vm<0>();
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) {
+      if (ragged_k && kt + 1 == ktiles - 1) sources(kt + 1); else advance();
+      issue(buf ^ 1);
+    }
+    const char* tA = smem + buf * STAGE;
+    const char* tB = tA + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Frag<bf16_t> fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = frag(tA, AK, fa_off[i], swzA, ks);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = frag(tB, BK, fb_off[j], swzB, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma_step(fa[i], fb[j], acc[i][j]);
+    }
+    wait_vm<0>();
+    __syncthreads();
+  }
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn);
 }
 
 __global__ void splitk_reduce_kernel(GemmParams p) {
@@ -356,6 +536,15 @@ static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStre
   else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), shmem, st, p);
   else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(256), shmem, st, p);
   else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), shmem, st, p);
+  return check_launch("peneo_gemm");
+}
+
+static int launch_gemm_dma(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
+  size_t shmem = 4 * TILE_BYTES;
+  if (ak && bk) hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, dim3(256), shmem, st, p);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, dim3(256), shmem, st, p);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_dma_kernel<false, true>), grid, dim3(256), shmem, st, p);
+  else hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, dim3(256), shmem, st, p);
   return check_launch("peneo_gemm");
 }
 
@@ -396,8 +585,17 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
                   "peneo_gemm: split-k workspace too small");
   dim3 grid((N + GB - 1) / GB, (M + GB - 1) / GB, split_k);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int rc = dtype == PENEO_BF16 ? launch_gemm<bf16_t>(p, a_kmajor != 0, b_kmajor != 0, grid, st)
-                               : launch_gemm<float>(p, a_kmajor != 0, b_kmajor != 0, grid, st);
+  // bf16 LDS-DMA path: 16-byte aligned bases / row strides, contiguous extents in whole 16-byte chunks
+  auto dma_ok = [](const void* ptr, int64_t ld, bool kmajor, int rows, int k) {
+    return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (ld % 8) == 0 && ((kmajor ? k : rows) % 8) == 0 && rows >= 8;
+  };
+  static const bool legacy = getenv("PENEO_GEMM_LEGACY") != nullptr;
+  int rc;
+  if (dtype == PENEO_BF16 && !legacy && dma_ok(A, lda, a_kmajor != 0, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K))
+    rc = launch_gemm_dma(p, a_kmajor != 0, b_kmajor != 0, grid, st);
+  else
+    rc = dtype == PENEO_BF16 ? launch_gemm<bf16_t>(p, a_kmajor != 0, b_kmajor != 0, grid, st)
+                             : launch_gemm<float>(p, a_kmajor != 0, b_kmajor != 0, grid, st);
   if (rc != PENEO_OK) return rc;
   if (split_k > 1) {
     int64_t total = (int64_t)M * N;

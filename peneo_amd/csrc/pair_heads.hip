@@ -223,9 +223,6 @@ __device__ __forceinline__ void pair_epilogue(const PairFwdParams& p, const f32x
 
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
 // hand-issued LDS reads: hipcc neither counts them nor (crucially) drains the in-flight LDS-DMA ring in front of them;
 // the reader owns lgkmcnt (s_waitcnt + sched_barrier before the first consumer, guide §5.7 / rule 18)
 #define DS_READ_B128(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
@@ -366,12 +363,6 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_pipe_kernel(P
 // issued from inline asm on purpose: hipcc drains the whole vm counter (s_waitcnt vmcnt(0)) in front of every ds_read
 // while an LDS-DMA *it knows about* is in flight, which would serialise the weight stream with the MFMAs.  Hidden in
 // asm, the DMA is ours to order: counted s_waitcnt vmcnt + s_barrier before the slab is read (cdna guide §5.7).
-template <int OFF>
-__device__ __forceinline__ void lds_dma_1k(const char* gsrc_lane, uint32_t lds_base_uniform) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_base_uniform), "n"(OFF) : "memory");
-}
 template <int U, int UPW>
 __device__ __forceinline__ void lds_dma_units(const char* gsrc_lane, uint32_t lds_base_uniform) {
   if constexpr (U < UPW) {
@@ -379,7 +370,6 @@ __device__ __forceinline__ void lds_dma_units(const char* gsrc_lane, uint32_t ld
     lds_dma_units<U + 1, UPW>(gsrc_lane, lds_base_uniform);
   }
 }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // Generic kernel (bf16 and fp32).  Per workgroup: 8 waves x 32 pairs.  Weight slabs (32 hidden rows: KS first-layer
 // fragments + 2 second-layer fragments, padded to UPW KiB per wave) stream L2 -> LDS through a ring of NSTAGE buffers,

@@ -50,6 +50,28 @@ def test_gemm_layouts(ops, dtype, ak, bk, M, N, K):
     assert rel_err(out, ref) < tol(dtype), (rel_err(out, ref))
 
 
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K,split", [(712, 200, 136, 1), (128, 128, 64, 1), (1000, 264, 200, 1), (256, 384, 1064, 3),
+                                         (8, 8, 8, 1), (136, 520, 72, 1), (768, 768, 5672, 8)])
+def test_gemm_bf16_lds_dma_path(ops, ak, bk, M, N, K, split):
+    """Shapes that qualify for the LDS-DMA kernel (16-byte aligned chunks) with ragged M/N edges, a k tail and
+    split-k; operands are strided views of wider buffers so that leading dims differ from the extents."""
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 5 * K)
+    a = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    b = torch.randn(N, K, generator=g).to(DEV).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+
+    def view(t):   # embed in a wider buffer: ld = cols + 16
+        buf = torch.full((t.shape[0], t.shape[1] + 16), 7.0, device=DEV, dtype=t.dtype)
+        buf[:, :t.shape[1]] = t
+        return buf[:, :t.shape[1]]
+    A = view(a if ak else a.t().contiguous())
+    Bm = view(b if bk else b.t().contiguous())
+    out = ops.gemm(A, Bm, a_kmajor=ak, b_kmajor=bk, out_dtype=torch.float32, split_k=split)
+    # bf16 inputs are exact in fp32 and the output stays fp32: only the accumulation order differs from torch
+    assert rel_err(out, ref) < 1e-5, rel_err(out, ref)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_is_transpose_detecting(ops, dtype):
     # A = identity against an asymmetric B catches swapped C rows/cols
