@@ -1,6 +1,7 @@
 // LayerNorm forward / backward: one 64-lane wave per row, the row held in registers as 16-byte
 // vectors (coalesced 1 KiB per wave-instruction), wavefront shuffles for the mean/variance and for
 // the two backward row-reductions.  fp32 statistics regardless of the storage dtype.
+#include <type_traits>
 #include "common.h"
 
 namespace peneo {
@@ -158,8 +159,199 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, con
   }
 }
 
+// ---- fast path: rows of 32*NV 16-byte vectors; a half-wave (32 lanes) owns a row, so no lane idles at H = 768 and
+// two rows are in flight per wave-instruction; everything is compile-time sized (no predicated register arrays).
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int NV, bool DROP>
+__global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* y, LnMap ym, const float* gamma,
+                                                       const float* beta, float eps, float* mean, float* rstd,
+                                                       int64_t rows, float drop_p, uint32_t seed) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int H = 32 * NV * VEC;
+  const int hl = threadIdx.x & 31;
+  const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+  const float keep_scale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (r >= rows) return;
+  const T* xr = x + ln_row_off(r, xm, H);
+  T* yr = y + ln_row_off(r, ym, H);
+  float v[NV][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    unpack16<T>(*reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC), v[k]);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s += v[k][e];
+  }
+  const float mu = half_sum(s) * (1.0f / (float)H);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { float d = v[k][e] - mu; q += d * d; }
+  const float rs = rsqrtf(half_sum(q) * (1.0f / (float)H) + eps);
+  if (hl == 0) {
+    if (mean) mean[r] = mu;
+    if (rstd) rstd[r] = rs;
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c0 = (hl + 32 * k) * VEC;
+    float gm[VEC], bt[VEC], o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) {
+      *reinterpret_cast<float4*>(gm + e) = *reinterpret_cast<const float4*>(gamma + c0 + e);
+      *reinterpret_cast<float4*>(bt + e) = *reinterpret_cast<const float4*>(beta + c0 + e);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t = (v[k][e] - mu) * rs * gm[e] + bt[e];
+      if (DROP) t = dropout_keep(seed, (uint64_t)r * H + c0 + e, thresh) ? t * keep_scale : 0.f;
+      o[e] = t;
+    }
+    *reinterpret_cast<uint4*>(yr + c0) = pack16<T>(o);
+  }
+}
+
+template <typename T, int NV, bool DROP>
+__global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
+                                                       const float* gamma, const float* mean, const float* rstd,
+                                                       float* dgamma, float* dbeta, int64_t rows, float drop_p,
+                                                       uint32_t seed) {
+  constexpr int VEC = Elem<T>::kVec;
+  constexpr int H = 32 * NV * VEC;
+  const int hl = threadIdx.x & 31;
+  const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+  const float keep_scale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
+  float gm[NV][VEC], ag[NV][VEC], ab[NV][VEC];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      gm[k][e] = gamma[(hl + 32 * k) * VEC + e];
+      ag[k][e] = 0.f; ab[k][e] = 0.f;
+    }
+  for (int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); r < rows; r += (int64_t)gridDim.x * 8) {
+    const T* dyr = dy + ln_row_off(r, dym, H);
+    const T* xr = x + ln_row_off(r, xm, H);
+    T* dxr = dx + ln_row_off(r, dxm, H);
+    uint4 rd[NV], rx[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if constexpr (sizeof(T) == 2) {
+        rd[k] = *reinterpret_cast<const uint4*>(dyr + (hl + 32 * k) * VEC);
+        rx[k] = *reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC);
+      } else {
+        rd[k] = *reinterpret_cast<const uint4*>(dyr + (hl + 32 * k) * VEC);
+        rx[k] = *reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC);
+      }
+    }
+    const float mu = mean[r], rs = rstd[r];
+    float g[NV][VEC], xh[NV][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float d[VEC], xv[VEC];
+      unpack16<T>(rd[k], d);
+      unpack16<T>(rx[k], xv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float dd = d[e];
+        if (DROP) dd = dropout_keep(seed, (uint64_t)r * H + (hl + 32 * k) * VEC + e, thresh) ? dd * keep_scale : 0.f;
+        const float h = (xv[e] - mu) * rs;
+        xh[k][e] = h;
+        ag[k][e] += dd * h;
+        ab[k][e] += dd;
+        const float gg = dd * gm[k][e];
+        g[k][e] = gg;
+        s1 += gg;
+        s2 += gg * h;
+      }
+    }
+    s1 = half_sum(s1) * (1.0f / (float)H);
+    s2 = half_sum(s2) * (1.0f / (float)H);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
+      *reinterpret_cast<uint4*>(dxr + (hl + 32 * k) * VEC) = pack16<T>(o);
+    }
+  }
+  // parameter gradients: 8 half-waves -> LDS -> one atomic per column per block
+  __shared__ float red[2][8][32 * NV * VEC + 1];
+  const int hw = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      red[0][hw][(hl + 32 * k) * VEC + e] = ag[k][e];
+      red[1][hw][(hl + 32 * k) * VEC + e] = ab[k][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+    if (dgamma) atomicAdd(dgamma + c, a);
+    if (dbeta) atomicAdd(dbeta + c, b);
+  }
+}
+
+template <typename T, int NV>
+static void launch_ln_fwd32(hipStream_t st, const void* x, LnMap xm, void* y, LnMap ym, const float* gamma, const float* beta,
+                            float eps, float* mean, float* rstd, int64_t rows, float drop_p, uint32_t seed) {
+  dim3 grid((unsigned)((rows + 7) / 8));
+  if (drop_p > 0.f)
+    hipLaunchKernelGGL((ln_fwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)x, xm, (T*)y, ym, gamma, beta, eps, mean,
+                       rstd, rows, drop_p, seed);
+  else
+    hipLaunchKernelGGL((ln_fwd32_kernel<T, NV, false>), grid, dim3(256), 0, st, (const T*)x, xm, (T*)y, ym, gamma, beta, eps, mean,
+                       rstd, rows, drop_p, seed);
+}
+template <typename T, int NV>
+static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const void* x, LnMap xm, void* dx, LnMap dxm,
+                            const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                            int64_t rows, float drop_p, uint32_t seed) {
+  int64_t blocks = (rows + 7) / 8;
+  if (blocks > 512) blocks = 512;
+  dim3 grid((unsigned)blocks);
+  if (drop_p > 0.f)
+    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed);
+  else
+    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed);
+}
+
+// true when a fast instantiation exists for this row length
+template <typename T, typename F> static bool ln32_dispatch(int H, F&& f) {
+  constexpr int VEC = sizeof(T) == 2 ? 8 : 4;
+  if (H % (32 * VEC)) return false;
+  switch (H / (32 * VEC)) {
+    case 1: f(std::integral_constant<int, 1>{}); return true;
+    case 2: f(std::integral_constant<int, 2>{}); return true;
+    case 3: f(std::integral_constant<int, 3>{}); return true;
+    case 4: f(std::integral_constant<int, 4>{}); return true;
+    case 6: if (sizeof(T) == 4) { f(std::integral_constant<int, 6>{}); return true; } return false;
+    case 8: if (sizeof(T) == 4) { f(std::integral_constant<int, 8>{}); return true; } return false;
+    default: return false;
+  }
+}
+
 }  // namespace peneo
 using namespace peneo;
+
+// 16-byte alignment of a row base: base pointer and (for sliced [B, R, H] maps) the batch stride
+static bool ln_aligned(const void* p, int64_t bstride, int dtype) {
+  const int esz = dtype == PENEO_BF16 ? 2 : 4;
+  return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ((bstride * esz) % 16) == 0;
+}
 
 static int ln_check(const char* who, int dtype, int64_t rows, int H) {
   PENEO_REQUIRE(dtype == PENEO_F32 || dtype == PENEO_BF16, "%s: bad dtype", who);
@@ -186,6 +378,15 @@ extern "C" int peneo_layernorm_fwd(int dtype, const void* x, int64_t x_rpb, int6
   PENEO_REQUIRE(x && y && gamma && beta, "peneo_layernorm_fwd: null pointer");
   PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_layernorm_fwd: drop_p out of range");
   LnMap xm{x_rpb, x_bstride}, ym{y_rpb, y_bstride};
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = ln_aligned(x, x_bstride, dtype) && ln_aligned(y, y_bstride, dtype) && ln_aligned(gamma, 0, PENEO_F32) &&
+                  ln_aligned(beta, 0, PENEO_F32);
+  if (al) {
+    bool done = dtype == PENEO_BF16
+        ? ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_fwd32<bf16_t, decltype(nv)::value>(st, x, xm, y, ym, gamma, beta, eps, mean, rstd, rows, drop_p, drop_seed); })
+        : ln32_dispatch<float>(H, [&](auto nv) { launch_ln_fwd32<float, decltype(nv)::value>(st, x, xm, y, ym, gamma, beta, eps, mean, rstd, rows, drop_p, drop_seed); });
+    if (done) return check_launch("peneo_layernorm_fwd");
+  }
   dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, xm, (bf16_t*)y, ym,
@@ -204,6 +405,14 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
   if (rc) return rc;
   PENEO_REQUIRE(dy && x && dx && gamma && mean && rstd, "peneo_layernorm_bwd: null pointer");
   LnMap dym{dy_rpb, dy_bstride}, xm{x_rpb, x_bstride}, dxm{dx_rpb, dx_bstride};
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_layernorm_bwd: drop_p out of range");
+  if (ln_aligned(dy, dy_bstride, dtype) && ln_aligned(x, x_bstride, dtype) && ln_aligned(dx, dx_bstride, dtype)) {
+    hipStream_t st = (hipStream_t)stream;
+    bool done = dtype == PENEO_BF16
+        ? ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_bwd32<bf16_t, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed); })
+        : ln32_dispatch<float>(H, [&](auto nv) { launch_ln_bwd32<float, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed); });
+    if (done) return check_launch("peneo_layernorm_bwd");
+  }
   dim3 grid(ln_grid(rows, 8));  // <= 256 blocks: each wave reduces several rows; one atomic per column per block
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dym,

@@ -55,16 +55,21 @@ __global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const uint8_t* bk1
   }
 }
 
-// one block per (b, h, 32-row slab): LDS histograms, then one global atomic per bin
+// one block per (b, h, 32-row slab): LDS histograms replicated 32x (slot = bin*32 + lane%32: every lane of a half-wave
+// hits its own bank and its own address, so the LDS atomics neither bank-conflict nor serialise on popular buckets),
+// folded at the end into one global atomic per bin.
+constexpr int RB_REP = 32;
 __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, const uint8_t* bk1, const uint8_t* bkx,
                                                               const uint8_t* bky, float* dw1, int bins1, float* dwx, float* dwy,
                                                               int bins2, float scale, int nh, int Tn, int64_t ldg) {
-  extern __shared__ float hist[];  // [bins1] [bins2] [bins2]
+  extern __shared__ float hist[];  // [bins1 | bins2 | bins2][RB_REP]
   float* h1 = hist;
-  float* hx = h1 + bins1;
-  float* hy = hx + bins2;
-  for (int i = threadIdx.x; i < bins1 + 2 * bins2; i += blockDim.x) hist[i] = 0.f;
+  float* hx = h1 + bins1 * RB_REP;
+  float* hy = hx + bins2 * RB_REP;
+  const int nb = bins1 + 2 * bins2;
+  for (int i = threadIdx.x; i < nb * RB_REP; i += blockDim.x) hist[i] = 0.f;
   __syncthreads();
+  const int rep = threadIdx.x & (RB_REP - 1);
   const int slabs = (Tn + 31) / 32;
   const int slab = blockIdx.x % slabs;
   const int h = (blockIdx.x / slabs) % nh;
@@ -75,15 +80,19 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, co
     const int64_t brow = (b * Tn + i) * (int64_t)Tn;
     for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
       const float v = grow[j];
-      if (bk1) atomicAdd(h1 + bk1[brow + j], v);
-      if (bkx) { atomicAdd(hx + bkx[brow + j], v); atomicAdd(hy + bky[brow + j], v); }
+      if (bk1) atomicAdd(h1 + bk1[brow + j] * RB_REP + rep, v);
+      if (bkx) { atomicAdd(hx + bkx[brow + j] * RB_REP + rep, v); atomicAdd(hy + bky[brow + j] * RB_REP + rep, v); }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < bins1; i += blockDim.x) if (dw1) atomicAdd(dw1 + h * bins1 + i, h1[i] * scale);
-  for (int i = threadIdx.x; i < bins2; i += blockDim.x) {
-    if (dwx) atomicAdd(dwx + h * bins2 + i, hx[i] * scale);
-    if (dwy) atomicAdd(dwy + h * bins2 + i, hy[i] * scale);
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RB_REP; ++r) sum += hist[i * RB_REP + ((r + i) & (RB_REP - 1))];
+    sum *= scale;
+    if (i < bins1) { if (dw1) atomicAdd(dw1 + h * bins1 + i, sum); }
+    else if (i < bins1 + bins2) { if (dwx) atomicAdd(dwx + h * bins2 + (i - bins1), sum); }
+    else if (dwy) atomicAdd(dwy + h * bins2 + (i - bins1 - bins2), sum);
   }
 }
 
@@ -127,7 +136,8 @@ extern "C" int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t*
   PENEO_REQUIRE(ldg >= T, "peneo_relpos_bias_bwd: ldg < T");
   PENEO_REQUIRE(g && B > 0 && nh > 0 && T > 0, "peneo_relpos_bias_bwd: bad arguments");
   PENEO_REQUIRE((bkx != nullptr) == (bky != nullptr), "peneo_relpos_bias_bwd: 2-D inputs mismatch");
-  size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2);
+  size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2) * RB_REP;
+  PENEO_REQUIRE(sh <= 64 * 1024, "peneo_relpos_bias_bwd: tables too large for LDS");
   int slabs = (T + 31) / 32;
   dim3 grid((unsigned)((int64_t)B * nh * slabs));
   hipLaunchKernelGGL(relpos_bias_bwd_kernel, grid, dim3(256), sh, (hipStream_t)stream, g, bk1, bkx, bky, dw1, bins1, dwx, dwy,

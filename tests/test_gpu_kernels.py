@@ -143,12 +143,17 @@ def test_cast_copy_colsum(ops):
     assert torch.equal(ops.copy2d(sub), sub)
     for dt in DTYPES:
         y = torch.randn(1300, 200, device=DEV).to(dt)
-        assert rel_err(ops.colsum(y), y.float().sum(0)) < 1e-4
+        assert rel_err(ops.colsum(y), y.float().sum(0)) < 1e-4                      # 16-byte vector kernel
+        assert rel_err(ops.colsum(y[:, 8:80]), y[:, 8:80].float().sum(0)) < 1e-4    # ... on a strided slice
+        assert rel_err(ops.colsum(y[:, 3:80]), y[:, 3:80].float().sum(0)) < 1e-4    # unaligned -> scalar kernel
+        acc = torch.ones(200, device=DEV)
+        ops.colsum(y, out=acc, accumulate=True)
+        assert rel_err(acc, 1 + y.float().sum(0)) < 1e-4
 
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H", [768, 64, 1024, 24])
+@pytest.mark.parametrize("H", [768, 64, 1024, 24, 256, 192])
 def test_layernorm_fwd_bwd(ops, dtype, H):
     rows = 517
     g = torch.Generator().manual_seed(H)
@@ -167,6 +172,41 @@ def test_layernorm_fwd_bwd(ops, dtype, H):
     dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db)
     assert rel_err(dx, xr.grad) < tol(dtype)
     assert rel_err(dg, gr.grad) < 5e-4 and rel_err(db, br.grad) < 5e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H", [768, 48])
+def test_layernorm_dropout_fwd_bwd_share_the_mask(ops, dtype, H):
+    rows = 300
+    g = torch.Generator().manual_seed(H + 1)
+    x = torch.randn(rows, H, generator=g).to(DEV).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = (0.5 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    y0, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    y1, _, _ = ops.layernorm_fwd(x, gamma, beta, 1e-5, drop_p=0.3, drop_seed=11)
+    y2, _, _ = ops.layernorm_fwd(x, gamma, beta, 1e-5, drop_p=0.3, drop_seed=11)
+    assert torch.equal(y1, y2)
+    keep = y1 != 0
+    assert 0.65 < float(keep.float().mean()) < 0.75
+    assert rel_err(y1[keep], y0[keep].float() / 0.7) < tol(dtype)
+    dy = torch.randn(rows, H, generator=g).to(DEV).to(dtype)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, drop_p=0.3, drop_seed=11)
+    dy_masked = (dy.float() * keep / 0.7).to(dtype)
+    dg2, db2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx2 = ops.layernorm_bwd(dy_masked, x, gamma, mean, rstd, dg2, db2)
+    assert rel_err(dx, dx2) < tol(dtype) and rel_err(dg, dg2) < tol(dtype) and rel_err(db, db2) < tol(dtype)
+
+
+def test_layernorm_strided_rows_fast_path(ops):
+    B, T, S, H = 3, 50, 20, 256
+    for dt in DTYPES:
+        buf = torch.randn(B, T, H, device=DEV).to(dt)
+        gamma, beta = torch.rand(H, device=DEV) + 0.5, torch.randn(H, device=DEV)
+        ref = buf.clone()
+        ref[:, :S] = F.layer_norm(buf[:, :S].float(), (H,), gamma, beta, 1e-5).to(dt)
+        ops.layernorm_fwd(buf[:, :S], gamma, beta, 1e-5, out=buf[:, :S])
+        assert rel_err(buf, ref) < tol(dt)
 
 
 def test_layernorm_strided_rows(ops):
