@@ -207,12 +207,16 @@ int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const
                    peneo_stream_t stream);
 /* dq/dk/dv share the q/k/v layout (ld_dqkv).  g_bias (fp32 [B, nh, T, bias_ld], may be NULL) is
  * accumulated with dS so the bias-table gradient can be reduced once per step.
- * `delta` is a [B, nh, T] fp32 scratch. */
+ * `delta` is a [B, nh, T] fp32 scratch.
+ * Two implementations: with dtype bf16 and `dq_accum` (fp32 scratch [B*T, nh*d], overwritten) the single-pass
+ * kernel runs (S / dP computed once, dQ through fp32 atomics; kt / qt / dot are not read and may be NULL);
+ * otherwise (fp32, or dq_accum NULL) the dQ kernel + the dK/dV kernel run and need the per-head
+ * transposed copies kt / qt / dot from peneo_head_transpose. */
 int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv,
                    const void* kt, const void* qt, const void* dot,
                    const void* out, const void* d_out, int64_t ld_out, const float* lse,
                    int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias,
-                   void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
+                   void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta, float* dq_accum,
                    float drop_p, uint32_t drop_seed, peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

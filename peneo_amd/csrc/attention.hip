@@ -17,6 +17,7 @@
 // tile ahead of the MFMAs.  The additive bias [B, nh, T, Tp] (row stride Tp = T rounded up to 64,
 // padding and masked keys = -1e30) is staged through LDS the same way.  Soft-max runs in the exp2
 // domain in fp32.  scores = scale * q.k + bias (reference: modeling_layoutlmv3.py:365-389).
+#include <cstdlib>
 #include "common.h"
 
 namespace peneo {
@@ -711,6 +712,264 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
+// ================================================================================================
+// backward, bf16 single pass: one workgroup = 128 keys (lane = key) streaming query tiles of 64.  S and dP are computed
+// once; dK / dV accumulate in registers; dS goes through LDS (stored key-major) into the dQ product of the tile, which
+// is added to an fp32 dQ accumulator in HBM with coalesced no-return atomics (6 key tiles contribute per element at
+// T = 709); the bias gradient is added to its fp32 accumulator the same way (this workgroup owns its columns).
+// Every operand that needs the reduction index strided comes from the hardware transpose read ds_read_b64_tr_b16 on
+// the plain row-major tiles, so no transposed copies of Q / K / dO are made.
+// ================================================================================================
+constexpr int FQ = 64;     // queries per step
+constexpr int FKEYS = 128; // keys per workgroup
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+// fragment for an MFMA operand whose row index is the contiguous LDS dimension: rows (lane&31) + col0, reduction
+// indices {k0..k0+3} and {k1..k1+3} (LDS rows) -> two transpose reads of a [4 k][16 rows] block per 16-lane group
+template <int PITCH>
+__device__ __forceinline__ Frag<bf16_t> frag_tr(const char* tile, int col0, int k0, int k1, int lane) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
+  const int c = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int kr = (lane & 15) >> 2;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + (k0 + kr) * PITCH + c * 2));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + (k1 + kr) * PITCH + c * 2));
+  uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  Frag<bf16_t> f;
+  f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
+  return f;
+}
+
+// bias tile [FQ queries][FKEYS keys] of bf16: 16-byte vector i of thread tid (4 per thread).  Kept as four named
+// registers on purpose: as an array the set ended up in scratch memory.
+__device__ __forceinline__ uint4 fused_bias_load(const bf16_t* bias, int64_t ld, int q0, int Tn, int key0, int tid, int i) {
+  const int v = tid + 256 * i;
+  const int r = min(q0 + v / (FKEYS / 8), Tn - 1), c = (v % (FKEYS / 8)) * 8;
+  const int cc = min(key0 + c, (int)ld - 8);   // the window may pass the padded row end: those keys are masked anyway
+  return *reinterpret_cast<const uint4*>(bias + (int64_t)r * ld + cc);
+}
+template <int PB>
+__device__ __forceinline__ void fused_bias_store(uint4 val, char* sB, int tid, int i) {
+  const int v = tid + 256 * i;
+  const int r = v / (FKEYS / 8), c = (v % (FKEYS / 8)) * 8;
+  *reinterpret_cast<uint4*>(sB + r * PB + c * 2) = val;
+}
+
+template <int DP, bool DROP, bool HAS_BIAS, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, float* dq_acc) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = DP / 16, DT = DP / 32;
+  constexpr int PQ = Pitch<T, DP>::v;              // pitch of the [*][DP] tiles
+  constexpr int PS = FQ * 2 + 16;                  // pitch of dS^T [keys][FQ]
+  constexpr int PB = FKEYS * 2 + 16;               // pitch of the bias tile [FQ][keys]
+  char* sQ = smem;                                  // [FQ][DP]
+  char* sdO = sQ + FQ * PQ;                         // [FQ][DP]
+  char* sK = sdO + FQ * PQ;                         // [FKEYS][DP]
+  char* sS = sK + FKEYS * PQ;                       // [FKEYS][FQ]  dS^T
+  char* sB = sS + FKEYS * PS;                       // [FQ][FKEYS]  bias
+  float* sLse = reinterpret_cast<float*>(sB + FQ * PB);   // [FQ]
+  float* sDelta = sLse + FQ;                        // [FQ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * FKEYS;
+  const int Tn = p.T, d = p.d, Tp = p.Tp;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + h * d;
+  const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * d;
+  const T* V = reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + h * d;
+  const T* dO = reinterpret_cast<const T*>(p.d_out) + (int64_t)b * Tn * p.ld_out + h * d;
+  const T* bias = HAS_BIAS ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
+  float* G = (HAS_BIAS && p.g_bias) ? p.g_bias + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
+  float* DQ = dq_acc + (int64_t)b * Tn * ((int64_t)p.nh * d) + h * d;
+  const int64_t ldq = (int64_t)p.nh * d;
+  const int keyl = wave * 32 + (lane & 31);
+  const int mykey = key0 + keyl;
+  const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] * LOG2E : 0.f) : MASKED;
+  const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+  const float keep_scale = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float sc2 = p.scale * LOG2E;
+  const bool q_al = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((p.ld * 2) % 16 == 0) && (d == DP);
+  const bool do_al = ((reinterpret_cast<uintptr_t>(dO) & 15) == 0) && ((p.ld_out * 2) % 16 == 0) && (d == DP);
+
+  // this workgroup's K rows -> LDS once (B operand of the dQ product); K / V fragments (lane = key) stay in registers
+  {
+    TileRegs<T, FKEYS, DP> rk;
+    tile_load<T, FKEYS, DP>(rk, K, p.ld, key0, Tn, 0, d, tid, q_al && key0 + FKEYS <= Tn);
+    tile_store<T, FKEYS, DP>(rk, sK, tid);
+  }
+  Frag<T> kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = frag_from_global<T>(K, p.ld, mykey, Tn, 16 * ks + 8 * half, d);
+    vf[ks] = frag_from_global<T>(V, p.ld, mykey, Tn, 16 * ks + 8 * half, d);
+  }
+  f32x16_t dk[DT], dv[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  TileRegs<T, FQ, DP> rq, rdo;
+  static_assert(FQ * (FKEYS / 8) / 256 == 4, "bias tile = 4 vectors per thread");
+  uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+  const int ntile = (Tn + FQ - 1) / FQ;
+#define FUSED_PREFETCH(t_)                                                               \
+  {                                                                                      \
+    const int q0_ = (t_) * FQ;                                                           \
+    tile_load<T, FQ, DP>(rq, Q, p.ld, q0_, Tn, 0, d, tid, q_al && q0_ + FQ <= Tn);       \
+    tile_load<T, FQ, DP>(rdo, dO, p.ld_out, q0_, Tn, 0, d, tid, do_al && q0_ + FQ <= Tn); \
+    if constexpr (HAS_BIAS) {                                                            \
+      rb0 = fused_bias_load(bias, p.bias_ld, q0_, Tn, key0, tid, 0);                     \
+      rb1 = fused_bias_load(bias, p.bias_ld, q0_, Tn, key0, tid, 1);                     \
+      rb2 = fused_bias_load(bias, p.bias_ld, q0_, Tn, key0, tid, 2);                     \
+      rb3 = fused_bias_load(bias, p.bias_ld, q0_, Tn, key0, tid, 3);                     \
+    }                                                                                    \
+  }
+  FUSED_PREFETCH(0)
+  for (int t = 0; t < ntile; ++t) {
+    const int q0 = t * FQ;
+    __syncthreads();
+    tile_store<T, FQ, DP>(rq, sQ, tid);
+    tile_store<T, FQ, DP>(rdo, sdO, tid);
+    if (tid < FQ) {
+      const int qq = q0 + tid;
+      const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
+      sLse[tid] = qq < Tn ? p.lse[rowid] : 0.f;
+      sDelta[tid] = qq < Tn ? p.delta[rowid] : 0.f;
+    }
+    if constexpr (HAS_BIAS) {
+      fused_bias_store<PB>(rb0, sB, tid, 0);
+      fused_bias_store<PB>(rb1, sB, tid, 1);
+      fused_bias_store<PB>(rb2, sB, tid, 2);
+      fused_bias_store<PB>(rb3, sB, tid, 3);
+    }
+    __syncthreads();
+    FUSED_PREFETCH(t + 1 < ntile ? t + 1 : t)
+
+    float* Gt = G ? G + (int64_t)q0 * p.bias_ld + key0 : nullptr;   // uniform tile base; lanes add 32-bit offsets
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
+      // S[q, key], dP[q, key]: A = Q / dO rows (q), B = K / V fragments (lane = key)
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        Frag<T> a = FragReader<T, DP>::straight(sQ, qt * 32 + (lane & 31), 16 * ks + 8 * half);
+        mma_step(a, kf[ks], s);
+        Frag<T> a2 = FragReader<T, DP>::straight(sdO, qt * 32 + (lane & 31), 16 * ks + 8 * half);
+        mma_step(a2, vf[ks], dp);
+      }
+      f32x16_t pr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qb = qt * 32 + 8 * g + 4 * half;           // 4 consecutive query rows: r = 4g .. 4g+3
+        const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb);
+        const float4 d4 = *reinterpret_cast<const float4*>(sDelta + qb);
+        const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
+        float ds4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e, ql = qb + e, qq = q0 + ql;
+          float bv = 0.f;
+          if constexpr (HAS_BIAS) bv = bf16_to_f32(*reinterpret_cast<const T*>(sB + ql * PB + keyl * 2));
+          const float v = fmaf(s[r], sc2, fmaf(bv, LOG2E, my_kb));
+          const float pv = (qq < Tn) ? fast_exp2(v - lse4[e]) : 0.f;
+          float dpv = dp[r];
+          float pdrop = pv;
+          if (DROP) {
+            const uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)qq) * Tn + mykey;
+            const bool keep = dropout_keep(p.seed, idx, thresh);
+            dpv = keep ? dpv * keep_scale : 0.f;
+            pdrop = keep ? pv * keep_scale : 0.f;
+          }
+          pr[r] = pdrop;
+          const float dsv = pv * (dpv - del4[e]);
+          s[r] = dsv;
+          ds4[e] = dsv;
+          if (G && qq < Tn && mykey < Tn) atomicAdd(Gt + ((uint32_t)ql * (uint32_t)p.bias_ld + (uint32_t)keyl), dsv);
+        }
+        // dS^T[key][q]: 4 consecutive queries of this key
+        *reinterpret_cast<uint2*>(sS + keyl * PS + qb * 2) = make_uint2(pack_bf16x2(ds4[0], ds4[1]), pack_bf16x2(ds4[2], ds4[3]));
+      }
+      // dV^T[d, key] += dO^T[d, q] . P[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        float a[8], c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = pr[8 * kk + e]; c[e] = s[8 * kk + e]; }
+        Frag<T> pf = pack_frag8<T>(a), dsf = pack_frag8<T>(c);
+        const int g0 = qt * 32 + 16 * kk + 4 * half;
+#pragma unroll
+        for (int t2 = 0; t2 < DT; ++t2) {
+          Frag<T> dot = frag_tr<PQ>(sdO, t2 * 32, g0, g0 + 8, lane);
+          mma_step(dot, pf, dv[t2]);
+          Frag<T> qtf = frag_tr<PQ>(sQ, t2 * 32, g0, g0 + 8, lane);
+          mma_step(qtf, dsf, dk[t2]);
+        }
+      }
+    }
+    __syncthreads();   // dS^T tile complete
+    // dQ[q, dcol] += dS[q, keys] . K[keys, dcol]: 2 x DT output tiles of 32 x 32 over the 4 waves
+    for (int tile = wave; tile < 2 * DT; tile += 4) {
+      const int qt = tile / DT, dt = tile % DT;
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < FKEYS / 16; ++kk) {
+        const int k0 = 16 * kk + 8 * half;
+        Frag<T> af = frag_tr<PS>(sS, qt * 32, k0, k0 + 4, lane);     // rows = q, reduction = keys
+        Frag<T> bf = frag_tr<PQ>(sK, dt * 32, k0, k0 + 4, lane);     // cols = dcol, reduction = keys
+        mma_step(af, bf, acc);
+      }
+      const int dcol = dt * 32 + (lane & 31);
+      float* DQt = DQ + (int64_t)(q0 + qt * 32) * ldq;   // uniform
+      if (dcol < d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = acc_row(r, lane);
+          if (q0 + qt * 32 + ql < Tn) atomicAdd(DQt + ((uint32_t)ql * (uint32_t)ldq + (uint32_t)dcol), acc[r] * p.scale);
+        }
+      }
+    }
+  }
+#undef FUSED_PREFETCH
+
+  __syncthreads();
+  float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
+  T* DK = reinterpret_cast<T*>(p.dk) + (int64_t)b * Tn * p.ld_d + h * d;
+  T* DV = reinterpret_cast<T*>(p.dv) + (int64_t)b * Tn * p.ld_d + h * d;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = which == 0 ? dk[t][r] * p.scale : dv[t][r];
+    __syncthreads();
+    store_rows<T, DP>(myO, which == 0 ? DK : DV, p.ld_d, key0 + wave * 32, Tn, d, lane);
+    __syncthreads();
+  }
+}
+
+// fp32 dQ accumulator [rows][cols] -> bf16 dq rows (leading dim ld)
+__global__ __launch_bounds__(256) void dq_finish_kernel(const float* acc, int64_t rows, int cols, bf16_t* dq, int64_t ld) {
+  const int64_t total = rows * (cols / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / (cols / 8);
+    const int c = (int)(i % (cols / 8)) * 8;
+    float f[8];
+    const uint4* q = reinterpret_cast<const uint4*>(acc + r * cols + c);
+    unpack16<float>(q[0], f); unpack16<float>(q[1], f + 4);
+    *reinterpret_cast<uint4*>(dq + r * ld + c) = pack16<bf16_t>(f);
+  }
+}
+
+template <int DP> static size_t fused_smem() {
+  size_t a = (size_t)2 * FQ * Pitch<bf16_t, DP>::v + (size_t)FKEYS * Pitch<bf16_t, DP>::v + (size_t)FKEYS * (FQ * 2 + 16) +
+             (size_t)FQ * (FKEYS * 2 + 16) + 2 * FQ * sizeof(float);
+  size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
+  return a > o ? a : o;
+}
+
 template <typename T, int DP> static size_t fwd_smem() {
   size_t a = (size_t)AK * Pitch<T, DP>::v + (size_t)DP * Pitch<T, AK>::v + (size_t)AQ * BiasPitch<T>::v + AK * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
@@ -754,11 +1013,41 @@ static int launch_fwd(const AttnParams& p, hipStream_t st) {
   return p.drop_p > 0.f ? launch_fwd_d<T, DP, true>(p, st) : launch_fwd_d<T, DP, false>(p, st);
 }
 template <typename T, int DP, bool DROP>
-static int launch_bwd_d(const AttnParams& p, hipStream_t st) {
+static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
   int64_t rows = (int64_t)p.B * p.nh * p.T;
   hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   int rc = check_launch("peneo_attn_bwd(delta)");
   if (rc) return rc;
+  if constexpr (sizeof(T) == 2) {
+    const int64_t cols = (int64_t)p.nh * p.d;
+    if (dq_acc) {   // eligibility was decided by peneo_attn_bwd
+      const int64_t R = (int64_t)p.B * p.T;
+      if (hipMemsetAsync(dq_acc, 0, sizeof(float) * R * cols, st) != hipSuccess) {
+        set_error("peneo_attn_bwd: memset of the dQ accumulator failed");
+        return PENEO_ERR_LAUNCH;
+      }
+      size_t sf = fused_smem<DP>();
+      dim3 fgrid((p.T + FKEYS - 1) / FKEYS, p.nh, p.B);
+      static const int occ_env = getenv("PENEO_ATTN_OCC") ? atoi(getenv("PENEO_ATTN_OCC")) : 0;
+      const int occ = occ_env ? occ_env : (DP <= 64 ? 2 : 1);
+#define PENEO_LAUNCH_FUSED(HB_, OCC_)                                                                        \
+  {                                                                                                          \
+    rc = set_smem(attn_bwd_fused_kernel<DP, DROP, HB_, OCC_>, sf);                                           \
+    if (rc) return rc;                                                                                       \
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<DP, DROP, HB_, OCC_>), fgrid, dim3(256), sf, st, p, dq_acc);    \
+  }
+      if (p.bias) { if (occ >= 2) PENEO_LAUNCH_FUSED(true, 2) else PENEO_LAUNCH_FUSED(true, 1) }
+      else { if (occ >= 2) PENEO_LAUNCH_FUSED(false, 2) else PENEO_LAUNCH_FUSED(false, 1) }
+#undef PENEO_LAUNCH_FUSED
+      rc = check_launch("peneo_attn_bwd(fused)");
+      if (rc) return rc;
+      int64_t blocks = (R * (cols / 8) + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(dq_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dq_acc, R, (int)cols,
+                         reinterpret_cast<bf16_t*>(p.dq), p.ld_d);
+      return check_launch("peneo_attn_bwd(dq finish)");
+    }
+  }
   dim3 grid((p.T + AQ - 1) / AQ, p.nh, p.B);
   size_t s1 = dq_smem<T, DP>();
   rc = set_smem(attn_bwd_dq_kernel<T, DP, DROP>, s1);
@@ -773,18 +1062,18 @@ static int launch_bwd_d(const AttnParams& p, hipStream_t st) {
   return check_launch("peneo_attn_bwd(dkv)");
 }
 template <typename T, int DP>
-static int launch_bwd(const AttnParams& p, hipStream_t st) {
-  return p.drop_p > 0.f ? launch_bwd_d<T, DP, true>(p, st) : launch_bwd_d<T, DP, false>(p, st);
+static int launch_bwd(const AttnParams& p, float* dq_acc, hipStream_t st) {
+  return p.drop_p > 0.f ? launch_bwd_d<T, DP, true>(p, dq_acc, st) : launch_bwd_d<T, DP, false>(p, dq_acc, st);
 }
 
 template <typename T>
-static int dispatch(const AttnParams& p, bool bwd, hipStream_t st) {
+static int dispatch(const AttnParams& p, bool bwd, hipStream_t st, float* dq_acc = nullptr) {
   const int dp = (p.d + 31) / 32 * 32;
   switch (dp) {
-    case 32: return bwd ? launch_bwd<T, 32>(p, st) : launch_fwd<T, 32>(p, st);
-    case 64: return bwd ? launch_bwd<T, 64>(p, st) : launch_fwd<T, 64>(p, st);
-    case 96: return bwd ? launch_bwd<T, 96>(p, st) : launch_fwd<T, 96>(p, st);
-    case 128: return bwd ? launch_bwd<T, 128>(p, st) : launch_fwd<T, 128>(p, st);
+    case 32: return bwd ? launch_bwd<T, 32>(p, dq_acc, st) : launch_fwd<T, 32>(p, st);
+    case 64: return bwd ? launch_bwd<T, 64>(p, dq_acc, st) : launch_fwd<T, 64>(p, st);
+    case 96: return bwd ? launch_bwd<T, 96>(p, dq_acc, st) : launch_fwd<T, 96>(p, st);
+    case 128: return bwd ? launch_bwd<T, 128>(p, dq_acc, st) : launch_fwd<T, 128>(p, st);
     default: set_error("attention: head dim %d not supported (<= 128)", p.d); return PENEO_ERR_INVALID;
   }
 }
@@ -838,10 +1127,15 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
                               const void* qt, const void* dot, const void* out, const void* d_out, int64_t ld_out,
                               const float* lse, int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
                               const float* key_bias, void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
-                              float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+                              float* dq_accum, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
   int rc = attn_common_check("peneo_attn_bwd", dtype, B, nh, T, d, bias, bias_ld);
   if (rc) return rc;
-  PENEO_REQUIRE(q && k && v && kt && qt && dot && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
+  PENEO_REQUIRE(q && k && v && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
+  // single-pass eligibility (bf16, accumulator given, dq rows writable as 16-byte vectors); otherwise the two-kernel path
+  bool fused = dtype == PENEO_BF16 && dq_accum != nullptr && (((int64_t)nh * d) % 8 == 0) &&
+               ((reinterpret_cast<uintptr_t>(dq) & 15) == 0) && ((ld_dqkv * 2) % 16 == 0);
+  if (!fused) dq_accum = nullptr;
+  PENEO_REQUIRE(fused || (kt && qt && dot), "peneo_attn_bwd: the two-kernel path needs the transposed copies kt / qt / dot");
   PENEO_REQUIRE(ld_qkv >= (int64_t)nh * d && ld_out >= (int64_t)nh * d && ld_dqkv >= (int64_t)nh * d, "peneo_attn_bwd: leading dims too small");
   PENEO_REQUIRE(!g_bias || bias, "peneo_attn_bwd: g_bias needs bias (it shares its row stride)");
   AttnParams p = {};
@@ -850,5 +1144,6 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
   p.out = const_cast<void*>(out); p.ld_out = ld_out; p.lse = const_cast<float*>(lse);
   p.drop_p = drop_p; p.seed = drop_seed; p.d_out = d_out; p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_dqkv;
   p.g_bias = g_bias; p.delta = delta;
-  return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, true, (hipStream_t)stream) : dispatch<float>(p, true, (hipStream_t)stream);
+  return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, true, (hipStream_t)stream, dq_accum)
+                             : dispatch<float>(p, true, (hipStream_t)stream, nullptr);
 }

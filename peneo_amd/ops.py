@@ -366,20 +366,30 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int,
 
 
 def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_bias,
-             dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
-    """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations)."""
+             dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0,
+             single_pass: Optional[bool] = None) -> torch.Tensor:
+    """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations).
+    bf16 runs the single-pass kernel (fp32 dQ accumulator, no transposed copies); fp32 the dQ + dK/dV pair."""
     H = nh * d
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     delta = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
     assert out.stride(0) == d_out.stride(0)
-    kt = head_transpose(k, B, nh, T, d)
-    qt = head_transpose(q, B, nh, T, d)
-    dot = head_transpose(d_out, B, nh, T, d)
+    if single_pass is None:
+        single_pass = (q.dtype == torch.bfloat16 and H % 8 == 0 and dqkv.stride(0) % 8 == 0
+                       and dqkv.data_ptr() % 16 == 0)
+    kt = qt = dot = dq_acc = None
+    if single_pass:
+        assert q.dtype == torch.bfloat16, "the single-pass attention backward is bf16 only"
+        dq_acc = torch.empty((B * T, H), dtype=torch.float32, device=q.device)
+    else:
+        kt = head_transpose(k, B, nh, T, d)
+        qt = head_transpose(q, B, nh, T, d)
+        dot = head_transpose(d_out, B, nh, T, d)
     check(lib().peneo_attn_bwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(kt), ptr(qt), ptr(dot),
                                ptr(out), ptr(d_out), out.stride(0), ptr(lse), B, nh, T, d, scale, ptr(bias),
                                bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(dq), ptr(dk), ptr(dv),
-                               dqkv.stride(0), ptr(g_bias), ptr(delta), drop_p, drop_seed & 0xFFFFFFFF, stream()),
-          "peneo_attn_bwd")
+                               dqkv.stride(0), ptr(g_bias), ptr(delta), ptr(dq_acc), drop_p, drop_seed & 0xFFFFFFFF,
+                               stream()), "peneo_attn_bwd")
     return dqkv
 
 

@@ -375,6 +375,11 @@ def test_attention_fwd_bwd(ops, dtype, B, nh, T, d):
     dqkv = torch.empty_like(qkv)
     gbias = torch.zeros(pb.shape, dtype=torch.float32, device=DEV)
     ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, scale, pb, None, dqkv, gbias)
+    if dtype == torch.bfloat16:   # the two-kernel path must agree with the single-pass default
+        dqkv2 = torch.empty_like(qkv)
+        gbias2 = torch.zeros_like(gbias)
+        ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, scale, pb, None, dqkv2, gbias2, single_pass=False)
+        assert rel_err(dqkv, dqkv2) < 2e-2 and rel_err(gbias, gbias2) < 2e-2
     t = 3e-5 if dtype == torch.float32 else 4e-2
     assert rel_err(dqkv[:, 2 * H:], leaf.grad[:, 2 * H:]) < t, "dv"
     assert rel_err(dqkv[:, H:2 * H], leaf.grad[:, H:2 * H]) < t, "dk"
@@ -384,6 +389,27 @@ def test_attention_fwd_bwd(ops, dtype, B, nh, T, d):
     # accumulation semantics of the bias gradient
     ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, scale, pb, None, dqkv, gbias)
     assert rel_err(gbias[..., :T], 2 * br.grad) < t
+
+
+@pytest.mark.parametrize("d", [64, 80])
+def test_attention_bf16_single_pass_matches_two_kernel_path_with_dropout(ops, d):
+    """Both backward implementations regenerate the forward's dropout mask from (seed, element index)."""
+    B, nh, T = 2, 2, 200
+    H = nh * d
+    g = torch.Generator().manual_seed(d)
+    qkv = torch.randn(B * T, 3 * H, generator=g).to(DEV).to(torch.bfloat16)
+    bias = _padded_bias((0.5 * torch.randn(B, nh, T, T, generator=g)).to(DEV).to(torch.bfloat16), None)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    out, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 0.11, bias, None, drop_p=0.2, drop_seed=9)
+    d_out = torch.randn(B * T, H, generator=g).to(DEV).to(torch.bfloat16)
+    res = []
+    for single in (True, False):
+        dqkv = torch.zeros_like(qkv)
+        gb = torch.zeros(bias.shape, dtype=torch.float32, device=DEV)
+        ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.11, bias, None, dqkv, gb, drop_p=0.2, drop_seed=9, single_pass=single)
+        res.append((dqkv.float(), gb))
+    assert rel_err(res[0][0], res[1][0]) < 2e-2
+    assert rel_err(res[0][1], res[1][1]) < 2e-2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
