@@ -58,6 +58,7 @@ const char* peneo_last_error(void);
  * Replaces torch.nn.Linear / F.linear call sites: modeling_layoutlmv3.py:292-294,335-360,
  * RobertaSelfOutput/Intermediate/Output, peneo_decoder.py:126,213-222 and their autograd.
  * ------------------------------------------------------------------------------------------ */
+struct peneo_pair_dz_args;
 typedef struct peneo_gemm_epilogue {
   const float* bias;        /* [N] fp32 or NULL */
   int act;                  /* PENEO_ACT_* applied after bias */
@@ -72,6 +73,12 @@ typedef struct peneo_gemm_epilogue {
   int accumulate;           /* C += result (c_dtype must be PENEO_F32) */
   float drop_p;             /* dropout probability (0 = off); keep mask = f(drop_seed, m*N+n) */
   uint32_t drop_seed;
+  /* pair-head backward fusion (K12 bwd): when set, the tile is the first-layer pre-activation z = acc + bias of
+   * rows = pairs, columns = [head, hidden]; the epilogue stores dz (see peneo_pair_dz) instead of z and adds the
+   * dW2 / db1 partial sums to `pair_dz_ws` (same workspace layout as peneo_pair_dz, row = m-tile index mod 256).
+   * No other epilogue option may be combined with it; split_k must be 1. */
+  const struct peneo_pair_dz_args* pair_dz;
+  float* pair_dz_ws;
 } peneo_gemm_epilogue;
 
 size_t peneo_gemm_workspace_bytes(int M, int N, int K, int split_k);

@@ -23,7 +23,11 @@ struct GemmParams {
   int split_k;        // >1: write raw fp32 partials to `ws` [split][M][N]
   float* ws;
   int kt_per_split;   // k-tiles per split
+  int dz_on;          // pair-head backward epilogue (z -> dz, dW2 / db1 partials)
+  peneo_pair_dz_args dz;
+  float* dz_ws;
 };
+constexpr int GEMM_DZ_SLOTS = 256;   // == DZ_SLOTS of pair_heads.hip (rows of the partial-sum workspace)
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4); }
 
@@ -240,6 +244,113 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
         sC[(wm * 64 + i * 32 + acc_row(r, lane)) * GB + wn * 64 + j * 32 + acc_col(lane)] = acc[i][j][r];
   __syncthreads();
   const int mrem = min(GB, p.M - m0), nrem = min(GB, p.N - n0);
+  if (p.dz_on) {
+    // z = acc + b1 -> dz.  Thread = 8 consecutive columns (one 16-byte store per row) x 8 rows; the per-row dlogits of
+    // the tile's head(s) are staged in LDS behind the C tile; column sums (dW2 / db1 partials) are reduced over the 16
+    // row-lanes through LDS (the C tile is dead by then) and leave as one atomic per column and quantity.
+    const peneo_pair_dz_args& a = p.dz;
+    float* sG = sC + GB * GB;                       // [2 heads][128 rows][4]: scale * dlogits (zero padded classes)
+    const int h_lo = n0 / a.D, h_hi = min((n0 + nrem - 1) / a.D, a.num_heads - 1);
+    const bool staged = (h_hi - h_lo) <= 1;         // tile spans at most 2 heads (always when D >= 128)
+    if (staged) {
+      for (int i = tid; i < 2 * GB; i += 256) {
+        const int hh = h_lo + (i >> 7), r = i & (GB - 1);
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (hh <= h_hi && r < mrem) {
+          const int Cn = a.classes[hh];
+          const float sc = a.scale[hh];
+          const float* dl = a.dlogits[hh] + (int64_t)(m0 + r) * Cn;
+          g0 = dl[0] * sc;
+          if (Cn > 1) g1 = dl[1] * sc;
+          if (Cn > 2) g2 = dl[2] * sc;
+        }
+        *reinterpret_cast<float4*>(sG + i * 4) = make_float4(g0, g1, g2, 0.f);
+      }
+      __syncthreads();
+    }
+    const int cg = tid & 15, rl = tid >> 4;           // 16 column groups x 16 row lanes
+    const int c0 = cg * 8;
+    float w2c[3][8], b1v[8], s0[8], s1[8], s2[8], sb[8];
+    int hsel[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = min(n0 + c0 + e, p.N - 1);
+      const int h = n / a.D, k = n - h * a.D;
+      const int Cn = a.classes[h];
+      hsel[e] = h - h_lo;
+      w2c[0][e] = a.w2[h][k];
+      w2c[1][e] = Cn > 1 ? a.w2[h][(int64_t)a.D + k] : 0.f;
+      w2c[2][e] = Cn > 2 ? a.w2[h][(int64_t)2 * a.D + k] : 0.f;
+      b1v[e] = p.ep.bias ? p.ep.bias[n] : 0.f;
+      s0[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; sb[e] = 0.f;
+    }
+    const bool one_head = hsel[0] == hsel[7];
+    const bool vec_store = (c0 + 8 <= nrem) && p.c_dtype == PENEO_BF16 && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                           ((p.ldc * 2) % 16 == 0);
+#pragma unroll 2
+    for (int i = 0; i < GB / 16; ++i) {
+      const int r = rl + 16 * i;
+      if (r < mrem && c0 < nrem) {
+        float zv[8], o[8];
+        const uint4* q = reinterpret_cast<const uint4*>(sC + r * GB + c0);
+        unpack16<float>(q[0], zv); unpack16<float>(q[1], zv + 4);
+        float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+        if (staged) {
+          ga = *reinterpret_cast<const float4*>(sG + (hsel[0] * GB + r) * 4);
+          gb = one_head ? ga : *reinterpret_cast<const float4*>(sG + (hsel[7] * GB + r) * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float g0, g1, g2;
+          if (staged) {
+            const bool lo = hsel[e] == hsel[0];
+            g0 = lo ? ga.x : gb.x; g1 = lo ? ga.y : gb.y; g2 = lo ? ga.z : gb.z;
+          } else {   // tiny decoder widths: a tile spans 3+ heads, read the row's dlogits directly
+            const int h = h_lo + hsel[e];
+            const int Cn = a.classes[h];
+            const float sc = a.scale[h];
+            const float* dl = a.dlogits[h] + (int64_t)(m0 + r) * Cn;
+            g0 = dl[0] * sc; g1 = Cn > 1 ? dl[1] * sc : 0.f; g2 = Cn > 2 ? dl[2] * sc : 0.f;
+          }
+          const float z = zv[e] + b1v[e];
+          const float sg = sigmoid_f(z);
+          const float y = z * sg;
+          const float dy = g0 * w2c[0][e] + g1 * w2c[1][e] + g2 * w2c[2][e];
+          const float dz = dy * sg * (1.f + z * (1.f - sg));
+          s0[e] += g0 * y; s1[e] += g1 * y; s2[e] += g2 * y; sb[e] += dz;
+          o[e] = dz;
+        }
+        const int64_t ci = (int64_t)(m0 + r) * p.ldc + n0 + c0;
+        if (vec_store) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + ci) = pack16<bf16_t>(o);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (c0 + e < nrem) store_any(p.C, p.c_dtype, ci + e, o[e]);
+        }
+      }
+    }
+    __syncthreads();                                  // every thread is done with the C tile: reuse it for the reduction
+    float* red = sC;                                  // [16 row lanes][4 quantities][128 columns]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(rl * 4 + 0) * GB + c0 + e] = s0[e];
+      red[(rl * 4 + 1) * GB + c0 + e] = s1[e];
+      red[(rl * 4 + 2) * GB + c0 + e] = s2[e];
+      red[(rl * 4 + 3) * GB + c0 + e] = sb[e];
+    }
+    __syncthreads();
+    const int64_t ncol = (int64_t)a.num_heads * a.D;
+    float* slot = p.dz_ws + (int64_t)((m0 / GB) % GEMM_DZ_SLOTS) * 4 * ncol;
+    for (int i = tid; i < 4 * GB; i += 256) {
+      const int qn = i >> 7, c = i & (GB - 1);
+      if (c < nrem) {
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) sum += red[(l * 4 + qn) * GB + c];
+        atomicAdd(slot + qn * ncol + n0 + c, sum);
+      }
+    }
+    return;
+  }
   // vector path: 8 columns per thread per step (16 threads per row), when every row segment is 16-byte aligned
   const peneo_gemm_epilogue& e = p.ep;
   const int csz = p.c_dtype == PENEO_F32 ? 4 : 2;
@@ -531,7 +642,12 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
 
 template <typename T>
 static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  size_t shmem = 4 * TILE_BYTES;
+  size_t shmem = 4 * TILE_BYTES + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
+  if (p.dz_on) {
+    if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
+  }
   if (ak && bk) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), shmem, st, p);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), shmem, st, p);
   else if (!ak && bk) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(256), shmem, st, p);
@@ -540,7 +656,12 @@ static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStre
 }
 
 static int launch_gemm_dma(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  size_t shmem = 4 * TILE_BYTES;
+  size_t shmem = 4 * TILE_BYTES + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
+  if (p.dz_on) {   // > 64 KiB of dynamic LDS needs the opt-in (the pair-dz epilogue is only used with k-major operands)
+    if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
+  }
   if (ak && bk) hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, dim3(256), shmem, st, p);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, dim3(256), shmem, st, p);
   else if (!ak && bk) hipLaunchKernelGGL((gemm_dma_kernel<false, true>), grid, dim3(256), shmem, st, p);
@@ -570,6 +691,19 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
   p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.c_dtype = c_dtype;
   if (ep) p.ep = *ep; else { peneo_gemm_epilogue z = {}; p.ep = z; }
   if (p.ep.alpha == 0.f) p.ep.alpha = 1.f;
+  p.dz_on = 0; p.dz_ws = nullptr;
+  if (p.ep.pair_dz) {
+    const peneo_pair_dz_args* a = p.ep.pair_dz;
+    PENEO_REQUIRE(p.ep.pair_dz_ws, "peneo_gemm: pair_dz needs its workspace");
+    PENEO_REQUIRE(a->num_heads > 0 && a->num_heads <= PENEO_MAX_HEADS && a->D > 0 && (int64_t)a->num_heads * a->D == N && a->scale,
+                  "peneo_gemm: pair_dz expects N == num_heads * D");
+    for (int h = 0; h < a->num_heads; ++h)
+      PENEO_REQUIRE(a->dlogits[h] && a->w2[h] && a->classes[h] >= 1 && a->classes[h] <= 3, "peneo_gemm: pair_dz head %d incomplete", h);
+    PENEO_REQUIRE(p.ep.act == PENEO_ACT_NONE && !p.ep.preact && !p.ep.grad_src && !p.ep.residual && !p.ep.accumulate &&
+                  p.ep.drop_p == 0.f && p.ep.alpha == 1.f, "peneo_gemm: pair_dz cannot be combined with other epilogue options");
+    split_k = 1;
+    p.dz_on = 1; p.dz = *a; p.dz_ws = p.ep.pair_dz_ws;
+  }
   PENEO_REQUIRE(!p.ep.accumulate || c_dtype == PENEO_F32, "peneo_gemm: accumulate needs an fp32 C");
   PENEO_REQUIRE(p.ep.drop_p >= 0.f && p.ep.drop_p < 1.f, "peneo_gemm: drop_p out of range");
   const int KT = dtype == PENEO_BF16 ? 64 : 32;

@@ -234,22 +234,41 @@ class _DecoderStage(torch.autograd.Function):
         P = N * (N + 1) // 2
         chunks = _row_chunks(N, dec.bwd_chunk_pairs)
         maxp = max((i1 * N - i1 * (i1 - 1) // 2) - (i0 * N - i0 * (i0 - 1) // 2) for i0, i1 in chunks)
-        xbuf = torch.empty((maxp, D), dtype=dt, device=dev)
-        zbuf = torch.empty((maxp, nh * D), dtype=dt, device=dev)
+        # Two-stage pipeline over the pair chunks on two HIP streams: stage 1 (x, z GEMM whose epilogue turns z into dz:
+        # VALU-bound) runs one chunk ahead of stage 2 (dW1 and dx GEMMs + the scatter into d_ab: MFMA-bound), so the two
+        # kinds of work share the CUs instead of alternating.  Buffers are double-buffered; events order the hand-offs.
+        xbuf = [torch.empty((maxp, D), dtype=dt, device=dev) for _ in range(2)]
+        zbuf = [torch.empty((maxp, nh * D), dtype=dt, device=dev) for _ in range(2)]
         dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
         w2d = [w.detach().contiguous() for w in w2s]
+        main = torch.cuda.current_stream()
+        side = dec.side_stream(dev)
+        ready = [torch.cuda.Event() for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+        side.wait_stream(main)                       # d_ab / dW1cat zero fills, ab, weights
+        idx = 0
         for b in range(B):
             for (i0, i1) in chunks:
+                k = idx & 1
                 p0 = i0 * N - i0 * (i0 - 1) // 2
                 p1 = i1 * N - i1 * (i1 - 1) // 2
                 npairs = p1 - p0
-                x, z, dx = xbuf[:npairs], zbuf[:npairs], dxbuf[:npairs]
+                x, z, dx = xbuf[k][:npairs], zbuf[k][:npairs], dxbuf[:npairs]
+                if idx >= 2:
+                    main.wait_event(done[k])         # stage 2 of chunk idx-2 has released x[k] / z[k]
                 ops.pair_x_fwd(ab[b], i0, i1, x)
-                ops.gemm(x, W1cat, bias=b1cat, out=z)
-                ops.pair_dz(z, npairs, D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, dz_ws, scale)
-                ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
-                ops.gemm(z, W1cat, b_kmajor=False, out=dx)
-                ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b])
+                # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
+                dza = ops.pair_dz_args(D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, scale)
+                ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
+                ready[k].record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready[k])
+                    ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
+                    ops.gemm(z, W1cat, b_kmajor=False, out=dx)
+                    ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b])
+                    done[k].record(side)
+                idx += 1
+        main.wait_stream(side)
         dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
         db2cat = sv["dls"]
         # back through the [a | b] projection and the shrink MLP
@@ -286,6 +305,14 @@ class _DecoderStage(torch.autograd.Function):
 
 class PEneoDecoder(nn.Module):
     """PEneo pair extraction downstream head (reference :201-443)."""
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """Second HIP stream of the chunked backward (created once per device)."""
+        key = str(device)
+        streams = self.__dict__.setdefault("_side_streams", {})
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
 
     def __init__(self, config, input_size: int) -> None:
         super().__init__()

@@ -76,7 +76,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
          preact: Optional[torch.Tensor] = None, grad_src: Optional[torch.Tensor] = None, grad_act: int = ACT_NONE,
          out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, accumulate: bool = False,
-         alpha: float = 1.0, drop_p: float = 0.0, drop_seed: int = 0, split_k: Optional[int] = None) -> torch.Tensor:
+         alpha: float = 1.0, drop_p: float = 0.0, drop_seed: int = 0, split_k: Optional[int] = None,
+         pair_dz=None, pair_dz_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(alpha * A.B^T); a, b are 2-D (row stride may exceed the row length)."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -107,6 +108,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ep.alpha = alpha
     ep.accumulate = 1 if accumulate else 0
     ep.drop_p, ep.drop_seed = drop_p, drop_seed & 0xFFFFFFFF
+    if pair_dz is not None:      # hip.PairDzArgs: the tile is z of the pair heads; store dz, accumulate dW2 / db1 partials
+        ep.pair_dz, ep.pair_dz_ws = C.cast(C.pointer(pair_dz), C.c_void_p), ptr(pair_dz_ws)
+        split_k = 1
     if split_k is None:
         split_k = choose_split_k(M, N, K, a.dtype)
     ws, ws_bytes = None, 0
@@ -472,14 +476,20 @@ def pair_dz_workspace(nh: int, D: int, device) -> torch.Tensor:
                        device=device)
 
 
-def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor],
-            w2: Sequence[torch.Tensor], workspace: torch.Tensor, scale: torch.Tensor) -> None:
+def pair_dz_args(D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor], w2: Sequence[torch.Tensor],
+                 scale: torch.Tensor) -> "hip.PairDzArgs":
     a = hip.PairDzArgs()
     a.num_heads, a.D = len(classes), D
     for h, c in enumerate(classes):
         a.classes[h] = c
         a.dlogits[h], a.w2[h] = ptr(dlogits[h]), ptr(w2[h])
     a.scale = ptr(scale)
+    return a
+
+
+def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor],
+            w2: Sequence[torch.Tensor], workspace: torch.Tensor, scale: torch.Tensor) -> None:
+    a = pair_dz_args(D, classes, dlogits, w2, scale)
     check(lib().peneo_pair_dz(dtype_code(z.dtype), ptr(z), npairs, C.byref(a), ptr(workspace), stream()), "peneo_pair_dz")
 
 

@@ -555,6 +555,23 @@ def test_pair_backward_blocks(ops, dtype):
     assert rel_err(db1, zr.grad.sum(0)) < t
     for h in range(nh):
         assert rel_err(dw2[h], w2r[h].grad) < t
+    # the same block fused into the epilogue of the z GEMM: z = x W1^T + b1 -> dz, with the dW2 / db1 partial sums
+    w1cat = (torch.randn(nh * D, D, generator=g) / math.sqrt(D)).to(DEV).to(dtype)
+    b1cat = (0.1 * torch.randn(nh * D, generator=g)).to(DEV)
+    zfull = ops.gemm(x, w1cat, bias=b1cat)
+    ws_a = ops.pair_dz_workspace(nh, D, DEV)
+    za = zfull.clone()
+    ops.pair_dz(za, npairs, D, classes, dl, w2, ws_a, scale)
+    ws_b = ops.pair_dz_workspace(nh, D, DEV)
+    zb = torch.empty_like(zfull)
+    ops.gemm(x, w1cat, bias=b1cat, out=zb, pair_dz=ops.pair_dz_args(D, classes, dl, w2, scale), pair_dz_ws=ws_b)
+    # unfused path rounds z to the storage dtype before the activation derivative; fused keeps fp32 -> bf16-level agreement
+    assert rel_err(zb, za) < (1e-5 if dtype == torch.float32 else 3e-2)
+    dw2a, db1a = ops.pair_dz_finish(ws_a, nh, D, classes)
+    dw2b, db1b = ops.pair_dz_finish(ws_b, nh, D, classes)
+    assert rel_err(db1b, db1a) < (1e-4 if dtype == torch.float32 else 2e-2)
+    for h in range(nh):
+        assert rel_err(dw2b[h], dw2a[h]) < (1e-4 if dtype == torch.float32 else 2e-2)
 
 
 def test_weighted_ce_and_spots(ops):
