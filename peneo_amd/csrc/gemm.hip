@@ -312,12 +312,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
             const float* dl = a.dlogits[h] + (int64_t)(m0 + r) * Cn;
             g0 = dl[0] * sc; g1 = Cn > 1 ? dl[1] * sc : 0.f; g2 = Cn > 2 ? dl[2] * sc : 0.f;
           }
+          // explicit fma: the library is built with -ffp-contract=off and this loop is VALU-bound
           const float z = zv[e] + b1v[e];
           const float sg = sigmoid_f(z);
           const float y = z * sg;
-          const float dy = g0 * w2c[0][e] + g1 * w2c[1][e] + g2 * w2c[2][e];
-          const float dz = dy * sg * (1.f + z * (1.f - sg));
-          s0[e] += g0 * y; s1[e] += g1 * y; s2[e] += g2 * y; sb[e] += dz;
+          const float dy = fmaf(g2, w2c[2][e], fmaf(g1, w2c[1][e], g0 * w2c[0][e]));
+          const float dz = dy * (sg * fmaf(z, 1.f - sg, 1.f));
+          s0[e] = fmaf(g0, y, s0[e]); s1[e] = fmaf(g1, y, s1[e]); s2[e] = fmaf(g2, y, s2[e]); sb[e] += dz;
           o[e] = dz;
         }
         const int64_t ci = (int64_t)(m0 + r) * p.ldc + n0 + c0;

@@ -10,6 +10,8 @@ triangle) so that its three GEMMs per chunk stay Infinity-Cache resident.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -354,7 +356,9 @@ class PEneoDecoder(nn.Module):
         self.le_loss = _ClassWeightedCE(torch.tensor(cw[:-1]).float(), config.peneo_ohem_num_positive,
                                         config.peneo_ohem_num_negative)
         self.weight_cache = WeightCache()
-        self.bwd_chunk_pairs = 32768
+        # pairs per backward chunk: the z / dz buffer is chunk x 5D (a whole base document is 0.5 GB in bf16, small against
+        # 288 GB of HBM), and long launches amortise tile tails and the split-k reduction of the weight-gradient GEMM
+        self.bwd_chunk_pairs = int(os.environ.get("PENEO_BWD_CHUNK_PAIRS", 1 << 18))
         self._ratio = {}
 
     def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
