@@ -22,15 +22,18 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # PENEO_DIST_BACKEND=gloo: test the multi-process path with several ranks on ONE GPU
+            backend = os.environ.get("PENEO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            return rank, local_rank, world
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if "PENEO_DEVICE" in os.environ:      # all ranks on one device (single-GPU test box)
+        local_rank = int(os.environ["PENEO_DEVICE"])
     return rank, local_rank, world
 
 
