@@ -410,23 +410,55 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
   const T* arow = abd + (int64_t)pi * 2 * D;
   const T* brow = abd + (int64_t)pj * 2 * D + D;
   Frag<T> xf[KS];
+  if constexpr (sizeof(T) == 2 && KS % 4 == 0) {
+    // groups of 4 k-steps, raw 16-byte gathers double-buffered by hand; the empty asm fences stop the compiler from
+    // hoisting every gather to the top (which spilled 760 bytes per thread: 3 GB of scratch traffic per launch)
+    uint4 ra[2][4], rb[2][4];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = 16 * ks + 8 * half;
-    float a[8], bb[8];
-    if constexpr (sizeof(T) == 2) {
-      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
-      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
-    } else {
-      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
-      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c + 4), a + 4);
-      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
-      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c + 4), bb + 4);
+    for (int i = 0; i < 4; ++i) {
+      ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
+      rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
-    xf[ks] = pack_frag8<T>(a);
-    if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep few gathers in flight (else the raw loads spill)
+    for (int g = 0; g < KS / 4; ++g) {
+      if (g + 1 < KS / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (4 * (g + 1) + i) + 8 * half);
+          rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (4 * (g + 1) + i) + 8 * half);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a[8], bb[8];
+        unpack16<T>(ra[g & 1][i], a);
+        unpack16<T>(rb[g & 1][i], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+        xf[4 * g + i] = pack_frag8<T>(a);
+        // pin the finished fragment here: otherwise the SiLU math sinks below all the gathers and their raw data spills
+        asm volatile("" : "+v"(xf[4 * g + i].v.x), "+v"(xf[4 * g + i].v.y), "+v"(xf[4 * g + i].v.z), "+v"(xf[4 * g + i].v.w) :: "memory");
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = 16 * ks + 8 * half;
+      float a[8], bb[8];
+      if constexpr (sizeof(T) == 2) {
+        unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+        unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+      } else {
+        unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+        unpack16<T>(*reinterpret_cast<const uint4*>(arow + c + 4), a + 4);
+        unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+        unpack16<T>(*reinterpret_cast<const uint4*>(brow + c + 4), bb + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+      xf[ks] = pack_frag8<T>(a);
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep few gathers in flight (else the raw loads spill)
+    }
   }
   // every ordinary global load above has been consumed: from here on the vm counter only sees our DMA pieces
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
