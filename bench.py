@@ -29,6 +29,21 @@ PAIR_HEADS_GFLOP_PER_DOC = 194.31   # heads L1 192.90 + L2 1.41: what one pair_h
 PEAK_BF16_TFLOPS = 2500.0           # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic_bytes(kernel_key: str, docs_per_gpu: int):
+    """HBM bytes per launch of the roofline kernel from the committed PMC collection (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes of tools/run_pair.py, the same launch this benchmark
+    times, with the gfx950 corrections of MI355X_MICROARCH.md).  bench.py cannot run rocprofv3 on itself, so the number
+    is the recorded one and only reported when it was taken at this workload; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel_key)
+        if rec and rec.get("docs_per_launch") == docs_per_gpu:
+            return int(rec["traffic_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def build_model(size: str, dtype):
     from seeded import layoutlmv3_config, peneo_config
     from peneo_amd.model import PEneoConfig, PEneoModel
@@ -164,7 +179,8 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma", "kernel": "pair_heads_fwd_kernel<bf16,24>" if args.dtype == "bf16" else "pair_heads_fwd_kernel<f32,24>",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" else None,
                          "avg_launch_ms": round(ph_ms, 4), "launches": len(ph)},
             "forward_only": {"ms_per_batch": round(fwd_ms, 3), "docs_per_s": round(B * 1e3 / fwd_ms, 1),
                              "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
