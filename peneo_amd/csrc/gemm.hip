@@ -229,11 +229,42 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
   store8_any(p.C, p.c_dtype, ci, v);
 }
 
+// Per-thread operands of the pair-dz epilogue, fetched at kernel start so their latency hides under the k loop:
+// the scaled dlogits of row (tid & 127) for the tile's first (tid < 128) / second head, and the second-layer weights
+// and first-layer bias of the thread's 8 columns.
+struct DzPre { float g[3]; float w2c[3][8]; float b1v[8]; };
+__device__ __forceinline__ void dz_prefetch(const GemmParams& p, int m0, int n0, int tid, DzPre& d) {
+  const peneo_pair_dz_args& a = p.dz;
+  const int nrem = min(GB, p.N - n0), mrem = min(GB, p.M - m0);
+  const int h_lo = n0 / a.D, h_hi = min((n0 + nrem - 1) / a.D, a.num_heads - 1);
+  const int hh = h_lo + (tid >> 7), r = tid & (GB - 1);
+  d.g[0] = 0.f; d.g[1] = 0.f; d.g[2] = 0.f;
+  if (hh <= h_hi && r < mrem) {
+    const int Cn = a.classes[hh];
+    const float sc = a.scale[hh];
+    const float* dl = a.dlogits[hh] + (int64_t)(m0 + r) * Cn;
+    d.g[0] = dl[0] * sc;
+    if (Cn > 1) d.g[1] = dl[1] * sc;
+    if (Cn > 2) d.g[2] = dl[2] * sc;
+  }
+  const int c0 = (tid & 15) * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int n = min(n0 + c0 + e, p.N - 1);
+    const int h = n / a.D, k = n - h * a.D;
+    const int Cn = a.classes[h];
+    d.w2c[0][e] = a.w2[h][k];
+    d.w2c[1][e] = Cn > 1 ? a.w2[h][(int64_t)a.D + k] : 0.f;
+    d.w2c[2][e] = Cn > 2 ? a.w2[h][(int64_t)2 * a.D + k] : 0.f;
+    d.b1v[e] = p.ep.bias ? p.ep.bias[n] : 0.f;
+  }
+}
+
 // epilogue: park the accumulators in LDS (the staging buffers are dead now), then walk the tile
 // row-major so that consecutive lanes own consecutive columns (coalesced C / residual traffic)
 // and the fused epilogue stays a compact rolled loop.
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&acc)[2][2], char* smem, int m0, int n0, int tid,
-                                              int lane, int wm, int wn) {
+                                              int lane, int wm, int wn, const DzPre& pre) {
   float* sC = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -253,19 +284,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
     const int h_lo = n0 / a.D, h_hi = min((n0 + nrem - 1) / a.D, a.num_heads - 1);
     const bool staged = (h_hi - h_lo) <= 1;         // tile spans at most 2 heads (always when D >= 128)
     if (staged) {
-      for (int i = tid; i < 2 * GB; i += 256) {
-        const int hh = h_lo + (i >> 7), r = i & (GB - 1);
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (hh <= h_hi && r < mrem) {
-          const int Cn = a.classes[hh];
-          const float sc = a.scale[hh];
-          const float* dl = a.dlogits[hh] + (int64_t)(m0 + r) * Cn;
-          g0 = dl[0] * sc;
-          if (Cn > 1) g1 = dl[1] * sc;
-          if (Cn > 2) g2 = dl[2] * sc;
-        }
-        *reinterpret_cast<float4*>(sG + i * 4) = make_float4(g0, g1, g2, 0.f);
-      }
+      *reinterpret_cast<float4*>(sG + tid * 4) = make_float4(pre.g[0], pre.g[1], pre.g[2], 0.f);
       __syncthreads();
     }
     const int cg = tid & 15, rl = tid >> 4;           // 16 column groups x 16 row lanes
@@ -278,15 +297,66 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
       const int h = n / a.D, k = n - h * a.D;
       const int Cn = a.classes[h];
       hsel[e] = h - h_lo;
-      w2c[0][e] = a.w2[h][k];
-      w2c[1][e] = Cn > 1 ? a.w2[h][(int64_t)a.D + k] : 0.f;
-      w2c[2][e] = Cn > 2 ? a.w2[h][(int64_t)2 * a.D + k] : 0.f;
-      b1v[e] = p.ep.bias ? p.ep.bias[n] : 0.f;
+      (void)k; (void)Cn;
+      w2c[0][e] = pre.w2c[0][e]; w2c[1][e] = pre.w2c[1][e]; w2c[2][e] = pre.w2c[2][e];
+      b1v[e] = pre.b1v[e];
       s0[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; sb[e] = 0.f;
     }
     const bool one_head = hsel[0] == hsel[7];
     const bool vec_store = (c0 + 8 <= nrem) && p.c_dtype == PENEO_BF16 && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                            ((p.ldc * 2) % 16 == 0);
+    if (staged && h_lo == h_hi) {
+      // common case (decoder width a multiple of the tile): one head per tile.  The loop is VALU-bound, so the
+      // full-rate arithmetic runs as packed fp32 pairs (v_pk_fma/mul/add_f32); only exp2 / rcp stay scalar.
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 w0p[4], w1p[4], w2p[4], b1p[4], s0p[4], s1p[4], s2p[4], sbp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w0p[j] = f2{w2c[0][2 * j], w2c[0][2 * j + 1]}; w1p[j] = f2{w2c[1][2 * j], w2c[1][2 * j + 1]};
+        w2p[j] = f2{w2c[2][2 * j], w2c[2][2 * j + 1]}; b1p[j] = f2{b1v[2 * j], b1v[2 * j + 1]};
+        s0p[j] = f2{0.f, 0.f}; s1p[j] = s0p[j]; s2p[j] = s0p[j]; sbp[j] = s0p[j];
+      }
+      const f2 one2 = f2{1.f, 1.f}, nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
+#pragma unroll 2
+      for (int i = 0; i < GB / 16; ++i) {
+        const int r = rl + 16 * i;
+        if (r < mrem && c0 < nrem) {
+          const float4 g4 = *reinterpret_cast<const float4*>(sG + r * 4);
+          const f2 g0 = f2{g4.x, g4.x}, g1 = f2{g4.y, g4.y}, g2 = f2{g4.z, g4.z};
+          const float4 za = *reinterpret_cast<const float4*>(sC + r * GB + c0);
+          const float4 zb = *reinterpret_cast<const float4*>(sC + r * GB + c0 + 4);
+          const f2 zin[4] = {f2{za.x, za.y}, f2{za.z, za.w}, f2{zb.x, zb.y}, f2{zb.z, zb.w}};
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f2 z = zin[j] + b1p[j];
+            const f2 t = z * nl2e;
+            const f2 ex = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            const f2 den = ex + one2;
+            const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            const f2 y = z * sg;
+            const f2 dy = __builtin_elementwise_fma(g2, w2p[j], __builtin_elementwise_fma(g1, w1p[j], g0 * w0p[j]));
+            const f2 dz = dy * (sg * __builtin_elementwise_fma(z, one2 - sg, one2));
+            s0p[j] = __builtin_elementwise_fma(g0, y, s0p[j]);
+            s1p[j] = __builtin_elementwise_fma(g1, y, s1p[j]);
+            s2p[j] = __builtin_elementwise_fma(g2, y, s2p[j]);
+            sbp[j] = sbp[j] + dz;
+            o[2 * j] = dz.x; o[2 * j + 1] = dz.y;
+          }
+          const int64_t ci = (int64_t)(m0 + r) * p.ldc + n0 + c0;
+          if (vec_store) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + ci) = pack16<bf16_t>(o);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (c0 + e < nrem) store_any(p.C, p.c_dtype, ci + e, o[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[2 * j] = s0p[j].x; s0[2 * j + 1] = s0p[j].y; s1[2 * j] = s1p[j].x; s1[2 * j + 1] = s1p[j].y;
+        s2[2 * j] = s2p[j].x; s2[2 * j + 1] = s2p[j].y; sb[2 * j] = sbp[j].x; sb[2 * j + 1] = sbp[j].y;
+      }
+    } else
 #pragma unroll 2
     for (int i = 0; i < GB / 16; ++i) {
       const int r = rl + 16 * i;
@@ -393,6 +463,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+  DzPre dzpre = {};
+  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
   const T* A = reinterpret_cast<const T*>(p.A);
   const T* B = reinterpret_cast<const T*>(p.B);
 
@@ -455,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn);
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre);
 }
 
 // ================================================================================================
@@ -521,6 +593,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
   const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
   const int tile = xcd * q8 + min(xcd, r8) + slot;
   const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
+  DzPre dzpre = {};
+  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
@@ -629,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
     wait_vm<0>();
     __syncthreads();
   }
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn);
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre);
 }
 
 __global__ void splitk_reduce_kernel(GemmParams p) {

@@ -75,13 +75,24 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, co
   const int h = (blockIdx.x / slabs) % nh;
   const int64_t b = blockIdx.x / ((int64_t)slabs * nh);
   const int i0 = slab * 32, i1 = min(Tn, i0 + 32);
-  for (int i = i0; i < i1; ++i) {
-    const float* grow = g + (((b * nh + h) * Tn + i) * ldg);
-    const int64_t brow = (b * Tn + i) * (int64_t)Tn;
+  // 4 rows per step with every load issued before the first LDS atomic: the loop is latency-bound otherwise
+  for (int i = i0; i < i1; i += 4) {
     for (int j = threadIdx.x; j < Tn; j += blockDim.x) {
-      const float v = grow[j];
-      if (bk1) atomicAdd(h1 + bk1[brow + j] * RB_REP + rep, v);
-      if (bkx) { atomicAdd(hx + bkx[brow + j] * RB_REP + rep, v); atomicAdd(hy + bky[brow + j] * RB_REP + rep, v); }
+      float v[4]; int c1[4], cx[4], cy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ii = min(i + u, i1 - 1);
+        const int64_t brow = (b * Tn + ii) * (int64_t)Tn + j;
+        v[u] = (i + u < i1) ? g[(((b * nh + h) * Tn + ii) * ldg) + j] : 0.f;
+        c1[u] = bk1 ? bk1[brow] : 0;
+        cx[u] = bkx ? bkx[brow] : 0;
+        cy[u] = bkx ? bky[brow] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (bk1) atomicAdd(h1 + c1[u] * RB_REP + rep, v[u]);
+        if (bkx) { atomicAdd(hx + cx[u] * RB_REP + rep, v[u]); atomicAdd(hy + cy[u] * RB_REP + rep, v[u]); }
+      }
     }
   }
   __syncthreads();
