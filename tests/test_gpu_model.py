@@ -191,3 +191,51 @@ def test_base_s512_matches_reference_golden():
     for n, g in fx["grads_full"].items():
         p = dict(m.named_parameters())[n]
         assert maxdiff(p.grad, g) <= 2e-3 * float(g.abs().max()) + 1e-7, n
+
+
+@pytest.mark.parametrize("which", ["lmv3_large_s1024", "lilt_base_s512"])
+def test_full_width_shapes_match_the_oracle(which):
+    """BASELINE config 4 / 5 widths (H = 1024, 16 heads, S = 1024, N = 1023, D = 512; LiLT H = 768 + 192, head dim 64 + 16)
+    with ONE encoder layer so that the CPU oracle finishes in seconds: fp32 logits / loss parity on seeded weights,
+    ragged attention masks, then a bf16 forward + backward through the same shapes."""
+    from oracle import peneo_oracle as O
+    from seeded import layoutlmv3_config, lilt_config, peneo_config, seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    if which == "lmv3_large_s1024":
+        bcfg = dict(layoutlmv3_config("large"), num_hidden_layers=1)
+        pcfg = peneo_config("layoutlmv3-base", bcfg)
+        batch = synthetic_rfund_batch(1, 1024, 256, bcfg["vocab_size"], seed=3)
+    else:
+        bcfg = dict(lilt_config("base"), num_hidden_layers=1)
+        pcfg = peneo_config("lilt-roberta-en-base", bcfg)
+        batch = synthetic_rfund_batch(2, 512, 128, bcfg["vocab_size"], seed=4)
+        batch.pop("image", None)
+        # ragged: the second document ends early (pad id 1, mask 0, zero boxes)
+        batch["input_ids"][1, 400:] = bcfg["pad_token_id"]
+        batch["attention_mask"][1, 400:] = 0
+        batch["bbox"][1, 400:] = 0
+    m = build_model(pcfg)
+    sd = m.state_dict()
+    seeded_fill_(sd, 21)
+    m = m.eval()
+    with torch.no_grad():
+        out = m(**to_cuda(batch))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.peneo_forward({k: v.cpu() for k, v in sd.items()}, pcfg, batch, training=False, as_executed=False)
+    for h in HEADS:
+        k = h + "_shaking_outputs"
+        assert maxdiff(out[k], ref[k]) < 1e-3, (k, maxdiff(out[k], ref[k]))
+        lg, rg = out[k].cpu(), ref[k]
+        top2 = rg.topk(2, dim=-1).values
+        clear = (top2[..., 0] - top2[..., 1]) > 2e-3
+        assert torch.equal(lg.argmax(-1)[clear], rg.argmax(-1)[clear]), k
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    # bf16 throughput mode through the same shapes: finite loss close to fp32, finite gradients everywhere
+    m.set_compute_dtype(torch.bfloat16)
+    o2 = m(**to_cuda(batch))
+    o2["loss"].backward()
+    assert abs(float(o2["loss"]) - float(ref["loss"])) < 3e-2 * abs(float(ref["loss"]))
+    for n, p in m.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
