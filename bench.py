@@ -24,8 +24,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 import torch  # noqa: E402
 
-FWD_GFLOP_PER_DOC = 334.7           # algorithmic, SURVEY §8(d) / BASELINE.md §3 (config 2)
-PAIR_HEADS_GFLOP_PER_DOC = 194.31   # heads L1 192.90 + L2 1.41: what one pair_heads_fwd launch computes per document
+# algorithmic GFLOP per document, SURVEY §8(d) / BASELINE.md §3: (forward total, what one pair_heads_fwd launch computes
+# = heads L1 + L2) for config 2 (LayoutLMv3-base S512), config 4 (large S1024), config 5 (LiLT-base S512)
+ALGO_GFLOP = {("layoutlmv3", "base", 512): (334.7, 192.90 + 1.41),
+              ("layoutlmv3", "large", 1024): (2269.2, 1373.05 + 7.51),
+              ("lilt", "base", 512): (300.1, 192.90 + 1.41)}
 PEAK_BF16_TFLOPS = 2500.0           # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -44,10 +47,13 @@ def pmc_traffic_bytes(kernel_key: str, docs_per_gpu: int):
     return None
 
 
-def build_model(size: str, dtype):
-    from seeded import layoutlmv3_config, peneo_config
+def build_model(size: str, dtype, backbone: str = "layoutlmv3"):
+    from seeded import layoutlmv3_config, lilt_config, peneo_config
     from peneo_amd.model import PEneoConfig, PEneoModel
-    pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config(size))
+    if backbone == "lilt":
+        pcfg = peneo_config("lilt-roberta-en-base", lilt_config(size))
+    else:
+        pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config(size))
     model = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"}))
     return model, pcfg
 
@@ -86,6 +92,8 @@ def main():
     ap.add_argument("--lines", type=int, default=128)
     ap.add_argument("--size", default="base", choices=["tiny", "base", "large"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backbone", default="layoutlmv3", choices=["layoutlmv3", "lilt"],
+                    help="lilt = BASELINE config 5 (side measurement; the headline metric is layoutlmv3 base)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-forward", action="store_true", help="time eval forward only (reported as a side metric)")
     args = ap.parse_args()
@@ -95,6 +103,7 @@ def main():
     from peneo_amd.parallel import init_distributed, max_over_ranks, wrap_data_parallel
     import torch.distributed as dist
 
+    FWD_GFLOP_PER_DOC, PAIR_HEADS_GFLOP_PER_DOC = ALGO_GFLOP.get((args.backbone, args.size, args.seq_len), (0.0, 0.0))
     rank, local_rank, world = init_distributed()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
@@ -102,7 +111,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     torch.manual_seed(1234)
-    model, pcfg = build_model(args.size, dtype)
+    model, pcfg = build_model(args.size, dtype, args.backbone)
     model = model.to(dev).set_compute_dtype(dtype).train()
     model.backbone.check_inputs = False
     net = wrap_data_parallel(model, device_ids=[local_rank]) if world > 1 else model
@@ -111,6 +120,8 @@ def main():
 
     def make_batch(step):
         b = synthetic_rfund_batch(B, args.seq_len, args.lines, vocab, seed=1000 * rank + step)
+        if args.backbone == "lilt":
+            b.pop("image", None)
         return {k: v.to(dev, non_blocking=True) for k, v in b.items()}
 
     batches = [make_batch(s) for s in range(4)]     # inputs resident in HBM before the timed region
@@ -160,7 +171,8 @@ def main():
         ph_ms = sum(ph) / max(1, len(ph))
         achieved = PAIR_HEADS_GFLOP_PER_DOC * B / ph_ms if ph_ms > 0 else 0.0      # GFLOP / ms = TFLOP/s
         res = {
-            "metric": "docs/sec fwd+bwd, LayoutLMv3-base seq512 L128",
+            "metric": "docs/sec fwd+bwd, LayoutLMv3-base seq512 L128" if (args.backbone, args.size, args.seq_len, args.lines) ==
+                      ("layoutlmv3", "base", 512, 128) else f"docs/sec fwd+bwd, {args.backbone}-{args.size} seq{args.seq_len} L{args.lines}",
             "value": round(docs / elapsed, 2),
             "unit": "docs/s",
             "n_gpus": world,
@@ -172,22 +184,22 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"LayoutLMv3-{args.size} PEneo, synthetic RFUND-shaped batch seq{args.seq_len}/"
+            "config": {"workload": f"{'LayoutLMv3' if args.backbone == 'layoutlmv3' else 'LiLT'}-{args.size} PEneo, synthetic RFUND-shaped batch seq{args.seq_len}/"
                                    f"{args.lines} lines, {B} docs/GPU, train mode (dropout 0.1), fwd+loss+bwd"
                                    f"{' + RCCL grad all-reduce (DDP, bf16 buckets)' if world > 1 else ''}",
                        "docs_per_gpu": B, "seq_len": args.seq_len, "lines": args.lines,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
-            "roofline": {"bound": "mfma", "kernel": "pair_heads_fwd_kernel<bf16,24>" if args.dtype == "bf16" else "pair_heads_fwd_kernel<f32,24>",
+            "roofline": {"bound": "mfma", "kernel": f"pair_heads_fwd_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},{pcfg['backbone_config']['hidden_size'] // 32}>",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" else None,
+                         "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
                          "avg_launch_ms": round(ph_ms, 4), "launches": len(ph)},
             "forward_only": {"ms_per_batch": round(fwd_ms, 3), "docs_per_s": round(B * 1e3 / fwd_ms, 1),
                              "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
                              "frac_of_mfma_peak": round(FWD_GFLOP_PER_DOC * B / fwd_ms / PEAK_BF16_TFLOPS, 4)},
             "train_tflops_algorithmic": round(3 * FWD_GFLOP_PER_DOC * docs / elapsed / 1e3, 1),
         }
-        if not args.no_cpu_baseline and world == 1 and args.size == "base":
+        if not args.no_cpu_baseline and world == 1 and args.size == "base" and args.backbone == "layoutlmv3":
             res["cpu_baseline"] = cpu_baseline(pcfg, args.seq_len, args.lines, seed=7)
         else:
             res["cpu_baseline"] = None
