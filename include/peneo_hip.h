@@ -191,6 +191,12 @@ int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_t* bkx, con
                           float scale, int B, int nh, int T, int Tp, const int32_t* key_mask, void* bias,
                           peneo_stream_t stream);
 /* dw*[h,bin] += scale * sum_{b,i,j in bin} g[b,h,i,j]   (g rows have stride ldg >= T) */
+/* Bias-table gradients from L per-layer bf16 dS^T buffers (layout of peneo_attn_bwd's ds_out, `layer_stride`
+ * elements apart): dS is summed over the layers in fp32, then binned.  The bucket maps are the TRANSPOSED ones,
+ * bkT[b, j, i] = bucket(i, j) (peneo_relpos_buckets on negated positions yields exactly that). */
+int peneo_relpos_bias_bwd_layers(const void* ds, int L, int64_t layer_stride, const uint8_t* bk1_t, const uint8_t* bkx_t,
+                                 const uint8_t* bky_t, float* dw1, int bins1, float* dwx, float* dwy, int bins2,
+                                 float scale, int B, int nh, int T, int Tp, peneo_stream_t stream);
 int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t* bk1, const uint8_t* bkx, const uint8_t* bky,
                           float* dw1, int bins1, float* dwx, float* dwy, int bins2,
                           float scale, int B, int nh, int T, peneo_stream_t stream);
@@ -218,13 +224,16 @@ int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const
  * Two implementations: with dtype bf16 and `dq_accum` (fp32 scratch [B*T, nh*d], overwritten) the single-pass
  * kernel runs (S / dP computed once, dQ through fp32 atomics; kt / qt / dot are not read and may be NULL);
  * otherwise (fp32, or dq_accum NULL) the dQ kernel + the dK/dV kernel run and need the per-head
- * transposed copies kt / qt / dot from peneo_head_transpose. */
+ * transposed copies kt / qt / dot from peneo_head_transpose.
+ * ds_out (single-pass only, may be NULL): bf16 [B, nh, T keys, Tp queries] receives this layer's dS^T (key-major,
+ * unscaled); with one such buffer per layer the bias-table gradient is reduced once per step by
+ * peneo_relpos_bias_bwd_layers instead of a read-modify-write of g_bias in every layer. */
 int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qkv,
                    const void* kt, const void* qt, const void* dot,
                    const void* out, const void* d_out, int64_t ld_out, const float* lse,
                    int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias,
                    void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta, float* dq_accum,
-                   float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+                   void* ds_out, float drop_p, uint32_t drop_seed, peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K11 + K12 (+ K13) — handshaking + the pair-classifier heads + class-weighted CE, fused

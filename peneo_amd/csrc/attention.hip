@@ -177,6 +177,7 @@ struct AttnParams {
   void* out; int64_t ld_out; float* lse;
   float drop_p; uint32_t seed;
   const void* d_out; void* dq; void* dk; void* dv; int64_t ld_d; float* g_bias; float* delta;
+  void* ds_out;   // single-pass backward only: bf16 dS^T [B, nh, T keys, Tp queries] of this layer (or NULL)
 };
 
 // 8 elements of row `row` starting at column c of a [rows, ld] matrix -> fragment (zero beyond rmax / cmax)
@@ -907,6 +908,17 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
       }
     }
     __syncthreads();   // dS^T tile complete
+    if (p.ds_out) {    // this layer's dS^T rows (key-major, 128 B per key and step): the bias-table gradient is reduced from
+                       // the per-layer bf16 copies once per step (peneo_relpos_bias_bwd_layers) instead of a fp32 RMW per layer
+      T* dsg = reinterpret_cast<T*>(p.ds_out) + (((int64_t)b * p.nh + h) * Tn + key0) * (int64_t)Tp + q0;
+#pragma unroll
+      for (int i = 0; i < FKEYS * (FQ / 8) / 256; ++i) {
+        const int v = tid + 256 * i;
+        const int kr = v >> 3, ch = v & 7;
+        if (key0 + kr < Tn)
+          *reinterpret_cast<uint4*>(dsg + (int64_t)kr * Tp + ch * 8) = *reinterpret_cast<const uint4*>(sS + kr * PS + ch * 16);
+      }
+    }
     // dQ[q, dcol] += dS[q, keys] . K[keys, dcol]: 2 x DT output tiles of 32 x 32 over the 4 waves
     for (int tile = wave; tile < 2 * DT; tile += 4) {
       const int qt = tile / DT, dt = tile % DT;
@@ -1127,7 +1139,7 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
                               const void* qt, const void* dot, const void* out, const void* d_out, int64_t ld_out,
                               const float* lse, int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
                               const float* key_bias, void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
-                              float* dq_accum, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+                              float* dq_accum, void* ds_out, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
   int rc = attn_common_check("peneo_attn_bwd", dtype, B, nh, T, d, bias, bias_ld);
   if (rc) return rc;
   PENEO_REQUIRE(q && k && v && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
@@ -1136,6 +1148,8 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
                ((reinterpret_cast<uintptr_t>(dq) & 15) == 0) && ((ld_dqkv * 2) % 16 == 0);
   if (!fused) dq_accum = nullptr;
   PENEO_REQUIRE(fused || (kt && qt && dot), "peneo_attn_bwd: the two-kernel path needs the transposed copies kt / qt / dot");
+  PENEO_REQUIRE(!ds_out || fused, "peneo_attn_bwd: ds_out is written by the single-pass (bf16) kernel only");
+  PENEO_REQUIRE(!ds_out || (reinterpret_cast<uintptr_t>(ds_out) & 15) == 0, "peneo_attn_bwd: ds_out must be 16-byte aligned");
   PENEO_REQUIRE(ld_qkv >= (int64_t)nh * d && ld_out >= (int64_t)nh * d && ld_dqkv >= (int64_t)nh * d, "peneo_attn_bwd: leading dims too small");
   PENEO_REQUIRE(!g_bias || bias, "peneo_attn_bwd: g_bias needs bias (it shares its row stride)");
   AttnParams p = {};
@@ -1143,7 +1157,7 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
   p.Tp = peneo_attn_padded_len(T); p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias;
   p.out = const_cast<void*>(out); p.ld_out = ld_out; p.lse = const_cast<float*>(lse);
   p.drop_p = drop_p; p.seed = drop_seed; p.d_out = d_out; p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_dqkv;
-  p.g_bias = g_bias; p.delta = delta;
+  p.g_bias = g_bias; p.delta = delta; p.ds_out = ds_out;
   return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, true, (hipStream_t)stream, dq_accum)
                              : dispatch<float>(p, true, (hipStream_t)stream, nullptr);
 }

@@ -107,8 +107,64 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, co
   }
 }
 
+// same reduction from L per-layer bf16 dS^T buffers [B, nh, T keys, Tp queries]: block = (b, h, 32-key slab)
+__global__ __launch_bounds__(256) void relpos_bias_bwd_layers_kernel(const bf16_t* ds, int L, int64_t lstride, const uint8_t* bk1,
+                                                                     const uint8_t* bkx, const uint8_t* bky, float* dw1, int bins1,
+                                                                     float* dwx, float* dwy, int bins2, float scale, int nh, int Tn,
+                                                                     int Tp) {
+  extern __shared__ float hist[];  // [bins1 | bins2 | bins2][RB_REP]
+  float* h1 = hist;
+  float* hx = h1 + bins1 * RB_REP;
+  float* hy = hx + bins2 * RB_REP;
+  const int nb = bins1 + 2 * bins2;
+  for (int i = threadIdx.x; i < nb * RB_REP; i += blockDim.x) hist[i] = 0.f;
+  __syncthreads();
+  const int rep = threadIdx.x & (RB_REP - 1);
+  const int slabs = (Tn + 31) / 32;
+  const int slab = blockIdx.x % slabs;
+  const int h = (blockIdx.x / slabs) % nh;
+  const int64_t b = blockIdx.x / ((int64_t)slabs * nh);
+  const int j0 = slab * 32, j1 = min(Tn, j0 + 32);
+  for (int j = j0; j < j1; ++j) {
+    const bf16_t* row = ds + (((b * nh + h) * Tn + j) * (int64_t)Tp);
+    const int64_t brow = (b * Tn + j) * (int64_t)Tn;
+    for (int i = threadIdx.x; i < Tn; i += blockDim.x) {
+      float v = 0.f;
+      for (int l = 0; l < L; ++l) v += bf16_to_f32(row[(int64_t)l * lstride + i]);
+      if (bk1) atomicAdd(h1 + bk1[brow + i] * RB_REP + rep, v);
+      if (bkx) { atomicAdd(hx + bkx[brow + i] * RB_REP + rep, v); atomicAdd(hy + bky[brow + i] * RB_REP + rep, v); }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RB_REP; ++r) sum += hist[i * RB_REP + ((r + i) & (RB_REP - 1))];
+    sum *= scale;
+    if (i < bins1) { if (dw1) atomicAdd(dw1 + h * bins1 + i, sum); }
+    else if (i < bins1 + bins2) { if (dwx) atomicAdd(dwx + h * bins2 + (i - bins1), sum); }
+    else if (dwy) atomicAdd(dwy + h * bins2 + (i - bins1 - bins2), sum);
+  }
+}
+
 }  // namespace peneo
 using namespace peneo;
+
+extern "C" int peneo_relpos_bias_bwd_layers(const void* ds, int L, int64_t layer_stride, const uint8_t* bk1_t,
+                                            const uint8_t* bkx_t, const uint8_t* bky_t, float* dw1, int bins1, float* dwx,
+                                            float* dwy, int bins2, float scale, int B, int nh, int T, int Tp,
+                                            peneo_stream_t stream) {
+  PENEO_REQUIRE(ds && L > 0 && B > 0 && nh > 0 && T > 0 && Tp >= T, "peneo_relpos_bias_bwd_layers: bad arguments");
+  PENEO_REQUIRE((bkx_t != nullptr) == (bky_t != nullptr), "peneo_relpos_bias_bwd_layers: 2-D inputs mismatch");
+  PENEO_REQUIRE(L == 1 || layer_stride >= (int64_t)B * nh * T * Tp, "peneo_relpos_bias_bwd_layers: layer stride too small");
+  size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2) * RB_REP;
+  PENEO_REQUIRE(sh <= 64 * 1024, "peneo_relpos_bias_bwd_layers: tables too large for LDS");
+  int slabs = (T + 31) / 32;
+  dim3 grid((unsigned)((int64_t)B * nh * slabs));
+  hipLaunchKernelGGL(relpos_bias_bwd_layers_kernel, grid, dim3(256), sh, (hipStream_t)stream, (const bf16_t*)ds, L, layer_stride,
+                     bk1_t, bkx_t, bky_t, dw1, bins1, dwx, dwy, bins2, scale, nh, T, Tp);
+  return check_launch("peneo_relpos_bias_bwd_layers");
+}
 
 extern "C" int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const int32_t* ys, int B, int T,
                                     const uint8_t* lut1, int lut1_len, int half1, const uint8_t* lut2, int lut2_len,

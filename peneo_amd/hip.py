@@ -83,13 +83,14 @@ SIGNATURES = {
     "peneo_visual_assemble_bwd": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_relpos_buckets": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_relpos_bias_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "peneo_relpos_bias_bwd_layers": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp]),
     "peneo_relpos_bias_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
     "peneo_attn_padded_len": (_i, [_i]),
     "peneo_attn_padded_dim": (_i, [_i]),
     "peneo_head_transpose": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "peneo_attn_fwd": (_i, [_i, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
     "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp,
-                            _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f, _u32, _vp]),
+                            _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _u32, _vp]),
     "peneo_pair_heads_packed_bytes": (_sz, [_i, _i, _i]),
     "peneo_pair_heads_pack": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "peneo_pair_heads_fwd": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp]),

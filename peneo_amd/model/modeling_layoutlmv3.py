@@ -105,6 +105,8 @@ class _FwdState:
         self.bias = None       # [B, nh, T, T] working dtype, already divided by sqrt(d)
         self.g_bias = None     # fp32 accumulator of dS over the layers (training only)
         self.buckets = (None, None, None)
+        self.bucket_inputs = None   # (pos_t, xs, ys, lut1, lut2): what the transposed maps are rebuilt from in backward
+        self.ds_layers = None       # bf16 [L, B, nh, T, Tp]: per-layer dS^T of the single-pass attention backward
         self.key_mask = None   # int32 [B, T]
         self.key_bias = None   # fp32 [B, Tp] additive mask, only when there is no bias tensor
         self.seeds: Optional[DropoutSeeds] = None
@@ -180,6 +182,7 @@ class _EmbedStage(torch.autograd.Function):
                 ys = torch.cat([bbox[:, :, 3].to(torch.int32), vy.unsqueeze(0).expand(B, nv)], dim=1).contiguous()
                 lut2 = model.lut("2d", cfg.rel_2d_pos_bins, cfg.max_rel_2d_pos, dev)
             st.buckets = ops.relpos_buckets(pos_t, xs, ys, B, T, lut1, cfg.rel_pos_bins // 2, lut2, cfg.rel_2d_pos_bins // 2)
+            st.bucket_inputs = (pos_t, xs, ys, lut1, lut2)
             ri = iter(rel)
             w1 = next(ri) if use1 else None
             wx = next(ri) if use2 else None
@@ -226,17 +229,27 @@ class _EmbedStage(torch.autograd.Function):
                       pad_id=cfg.pad_token_id)
         ops.colsum(d_x0.view(B * S, H), out=g[id(type_w)][0], accumulate=True)
         # rel-pos tables: every layer has accumulated its dS into st.g_bias by now
-        if st.g_bias is not None and rel:
+        if (st.g_bias is not None or st.ds_layers is not None) and rel:
             use1, use2 = cfg.has_relative_attention_bias, cfg.has_spatial_attention_bias
             ri = iter(rel)
             w1 = next(ri) if use1 else None
             wx = next(ri) if use2 else None
             wy = next(ri) if use2 else None
             d = H // cfg.num_attention_heads
-            ops.relpos_bias_bwd(st.g_bias, st.buckets[0], st.buckets[1], st.buckets[2],
-                                g[id(w1)] if w1 is not None else None, g[id(wx)] if wx is not None else None,
-                                g[id(wy)] if wy is not None else None, 1.0 / math.sqrt(d))
-            st.g_bias = None
+            gw = (g[id(w1)] if w1 is not None else None, g[id(wx)] if wx is not None else None,
+                  g[id(wy)] if wy is not None else None)
+            if st.ds_layers is not None:
+                # bf16 path: every layer stored its dS^T; transposed bucket maps = the bucket kernel on negated positions
+                pos_t, xs, ys, lut1, lut2 = st.bucket_inputs
+                neg = lambda t: (-t).contiguous() if t is not None else None
+                bt = ops.relpos_buckets(neg(pos_t), neg(xs), neg(ys), B, T, lut1, cfg.rel_pos_bins // 2, lut2,
+                                        cfg.rel_2d_pos_bins // 2)
+                ops.relpos_bias_bwd_layers(st.ds_layers, bt[0], bt[1], bt[2], gw[0], gw[1], gw[2], 1.0 / math.sqrt(d))
+                st.ds_layers = None
+            else:
+                ops.relpos_bias_bwd(st.g_bias, st.buckets[0], st.buckets[1], st.buckets[2], gw[0], gw[1], gw[2],
+                                    1.0 / math.sqrt(d))
+                st.g_bias = None
         grads = tuple(g[id(p)] if p.requires_grad else None for p in ctx.params)
         return (None, None, None, None, None, None) + grads
 
@@ -307,12 +320,22 @@ class _LayerStage(torch.autograd.Function):
         dwo = ops.gemm(d_dense1, att, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
-        if st.bias is not None and st.g_bias is None:
-            st.g_bias = torch.zeros(st.bias.shape, dtype=torch.float32, device=dev)
         dqkv = torch.empty_like(qkv)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-        ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv, st.g_bias,
-                     drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
+        ds_out = None
+        if st.bias is not None and model.rel_tables_need_grad():
+            if dt == torch.bfloat16 and H % 8 == 0:
+                # single-pass kernel: this layer's dS^T goes to its own bf16 slab (12 x 105 MB at B = 8: nothing against
+                # 288 GB); the three tables are reduced from all slabs once, in _EmbedStage.backward
+                if st.ds_layers is None:
+                    L = cfg.num_hidden_layers
+                    st.ds_layers = torch.empty((L, B, nh, T, st.bias.shape[-1]), dtype=dt, device=dev)   # every element is written
+                ds_out = st.ds_layers[idx]
+            elif st.g_bias is None:
+                st.g_bias = torch.zeros(st.bias.shape, dtype=torch.float32, device=dev)
+        ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv,
+                     st.g_bias if ds_out is None else None, drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1),
+                     ds_out=ds_out)
         dbqkv = ops.colsum(dqkv)
         dwqkv = ops.gemm(dqkv, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
@@ -364,6 +387,11 @@ class LayoutLMv3Model(nn.Module):
         if key not in self._luts:
             self._luts[key] = bucket_lut(bins, max_dist, 1024).to(dev)
         return self._luts[key]
+
+    def rel_tables_need_grad(self) -> bool:
+        enc = self.encoder
+        return any(p.requires_grad for p in (getattr(enc, "rel_pos_bias", None), getattr(enc, "rel_pos_x_bias", None),
+                                             getattr(enc, "rel_pos_y_bias", None)) if p is not None for p in p.parameters())
 
     def visual_xy(self, dev, nv: int):
         key = ("vxy", nv, str(dev))

@@ -333,6 +333,15 @@ def relpos_bias_fwd(dtype: torch.dtype, bk1, bkx, bky, w1, wx, wy, scale: float,
     return bias
 
 
+def relpos_bias_bwd_layers(ds: torch.Tensor, bk1_t, bkx_t, bky_t, dw1, dwx, dwy, scale: float) -> None:
+    """ds: bf16 [L, B, nh, T, Tp] per-layer dS^T (attn_bwd's ds_out); bk*_t: transposed bucket maps [B, T, T]."""
+    L, B, nh, T, Tp = ds.shape
+    check(lib().peneo_relpos_bias_bwd_layers(ptr(_c(ds)), L, ds.stride(0), ptr(bk1_t), ptr(bkx_t), ptr(bky_t), ptr(dw1),
+                                             dw1.shape[1] if dw1 is not None else 0, ptr(dwx), ptr(dwy),
+                                             dwx.shape[1] if dwx is not None else 0, scale, B, nh, T, Tp, stream()),
+          "peneo_relpos_bias_bwd_layers")
+
+
 def relpos_bias_bwd(g: torch.Tensor, bk1, bkx, bky, dw1, dwx, dwy, scale: float) -> None:
     B, nh, T, ldg = g.shape
     check(lib().peneo_relpos_bias_bwd(ptr(_c(g)), ldg, ptr(bk1), ptr(bkx), ptr(bky), ptr(dw1),
@@ -371,7 +380,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int,
 
 def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_bias,
              dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0,
-             single_pass: Optional[bool] = None) -> torch.Tensor:
+             single_pass: Optional[bool] = None, ds_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations).
     bf16 runs the single-pass kernel (fp32 dQ accumulator, no transposed copies); fp32 the dQ + dK/dV pair."""
     H = nh * d
@@ -392,8 +401,8 @@ def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: f
     check(lib().peneo_attn_bwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(kt), ptr(qt), ptr(dot),
                                ptr(out), ptr(d_out), out.stride(0), ptr(lse), B, nh, T, d, scale, ptr(bias),
                                bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(dq), ptr(dk), ptr(dv),
-                               dqkv.stride(0), ptr(g_bias), ptr(delta), ptr(dq_acc), drop_p, drop_seed & 0xFFFFFFFF,
-                               stream()), "peneo_attn_bwd")
+                               dqkv.stride(0), ptr(g_bias), ptr(delta), ptr(dq_acc), ptr(ds_out), drop_p,
+                               drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_bwd")
     return dqkv
 
 

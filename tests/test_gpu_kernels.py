@@ -410,6 +410,25 @@ def test_attention_bf16_single_pass_matches_two_kernel_path_with_dropout(ops, d)
         res.append((dqkv.float(), gb))
     assert rel_err(res[0][0], res[1][0]) < 2e-2
     assert rel_err(res[0][1], res[1][1]) < 2e-2
+    # per-layer dS^T copy (key-major bf16) instead of the fp32 accumulator; padding columns stay zero
+    Tp = bias.shape[-1]
+    ds = torch.full((B, nh, T, Tp), 7.0, device=DEV, dtype=torch.bfloat16)
+    dq2 = torch.zeros_like(qkv)
+    ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.11, bias, None, dq2, None, drop_p=0.2, drop_seed=9, ds_out=ds)
+    assert rel_err(dq2.float(), res[0][0]) < 1e-6
+    assert rel_err(ds[..., :T].float().transpose(2, 3), res[0][1][..., :T]) < 1e-2
+    assert float(ds[..., T:].abs().max()) == 0.0
+    # ... and the table gradients reduced from two "layers" of it equal those from the fp32 accumulator
+    w = [torch.zeros(nh, 32, device=DEV), torch.zeros(nh, 64, device=DEV), torch.zeros(nh, 64, device=DEV)]
+    w2 = [torch.zeros_like(t) for t in w]
+    gen = torch.Generator().manual_seed(3)
+    bk = [torch.randint(0, n, (B, T, T), generator=gen, dtype=torch.uint8).to(DEV) for n in (32, 64, 64)]
+    ops.relpos_bias_bwd(2 * res[0][1], bk[0], bk[1], bk[2], w[0], w[1], w[2], 0.3)
+    ds2 = torch.stack([ds, ds]).contiguous()
+    bkt = [t.transpose(1, 2).contiguous() for t in bk]
+    ops.relpos_bias_bwd_layers(ds2, bkt[0], bkt[1], bkt[2], w2[0], w2[1], w2[2], 0.3)
+    for a_, b_ in zip(w, w2):
+        assert rel_err(b_, a_) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
