@@ -275,11 +275,13 @@ int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pa
 
 /* --- building blocks of the chunked backward (rows i0..i1 of the pair triangle = pairs
  *     p(i0,i0) .. p(i1,i1)-1 of one document) ------------------------------------------- */
-/* x[p - p0, :] = SiLU(a_i + b_j)                         [npairs, D]  */
-int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, void* x, peneo_stream_t stream);
-/* du = dx * SiLU'(a_i + b_j);  d_ab_doc[i, :D] += sum_j du ; d_ab_doc[j, D:] += sum_i du   (fp32 [N, 2D]) */
+/* x[p - p0, :] = SiLU(a_i + b_j)  [npairs, D];  pre (may be NULL) receives a_i + b_j itself, the `grad_src` that lets the
+ * dx GEMM epilogue apply SiLU' (peneo_gemm_epilogue.grad_src / grad_act) */
+int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, void* x, void* pre, peneo_stream_t stream);
+/* du = dx * SiLU'(a_i + b_j)  (or du = dx when `premultiplied`: the GEMM epilogue already applied the factor);
+ * d_ab_doc[i, :D] += sum_j du ; d_ab_doc[j, D:] += sum_i du   (fp32 [N, 2D]) */
 int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* dx, float* d_ab_doc,
-                     peneo_stream_t stream);
+                     int premultiplied, peneo_stream_t stream);
 /* For the [npairs, nh*D] pre-activations z of all heads' first layers (in place):
  *   y = SiLU(z);  dy[p, h*D+k] = sum_c scale_h * dlogits_h[p, c] * w2_h[c, k];  dz = dy * SiLU'(z)  (written over z)
  * and the reductions over pairs needed by the parameter gradients are accumulated into `workspace`

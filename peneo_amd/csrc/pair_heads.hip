@@ -570,7 +570,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
 // building blocks of the chunked backward
 // ================================================================================================
 template <typename T>
-__global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pbase, int64_t npairs, T* x) {
+__global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pbase, int64_t npairs, T* x, T* pre) {
   constexpr int VEC = Elem<T>::kVec;
   const int vpr = D / VEC;
   const int64_t total = npairs * vpr;
@@ -583,7 +583,10 @@ __global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pb
     unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)i * 2 * D + c), a);
     unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)j * 2 * D + D + c), b);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) a[e] = silu_f(a[e] + b[e]);
+    for (int e = 0; e < VEC; ++e) a[e] += b[e];
+    if (pre) *reinterpret_cast<uint4*>(pre + pr * D + c) = pack16<T>(a);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = silu_f(a[e]);
     *reinterpret_cast<uint4*>(x + pr * D + c) = pack16<T>(a);
   }
 }
@@ -592,7 +595,7 @@ __global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pb
 // dx rows; a 64-thread block owns (row i, one of JSPLIT slices of j), each thread 8 (bf16) / 4 (fp32) columns with
 // 16-byte loads, 4 rows in flight; the JSPLIT partial sums meet in fp32 atomics (JSPLIT * D per row: negligible).
 constexpr int JSPLIT = 4;
-template <typename T>
+template <typename T, bool PRE>   // PRE: dx already carries the SiLU'(a_i + b_j) factor (applied by the dx GEMM epilogue)
 __global__ __launch_bounds__(256) void pair_x_bwd_a_kernel(const T* abd, int N, int D, int i0, int64_t pbase, const T* dx,
                                                           float* d_ab) {
   constexpr int VEC = Elem<T>::kVec;
@@ -614,16 +617,21 @@ __global__ __launch_bounds__(256) void pair_x_bwd_a_kernel(const T* abd, int N, 
     for (int u = 0; u < 4; ++u) {
       const int jj = min(j + u, j1 - 1);
       dv[u] = *reinterpret_cast<const uint4*>(dx + (prow + (jj - i)) * D + c);
-      bv[u] = *reinterpret_cast<const uint4*>(abd + (int64_t)jj * 2 * D + D + c);
+      if constexpr (!PRE) bv[u] = *reinterpret_cast<const uint4*>(abd + (int64_t)jj * 2 * D + D + c);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (j + u < j1) {
         float d[VEC], bj[VEC];
         unpack16<T>(dv[u], d);
-        unpack16<T>(bv[u], bj);
+        if constexpr (PRE) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s[e] += d[e] * silu_grad_f(a[e] + bj[e]);
+          for (int e = 0; e < VEC; ++e) s[e] += d[e];
+        } else {
+          unpack16<T>(bv[u], bj);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s[e] += d[e] * silu_grad_f(a[e] + bj[e]);
+        }
       }
     }
   }
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(256) void pair_x_bwd_a_kernel(const T* abd, int N, 
   for (int e = 0; e < VEC; ++e) atomicAdd(d_ab + (int64_t)i * 2 * D + c + e, s[e]);
 }
 // d_b[j, k] += sum_{i0 <= i < i1, i <= j} dx[p(i,j), k] * SiLU'(a_i[k] + b_j[k]): block = (column j, slice of i)
-template <typename T>
+template <typename T, bool PRE>
 __global__ __launch_bounds__(256) void pair_x_bwd_b_kernel(const T* abd, int N, int D, int i0, int i1, int64_t pbase, const T* dx,
                                                           float* d_ab) {
   constexpr int VEC = Elem<T>::kVec;
@@ -652,16 +660,21 @@ __global__ __launch_bounds__(256) void pair_x_bwd_b_kernel(const T* abd, int N, 
     for (int u = 0; u < 4; ++u) {
       const int ii = min(i + u, ib - 1);
       dv[u] = *reinterpret_cast<const uint4*>(dx + (pair_row_start(ii, N) + (j - ii) - pbase) * D + c);
-      av[u] = *reinterpret_cast<const uint4*>(abd + (int64_t)ii * 2 * D + c);
+      if constexpr (!PRE) av[u] = *reinterpret_cast<const uint4*>(abd + (int64_t)ii * 2 * D + c);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (i + u < ib) {
         float d[VEC], ai[VEC];
         unpack16<T>(dv[u], d);
-        unpack16<T>(av[u], ai);
+        if constexpr (PRE) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s[e] += d[e] * silu_grad_f(ai[e] + bj[e]);
+          for (int e = 0; e < VEC; ++e) s[e] += d[e];
+        } else {
+          unpack16<T>(av[u], ai);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s[e] += d[e] * silu_grad_f(ai[e] + bj[e]);
+        }
       }
     }
   }
@@ -963,19 +976,20 @@ static int chunk_check(const char* who, int dtype, int N, int D, int i0, int i1)
   return PENEO_OK;
 }
 
-extern "C" int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, void* x, peneo_stream_t stream) {
+extern "C" int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, void* x, void* pre,
+                                peneo_stream_t stream) {
   int rc = chunk_check("peneo_pair_x_fwd", dtype, N, D, i0, i1);
   if (rc) return rc;
   PENEO_REQUIRE(ab_doc && x, "peneo_pair_x_fwd: null pointer");
   const int64_t pbase = pair_row_start(i0, N), npairs = pair_row_start(i1, N) - pbase;
   const int64_t total = npairs * (D / (dtype == PENEO_BF16 ? 8 : 4));
-  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_x_fwd_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab_doc, N, D, i0, pbase, npairs, (bf16_t*)x);
-  else hipLaunchKernelGGL(pair_x_fwd_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)ab_doc, N, D, i0, pbase, npairs, (float*)x);
+  if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_x_fwd_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab_doc, N, D, i0, pbase, npairs, (bf16_t*)x, (bf16_t*)pre);
+  else hipLaunchKernelGGL(pair_x_fwd_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)ab_doc, N, D, i0, pbase, npairs, (float*)x, (float*)pre);
   return check_launch("peneo_pair_x_fwd");
 }
 
 extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* dx, float* d_ab_doc,
-                                peneo_stream_t stream) {
+                                int premultiplied, peneo_stream_t stream) {
   int rc = chunk_check("peneo_pair_x_bwd", dtype, N, D, i0, i1);
   if (rc) return rc;
   PENEO_REQUIRE(ab_doc && dx && d_ab_doc, "peneo_pair_x_bwd: null pointer");
@@ -986,13 +1000,16 @@ extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int
                 "peneo_pair_x_bwd: pointers must be 16-byte aligned");
   const int64_t pbase = pair_row_start(i0, N);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == PENEO_BF16) {
-    hipLaunchKernelGGL(pair_x_bwd_a_kernel<bf16_t>, dim3(i1 - i0, JSPLIT), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, pbase, (const bf16_t*)dx, d_ab_doc);
-    hipLaunchKernelGGL(pair_x_bwd_b_kernel<bf16_t>, dim3(N - i0, JSPLIT), dim3(threads), 0, st, (const bf16_t*)ab_doc, N, D, i0, i1, pbase, (const bf16_t*)dx, d_ab_doc);
-  } else {
-    hipLaunchKernelGGL(pair_x_bwd_a_kernel<float>, dim3(i1 - i0, JSPLIT), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, pbase, (const float*)dx, d_ab_doc);
-    hipLaunchKernelGGL(pair_x_bwd_b_kernel<float>, dim3(N - i0, JSPLIT), dim3(threads), 0, st, (const float*)ab_doc, N, D, i0, i1, pbase, (const float*)dx, d_ab_doc);
+#define PENEO_XBWD(T_, PRE_)                                                                                                   \
+  {                                                                                                                           \
+    hipLaunchKernelGGL((pair_x_bwd_a_kernel<T_, PRE_>), dim3(i1 - i0, JSPLIT), dim3(threads), 0, st, (const T_*)ab_doc, N, D, i0, \
+                       pbase, (const T_*)dx, d_ab_doc);                                                                       \
+    hipLaunchKernelGGL((pair_x_bwd_b_kernel<T_, PRE_>), dim3(N - i0, JSPLIT), dim3(threads), 0, st, (const T_*)ab_doc, N, D, i0, \
+                       i1, pbase, (const T_*)dx, d_ab_doc);                                                                   \
   }
+  if (dtype == PENEO_BF16) { if (premultiplied) PENEO_XBWD(bf16_t, true) else PENEO_XBWD(bf16_t, false) }
+  else { if (premultiplied) PENEO_XBWD(float, true) else PENEO_XBWD(float, false) }
+#undef PENEO_XBWD
   return check_launch("peneo_pair_x_bwd");
 }
 

@@ -94,8 +94,8 @@ SIGNATURES = {
     "peneo_pair_heads_packed_bytes": (_sz, [_i, _i, _i]),
     "peneo_pair_heads_pack": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "peneo_pair_heads_fwd": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp]),
-    "peneo_pair_x_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "peneo_pair_x_bwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "peneo_pair_x_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "peneo_pair_x_bwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "peneo_pair_dz_workspace_bytes": (_sz, [_i, _i]),
     "peneo_pair_dz": (_i, [_i, _vp, _i64, C.POINTER(PairDzArgs), _vp, _vp]),
     "peneo_pair_loss_partials": (_i64, [_i, _i]),

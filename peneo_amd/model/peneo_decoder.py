@@ -240,6 +240,7 @@ class _DecoderStage(torch.autograd.Function):
         # VALU-bound) runs one chunk ahead of stage 2 (dW1 and dx GEMMs + the scatter into d_ab: MFMA-bound), so the two
         # kinds of work share the CUs instead of alternating.  Buffers are double-buffered; events order the hand-offs.
         xbuf = [torch.empty((maxp, D), dtype=dt, device=dev) for _ in range(2)]
+        prebuf = [torch.empty((maxp, D), dtype=dt, device=dev) for _ in range(2)]   # a_i + b_j: SiLU' source of the dx GEMM
         zbuf = [torch.empty((maxp, nh * D), dtype=dt, device=dev) for _ in range(2)]
         dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
         w2d = [w.detach().contiguous() for w in w2s]
@@ -255,10 +256,10 @@ class _DecoderStage(torch.autograd.Function):
                 p0 = i0 * N - i0 * (i0 - 1) // 2
                 p1 = i1 * N - i1 * (i1 - 1) // 2
                 npairs = p1 - p0
-                x, z, dx = xbuf[k][:npairs], zbuf[k][:npairs], dxbuf[:npairs]
+                x, z, dx, pre = xbuf[k][:npairs], zbuf[k][:npairs], dxbuf[:npairs], prebuf[k][:npairs]
                 if idx >= 2:
                     main.wait_event(done[k])         # stage 2 of chunk idx-2 has released x[k] / z[k]
-                ops.pair_x_fwd(ab[b], i0, i1, x)
+                ops.pair_x_fwd(ab[b], i0, i1, x, pre)
                 # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
                 dza = ops.pair_dz_args(D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, scale)
                 ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
@@ -266,8 +267,9 @@ class _DecoderStage(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     side.wait_event(ready[k])
                     ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
-                    ops.gemm(z, W1cat, b_kmajor=False, out=dx)
-                    ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b])
+                    # du = (dz W1) * SiLU'(a_i + b_j) in the GEMM epilogue, then plain segmented sums into d_a / d_b
+                    ops.gemm(z, W1cat, b_kmajor=False, out=dx, grad_src=pre, grad_act=ACT_SILU)
+                    ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b], premultiplied=True)
                     done[k].record(side)
                 idx += 1
         main.wait_stream(side)

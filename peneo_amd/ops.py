@@ -465,18 +465,20 @@ def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: tor
     return logits, partials, dlog
 
 
-def pair_x_fwd(ab_doc: torch.Tensor, i0: int, i1: int, out: torch.Tensor) -> torch.Tensor:
+def pair_x_fwd(ab_doc: torch.Tensor, i0: int, i1: int, out: torch.Tensor, pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x = SiLU(a_i + b_j) for the pairs of rows i0..i1; `pre` (same shape) optionally receives a_i + b_j."""
     N, D2 = ab_doc.shape
-    check(lib().peneo_pair_x_fwd(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(out), stream()),
+    check(lib().peneo_pair_x_fwd(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(out), ptr(pre), stream()),
           "peneo_pair_x_fwd")
     return out
 
 
-def pair_x_bwd(ab_doc: torch.Tensor, i0: int, i1: int, dx: torch.Tensor, d_ab_doc: torch.Tensor) -> None:
+def pair_x_bwd(ab_doc: torch.Tensor, i0: int, i1: int, dx: torch.Tensor, d_ab_doc: torch.Tensor,
+               premultiplied: bool = False) -> None:
     N, D2 = ab_doc.shape
     assert d_ab_doc.dtype == torch.float32 and d_ab_doc.shape == ab_doc.shape
     check(lib().peneo_pair_x_bwd(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(dx), ptr(_c(d_ab_doc)),
-                                 stream()), "peneo_pair_x_bwd")
+                                 int(premultiplied), stream()), "peneo_pair_x_bwd")
 
 
 def pair_dz_workspace(nh: int, D: int, device) -> torch.Tensor:

@@ -552,6 +552,18 @@ def test_pair_backward_blocks(ops, dtype):
     dab = torch.zeros(N, 2 * D, device=DEV)
     ops.pair_x_bwd(ab, i0, i1, dx, dab)
     assert rel_err(dab, abr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    # split form used by the model: pre = a_i + b_j stored, SiLU' applied elsewhere (GEMM epilogue), plain segmented sums here
+    pre = torch.empty_like(x)
+    x2 = torch.empty_like(x)
+    ops.pair_x_fwd(ab, i0, i1, x2, pre)
+    assert torch.equal(x2, x)
+    prr = (ab.float()[ii, :D] + ab.float()[jj, D:])[p0:p1]
+    assert rel_err(pre, prr) < tol(dtype)
+    sg = torch.sigmoid(pre.float())
+    du = (dx.float() * (sg * (1 + pre.float() * (1 - sg)))).to(dtype)
+    dab2 = torch.zeros(N, 2 * D, device=DEV)
+    ops.pair_x_bwd(ab, i0, i1, du, dab2, premultiplied=True)
+    assert rel_err(dab2, abr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
     # dz block
     nh = len(classes)
     z = torch.randn(npairs, nh * D, generator=g).to(DEV).to(dtype)
