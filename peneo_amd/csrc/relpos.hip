@@ -130,7 +130,13 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_layers_kernel(const bf16_
     const int64_t brow = (b * Tn + j) * (int64_t)Tn;
     for (int i = threadIdx.x; i < Tn; i += blockDim.x) {
       float v = 0.f;
-      for (int l = 0; l < L; ++l) v += bf16_to_f32(row[(int64_t)l * lstride + i]);
+      int l = 0;
+      for (; l + 4 <= L; l += 4) {   // four layers in flight per step (the loop is latency-bound otherwise)
+        const bf16_t r0 = row[(int64_t)l * lstride + i], r1 = row[(int64_t)(l + 1) * lstride + i];
+        const bf16_t r2 = row[(int64_t)(l + 2) * lstride + i], r3 = row[(int64_t)(l + 3) * lstride + i];
+        v += (bf16_to_f32(r0) + bf16_to_f32(r1)) + (bf16_to_f32(r2) + bf16_to_f32(r3));
+      }
+      for (; l < L; ++l) v += bf16_to_f32(row[(int64_t)l * lstride + i]);
       if (bk1) atomicAdd(h1 + bk1[brow + i] * RB_REP + rep, v);
       if (bkx) { atomicAdd(hx + bkx[brow + i] * RB_REP + rep, v); atomicAdd(hy + bky[brow + i] * RB_REP + rep, v); }
     }
