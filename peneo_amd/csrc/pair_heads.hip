@@ -591,6 +591,34 @@ __global__ void pair_x_fwd_kernel(const T* abd, int N, int D, int i0, int64_t pb
   }
 }
 
+// row-based variant (16-byte aligned, D / VEC <= 256): block = (row i, slice of 64 columns j); a_i stays in registers,
+// no per-element pair decode, every store a full 16-byte vector of a contiguous pair row
+constexpr int XF_JCH = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void pair_x_fwd_rows_kernel(const T* abd, int N, int D, int i0, int64_t pbase, T* x, T* pre) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int vpr = D / VEC, nj = 256 / vpr;
+  const int cv = threadIdx.x % vpr, jl = threadIdx.x / vpr;
+  if (jl >= nj) return;
+  const int i = i0 + blockIdx.x;
+  const int jb = i + blockIdx.y * XF_JCH, je = min(N, jb + XF_JCH);
+  if (jb >= N) return;
+  const int c = cv * VEC;
+  float a[VEC];
+  unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)i * 2 * D + c), a);
+  const int64_t prow = pair_row_start(i, N) - pbase - i;
+  for (int j = jb + jl; j < je; j += nj) {
+    float b[VEC], s[VEC];
+    unpack16<T>(*reinterpret_cast<const uint4*>(abd + (int64_t)j * 2 * D + D + c), b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) b[e] += a[e];
+    if (pre) *reinterpret_cast<uint4*>(pre + (prow + j) * D + c) = pack16<T>(b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = silu_f(b[e]);
+    *reinterpret_cast<uint4*>(x + (prow + j) * D + c) = pack16<T>(s);
+  }
+}
+
 // d_a[i, k] += sum_{j >= i} dx[p(i,j), k] * SiLU'(a_i[k] + b_j[k]).  Rows of the triangle are contiguous runs of
 // dx rows; a 64-thread block owns (row i, one of JSPLIT slices of j), each thread 8 (bf16) / 4 (fp32) columns with
 // 16-byte loads, 4 rows in flight; the JSPLIT partial sums meet in fp32 atomics (JSPLIT * D per row: negligible).
@@ -983,6 +1011,14 @@ extern "C" int peneo_pair_x_fwd(int dtype, const void* ab_doc, int N, int D, int
   PENEO_REQUIRE(ab_doc && x, "peneo_pair_x_fwd: null pointer");
   const int64_t pbase = pair_row_start(i0, N), npairs = pair_row_start(i1, N) - pbase;
   const int64_t total = npairs * (D / (dtype == PENEO_BF16 ? 8 : 4));
+  const int vec = dtype == PENEO_BF16 ? 8 : 4;
+  if (D / vec <= 256 && (reinterpret_cast<uintptr_t>(ab_doc) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(pre) & 15) == 0) {
+    dim3 grid(i1 - i0, (N - i0 + XF_JCH - 1) / XF_JCH);
+    if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_x_fwd_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab_doc, N, D, i0, pbase, (bf16_t*)x, (bf16_t*)pre);
+    else hipLaunchKernelGGL(pair_x_fwd_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)ab_doc, N, D, i0, pbase, (float*)x, (float*)pre);
+    return check_launch("peneo_pair_x_fwd");
+  }
   if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_x_fwd_kernel<bf16_t>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab_doc, N, D, i0, pbase, npairs, (bf16_t*)x, (bf16_t*)pre);
   else hipLaunchKernelGGL(pair_x_fwd_kernel<float>, dim3(cap_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)ab_doc, N, D, i0, pbase, npairs, (float*)x, (float*)pre);
   return check_launch("peneo_pair_x_fwd");
