@@ -13,6 +13,7 @@ backward are sequences of HIP kernel launches on the current stream:
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -303,21 +304,34 @@ class _LayerStage(torch.autograd.Function):
         f32 = lambda p: torch.zeros(p.shape, dtype=torch.float32, device=dev)
         d_out = d_out.contiguous()
 
+        # The parameter-gradient work (wgrad GEMMs, bias column sums) is off the activation-gradient critical path: it
+        # goes to a second HIP stream and fills the CUs the small / tail-heavy critical-path kernels leave idle.  The
+        # main stream joins the side stream before the stage returns (autograd consumes the gradients on main).
+        main = torch.cuda.current_stream()
+        side = model.side_stream(dev) if model.wgrad_on_side_stream else None
+
+        def on_side(fn):
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                return fn()
+
+        wgrad = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
         dg2, db2 = f32(g2), f32(b2)
         d_h2 = ops.layernorm_bwd(d_out, h2, g2, m2, r2, dg2, db2)
         d_dense2 = ops.copy2d(d_h2, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3)) if seeds.p_hidden > 0 else d_h2
-        dbo2 = ops.colsum(d_dense2)
-        dwo2 = ops.gemm(d_dense2, inter, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        dbo2, dwo2 = on_side(lambda: (ops.colsum(d_dense2), wgrad(d_dense2, inter)))
         d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
-        dbi = ops.colsum(d_zi)
-        dwi = ops.gemm(d_zi, a, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        dbi, dwi = on_side(lambda: (ops.colsum(d_zi), wgrad(d_zi, a)))
         d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
 
         dg1, db1 = f32(g1), f32(b1)
         d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1)
         d_dense1 = ops.copy2d(d_h1, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2)) if seeds.p_hidden > 0 else d_h1
-        dbo = ops.colsum(d_dense1)
-        dwo = ops.gemm(d_dense1, att, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        dbo, dwo = on_side(lambda: (ops.colsum(d_dense1), wgrad(d_dense1, att)))
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
         dqkv = torch.empty_like(qkv)
@@ -336,9 +350,10 @@ class _LayerStage(torch.autograd.Function):
         ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv,
                      st.g_bias if ds_out is None else None, drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1),
                      ds_out=ds_out)
-        dbqkv = ops.colsum(dqkv)
-        dwqkv = ops.gemm(dqkv, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        dbqkv, dwqkv = on_side(lambda: (ops.colsum(dqkv), wgrad(dqkv, x)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
+        if side is not None:
+            main.wait_stream(side)
         grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, db1,
                  dwi, dbi, dwo2, dbo2, dg2, db2)
         grads = tuple(gr if p.requires_grad else None for gr, p in zip(grads, ctx.params))
@@ -379,6 +394,7 @@ class LayoutLMv3Model(nn.Module):
             self.norm = nn.LayerNorm(H, eps=1e-6)
         self.weight_cache = WeightCache()
         self.compute_dtype = torch.float32
+        self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
         self._luts = {}
 
     # ---- small host-side constants ---------------------------------------------------------
@@ -386,6 +402,12 @@ class LayoutLMv3Model(nn.Module):
         key = (kind, bins, max_dist, str(dev))
         if key not in self._luts:
             self._luts[key] = bucket_lut(bins, max_dist, 1024).to(dev)
+        return self._luts[key]
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        key = ("side", str(device))
+        if key not in self._luts:
+            self._luts[key] = torch.cuda.Stream(device=device)
         return self._luts[key]
 
     def rel_tables_need_grad(self) -> bool:
