@@ -246,9 +246,13 @@ class _DecoderStage(torch.autograd.Function):
         w2d = [w.detach().contiguous() for w in w2s]
         main = torch.cuda.current_stream()
         side = dec.side_stream(dev)
+        third = dec.side_stream(dev, 1) if dec.three_streams else None   # the weight-gradient GEMM on its own stream
         ready = [torch.cuda.Event() for _ in range(2)]
         done = [torch.cuda.Event() for _ in range(2)]
+        done_w = [torch.cuda.Event() for _ in range(2)]
         side.wait_stream(main)                       # d_ab / dW1cat zero fills, ab, weights
+        if third is not None:
+            third.wait_stream(main)
         idx = 0
         for b in range(B):
             for (i0, i1) in chunks:
@@ -259,20 +263,33 @@ class _DecoderStage(torch.autograd.Function):
                 x, z, dx, pre = xbuf[k][:npairs], zbuf[k][:npairs], dxbuf[:npairs], prebuf[k][:npairs]
                 if idx >= 2:
                     main.wait_event(done[k])         # stage 2 of chunk idx-2 has released x[k] / z[k]
+                    if third is not None:
+                        main.wait_event(done_w[k])
                 ops.pair_x_fwd(ab[b], i0, i1, x, pre)
                 # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
                 dza = ops.pair_dz_args(D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, scale)
                 ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
                 ready[k].record(main)
+                if third is not None:
+                    with torch.cuda.stream(third):
+                        third.wait_event(ready[k])
+                        ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
+                        done_w[k].record(third)
                 with torch.cuda.stream(side):
                     side.wait_event(ready[k])
-                    ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
+                    if idx > 0:
+                        side.wait_event(done_x)      # dxbuf is single-buffered: the previous chunk's scatter has read it
+                    if third is None:
+                        ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
                     # du = (dz W1) * SiLU'(a_i + b_j) in the GEMM epilogue, then plain segmented sums into d_a / d_b
                     ops.gemm(z, W1cat, b_kmajor=False, out=dx, grad_src=pre, grad_act=ACT_SILU)
                     ops.pair_x_bwd(ab[b], i0, i1, dx, d_ab[b], premultiplied=True)
                     done[k].record(side)
+                    done_x = done[k]
                 idx += 1
         main.wait_stream(side)
+        if third is not None:
+            main.wait_stream(third)
         dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
         db2cat = sv["dls"]
         # back through the [a | b] projection and the shrink MLP
@@ -310,9 +327,9 @@ class _DecoderStage(torch.autograd.Function):
 class PEneoDecoder(nn.Module):
     """PEneo pair extraction downstream head (reference :201-443)."""
 
-    def side_stream(self, device) -> "torch.cuda.Stream":
-        """Second HIP stream of the chunked backward (created once per device)."""
-        key = str(device)
+    def side_stream(self, device, which: int = 0) -> "torch.cuda.Stream":
+        """Extra HIP streams of the chunked backward (created once per device)."""
+        key = (str(device), which)
         streams = self.__dict__.setdefault("_side_streams", {})
         if key not in streams:
             streams[key] = torch.cuda.Stream(device=device)
@@ -361,6 +378,7 @@ class PEneoDecoder(nn.Module):
         # pairs per backward chunk: the z / dz buffer is chunk x 5D (a whole base document is 0.5 GB in bf16, small against
         # 288 GB of HBM), and long launches amortise tile tails and the split-k reduction of the weight-gradient GEMM
         self.bwd_chunk_pairs = int(os.environ.get("PENEO_BWD_CHUNK_PAIRS", 1 << 18))
+        self.three_streams = os.environ.get("PENEO_DEC_STREAMS", "2") == "3"   # measured: no gain over two
         self._ratio = {}
 
     def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
