@@ -108,6 +108,8 @@ class _FwdState:
         self.buckets = (None, None, None)
         self.bucket_inputs = None   # (pos_t, xs, ys, lut1, lut2): what the transposed maps are rebuilt from in backward
         self.ds_layers = None       # bf16 [L, B, nh, T, Tp]: per-layer dS^T of the single-pass attention backward
+        self.rel_grads = None       # fp32 (dw1, dwx, dwy) filled group by group from ds_layers on the side stream
+        self.bucket_t = None        # transposed bucket maps (built when the first group is reduced)
         self.key_mask = None   # int32 [B, T]
         self.key_bias = None   # fp32 [B, Tp] additive mask, only when there is no bias tensor
         self.seeds: Optional[DropoutSeeds] = None
@@ -240,13 +242,13 @@ class _EmbedStage(torch.autograd.Function):
             gw = (g[id(w1)] if w1 is not None else None, g[id(wx)] if wx is not None else None,
                   g[id(wy)] if wy is not None else None)
             if st.ds_layers is not None:
-                # bf16 path: every layer stored its dS^T; transposed bucket maps = the bucket kernel on negated positions
-                pos_t, xs, ys, lut1, lut2 = st.bucket_inputs
-                neg = lambda t: (-t).contiguous() if t is not None else None
-                bt = ops.relpos_buckets(neg(pos_t), neg(xs), neg(ys), B, T, lut1, cfg.rel_pos_bins // 2, lut2,
-                                        cfg.rel_2d_pos_bins // 2)
-                ops.relpos_bias_bwd_layers(st.ds_layers, bt[0], bt[1], bt[2], gw[0], gw[1], gw[2], 1.0 / math.sqrt(d))
-                st.ds_layers = None
+                # bf16 path: the layer stages already reduced their dS^T slabs group by group (side stream, joined by every
+                # layer stage before it returned) into st.rel_grads
+                torch.cuda.current_stream().wait_stream(model.side_stream(d_emb.device, "rel"))
+                for dst, src in zip(gw, st.rel_grads):
+                    if dst is not None and src is not None:
+                        dst.add_(src)
+                st.ds_layers, st.rel_grads, st.bucket_t = None, None, None
             else:
                 ops.relpos_bias_bwd(st.g_bias, st.buckets[0], st.buckets[1], st.buckets[2], gw[0], gw[1], gw[2],
                                     1.0 / math.sqrt(d))
@@ -350,6 +352,16 @@ class _LayerStage(torch.autograd.Function):
         ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv,
                      st.g_bias if ds_out is None else None, drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1),
                      ds_out=ds_out)
+        if ds_out is not None and idx % model.rel_group == 0:
+            # the bias-table gradient of layers idx .. idx+group-1 (their dS^T slabs are complete): LDS-atomic bound, so it
+            # runs beside the GEMMs of the remaining layers instead of as one ~1 ms tail after layer 0
+            hi = min(idx + model.rel_group, cfg.num_hidden_layers)
+            rel_stream = model.side_stream(dev, "rel")       # its own stream: joined only by _EmbedStage.backward
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(rel_stream):
+                rel_stream.wait_event(ev)
+                model.reduce_rel_group(st, idx, hi, B, T)
         dbqkv, dwqkv = on_side(lambda: (ops.colsum(dqkv), wgrad(dqkv, x)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
         if side is not None:
@@ -395,6 +407,8 @@ class LayoutLMv3Model(nn.Module):
         self.weight_cache = WeightCache()
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
+        self.rel_group = int(os.environ.get("PENEO_REL_GROUP", "1000"))   # layers per bias-table reduction; groups of 4 run beside the
+        # remaining layers but measured slower (285 vs 302 docs/s): the histogram kernel crowds the GEMMs off the CUs
         self._luts = {}
 
     # ---- small host-side constants ---------------------------------------------------------
@@ -404,11 +418,29 @@ class LayoutLMv3Model(nn.Module):
             self._luts[key] = bucket_lut(bins, max_dist, 1024).to(dev)
         return self._luts[key]
 
-    def side_stream(self, device) -> "torch.cuda.Stream":
-        key = ("side", str(device))
+    def side_stream(self, device, which: str = "wgrad") -> "torch.cuda.Stream":
+        key = ("side", which, str(device))
         if key not in self._luts:
             self._luts[key] = torch.cuda.Stream(device=device)
         return self._luts[key]
+
+    def reduce_rel_group(self, st, lo: int, hi: int, B: int, T: int) -> None:
+        """Bias-table gradients of layers lo..hi-1 from their bf16 dS^T slabs (runs on the caller's current stream)."""
+        cfg = self.config
+        d = cfg.hidden_size // cfg.num_attention_heads
+        nh = cfg.num_attention_heads
+        dev = st.ds_layers.device
+        if st.bucket_t is None:   # transposed bucket maps = the bucket kernel on negated positions
+            pos_t, xs, ys, lut1, lut2 = st.bucket_inputs
+            neg = lambda t: (-t).contiguous() if t is not None else None
+            st.bucket_t = ops.relpos_buckets(neg(pos_t), neg(xs), neg(ys), B, T, lut1, cfg.rel_pos_bins // 2, lut2,
+                                             cfg.rel_2d_pos_bins // 2)
+            z = lambda on, bins: torch.zeros((nh, bins), dtype=torch.float32, device=dev) if on else None
+            st.rel_grads = (z(cfg.has_relative_attention_bias, cfg.rel_pos_bins),
+                            z(cfg.has_spatial_attention_bias, cfg.rel_2d_pos_bins),
+                            z(cfg.has_spatial_attention_bias, cfg.rel_2d_pos_bins))
+        bt, rg = st.bucket_t, st.rel_grads
+        ops.relpos_bias_bwd_layers(st.ds_layers[lo:hi], bt[0], bt[1], bt[2], rg[0], rg[1], rg[2], 1.0 / math.sqrt(d))
 
     def rel_tables_need_grad(self) -> bool:
         enc = self.encoder
