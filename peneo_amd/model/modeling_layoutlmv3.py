@@ -115,6 +115,28 @@ class _FwdState:
         self.seeds: Optional[DropoutSeeds] = None
         self.dtype = torch.float32
         self.dims = None       # (B, S, T)
+        self.children = None   # per-stream slices of this state when the encoder runs document groups on several streams
+
+    def child(self, k: int, n: int) -> "_FwdState":
+        """State of document group k of n (documents are independent): slices of the shared tensors, own gradient buffers,
+        own dropout streams."""
+        import copy
+        B, S, T = self.dims
+        Bh = B // n
+        sl = slice(k * Bh, (k + 1) * Bh)
+        c = _FwdState()
+        c.dtype, c.dims = self.dtype, (Bh, S, T)
+        c.bias = self.bias[sl] if self.bias is not None else None
+        c.key_bias = self.key_bias[sl] if self.key_bias is not None else None
+        c.key_mask = self.key_mask[sl] if self.key_mask is not None else None
+        c.buckets = tuple(t[sl] if t is not None else None for t in self.buckets)
+        if self.bucket_inputs is not None:
+            pos_t, xs, ys, lut1, lut2 = self.bucket_inputs
+            cut = lambda t: t[sl].contiguous() if t is not None else None
+            c.bucket_inputs = (cut(pos_t), cut(xs), cut(ys), lut1, lut2)
+        c.seeds = copy.copy(self.seeds)
+        c.seeds.base = (self.seeds.base ^ ((k + 1) * 0x9E3779B9)) & 0xFFFFFFFF
+        return c
 
 
 # ------------------------------------------------------------------------------------------------
@@ -232,7 +254,10 @@ class _EmbedStage(torch.autograd.Function):
                       pad_id=cfg.pad_token_id)
         ops.colsum(d_x0.view(B * S, H), out=g[id(type_w)][0], accumulate=True)
         # rel-pos tables: every layer has accumulated its dS into st.g_bias by now
-        if (st.g_bias is not None or st.ds_layers is not None) and rel:
+        for stc in (st.children or [st]):
+            if not ((stc.g_bias is not None or stc.ds_layers is not None) and rel):
+                continue
+            st_parent, st = st, stc
             use1, use2 = cfg.has_relative_attention_bias, cfg.has_spatial_attention_bias
             ri = iter(rel)
             w1 = next(ri) if use1 else None
@@ -253,6 +278,7 @@ class _EmbedStage(torch.autograd.Function):
                 ops.relpos_bias_bwd(st.g_bias, st.buckets[0], st.buckets[1], st.buckets[2], gw[0], gw[1], gw[2],
                                     1.0 / math.sqrt(d))
                 st.g_bias = None
+            st = st_parent
         grads = tuple(g[id(p)] if p.requires_grad else None for p in ctx.params)
         return (None, None, None, None, None, None) + grads
 
@@ -407,6 +433,7 @@ class LayoutLMv3Model(nn.Module):
         self.weight_cache = WeightCache()
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
+        self.enc_split = int(os.environ.get("PENEO_ENC_SPLIT", "1"))   # document groups (HIP streams) through the encoder
         self.rel_group = int(os.environ.get("PENEO_REL_GROUP", "1000"))   # layers per bias-table reduction; groups of 4 run beside the
         # remaining layers but measured slower (285 vs 302 docs/s): the histogram kernel crowds the GEMMs off the CUs
         self._luts = {}
@@ -503,7 +530,40 @@ class LayoutLMv3Model(nn.Module):
         st.seeds = DropoutSeeds(self.training, cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob)
         x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(), attention_mask.contiguous(), image,
                               *self.embed_params())
-        for i, layer in enumerate(self.encoder.layer):
-            x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
         _, _, T = st.dims
-        return (x.view(B, T, cfg.hidden_size),)
+        n = self.enc_split if (self.enc_split > 1 and B % self.enc_split == 0) else 1
+        if n == 1:
+            for i, layer in enumerate(self.encoder.layer):
+                x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
+            return (x.view(B, T, cfg.hidden_size),)
+        # Documents are independent through the encoder: run n groups of documents on n HIP streams.  The kernels of one
+        # group fill the tails / small launches of the other, in the forward and (autograd replays each stage on the
+        # stream of its forward) in the backward.  Working copies of the weights are cast on the main stream first.
+        H, dt, dev = cfg.hidden_size, st.dtype, x.device
+        for i, layer in enumerate(self.encoder.layer):
+            s_, o_ = layer.attention.self, layer.attention.output
+            self.weight_cache.cat_rows(f"L{i}.qkv", [s_.query.weight, s_.key.weight, s_.value.weight], dt)
+            self.weight_cache.get((f"L{i}.bqkv",), [s_.query.bias, s_.key.bias, s_.value.bias],
+                                  lambda: torch.cat([s_.query.bias.detach(), s_.key.bias.detach(), s_.value.bias.detach()]))
+            self.weight_cache.cast(f"L{i}.o", o_.dense.weight, dt)
+            self.weight_cache.cast(f"L{i}.i", layer.intermediate.dense.weight, dt)
+            self.weight_cache.cast(f"L{i}.o2", layer.output.dense.weight, dt)
+        main = torch.cuda.current_stream()
+        st.children = [st.child(k, n) for k in range(n)]
+        Bh = B // n
+        x3 = x.view(B, T, H)
+        streams = [self.side_stream(dev, f"enc{k}") for k in range(n)]
+        parts = []
+        for k in range(n):
+            streams[k].wait_stream(main)
+            with torch.cuda.stream(streams[k]):
+                parts.append(x3[k * Bh:(k + 1) * Bh].reshape(Bh * T, H))
+        for i, layer in enumerate(self.encoder.layer):
+            params = layer_params(layer)
+            for k in range(n):
+                with torch.cuda.stream(streams[k]):
+                    parts[k] = _LayerStage.apply(self, st.children[k], i, parts[k], *params)
+        for k in range(n):
+            main.wait_stream(streams[k])
+        x = torch.cat([p.view(Bh, T, H) for p in parts], dim=0)
+        return (x,)
