@@ -264,7 +264,7 @@ __device__ __forceinline__ void dz_prefetch(const GemmParams& p, int m0, int n0,
 // row-major so that consecutive lanes own consecutive columns (coalesced C / residual traffic)
 // and the fused epilogue stays a compact rolled loop.
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&acc)[2][2], char* smem, int m0, int n0, int tid,
-                                              int lane, int wm, int wn, const DzPre& pre) {
+                                              int lane, int wm, int wn, const DzPre& pre, int zsplit) {
   float* sC = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -445,7 +445,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
       const int r = idx >> 7, c = idx & (GB - 1);
       if (r < mrem && c < nrem) {
         const float v = sC[idx];
-        if (p.split_k > 1) p.ws[((int64_t)blockIdx.z * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
+        if (p.split_k > 1) p.ws[((int64_t)zsplit * p.M + (m0 + r)) * p.N + (n0 + c)] = v;
         else epilogue_store(p, m0 + r, n0 + c, v);
       }
     }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre);
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, blockIdx.z);
 }
 
 // ================================================================================================
@@ -588,10 +588,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
 
   // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous band of tiles
   // (n fastest) so that its L2 sees one slice of A and streams B, instead of every L2 seeing everything.
-  const int gx = gridDim.x, total = gx * gridDim.y;
-  const int lin = blockIdx.y * gx + blockIdx.x;
+  // (with split-k the k slices are part of the same linear order: the n-tiles that share one A panel of one k slice are
+  // neighbours on one XCD and hit its L2 instead of re-reading the panel from HBM)
+  const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
+  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
   const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
-  const int tile = xcd * q8 + min(xcd, r8) + slot;
+  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
+  const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
   const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
   DzPre dzpre = {};
   if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
   const int ktiles = (p.K + 63) / 64;
   int kt_begin = 0, kt_end = ktiles;
   if (p.split_k > 1) {
-    kt_begin = blockIdx.z * p.kt_per_split;
+    kt_begin = zsplit * p.kt_per_split;
     kt_end = min(ktiles, kt_begin + p.kt_per_split);
   }
   const bool ragged_k = (p.K & 63) != 0;
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
     wait_vm<0>();
     __syncthreads();
   }
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre);
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
 }
 
 __global__ void splitk_reduce_kernel(GemmParams p) {

@@ -69,7 +69,8 @@ def choose_split_k(M: int, N: int, K: int, dtype: torch.dtype) -> int:
     kt = (K + (63 if dtype == torch.bfloat16 else 31)) // (64 if dtype == torch.bfloat16 else 32)
     if tiles >= 192 or kt < 8:
         return 1
-    return max(1, min(kt // 4, (512 + tiles - 1) // tiles, 16))
+    # 512 = resident workgroups (2 per CU): never spill a few workgroups into a second, almost empty round
+    return max(1, min(kt // 4, 512 // tiles, 16))
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: bool = True,
