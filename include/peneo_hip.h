@@ -316,6 +316,12 @@ int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* cla
  * the non-zero tags of one [P, C] map into (i, j, tag, score) spots in increasing p order.
  * count: device int (number found, may exceed max_spots; only max_spots are stored).
  * ------------------------------------------------------------------------------------------ */
+/* K13 input side ("next" row f.2): dense label maps [B, P] int64 from n sparse spots (b, i, j, tag) — replaces the
+ * host loop of HandshakingTaggingScheme.spots2shaking_tag4batch (model/peneo_decoder.py:35-73, called per head by
+ * data/collator.py:156-204) and the 5.2 MB/document host-to-device copy of its result.  Last spot wins, like the
+ * host loop; *status is set to 1 when a spot lies outside [0, B) x [0, N)^2. */
+int peneo_spots_to_tags(const int32_t* spots_bijt, int n_spots, int B, int N, int64_t* tags, int32_t* status,
+                        peneo_stream_t stream);
 int peneo_spots_compact(const float* logits, int64_t P, int C, int N, int32_t* spots_ijt, float* scores,
                         int32_t* count, int max_spots, peneo_stream_t stream);
 

@@ -935,6 +935,26 @@ static int dispatch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
   }
 }
 
+// label maps from sparse spots (b, i, j, tag): the dense [B, P] int64 maps the collator builds on the host
+// (data/collator.py:156-204 -> spots2shaking_tag4batch, model/peneo_decoder.py:35-73) scattered on the device instead.
+// "Last spot wins" like the host loop: a spot is skipped when a later one addresses the same cell.
+__global__ __launch_bounds__(256) void spots_to_tags_kernel(const int32_t* spots, int n, int B, int N, int64_t* tags,
+                                                            int32_t* bad) {
+  const int64_t P = (int64_t)N * (N + 1) / 2;
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const int b = spots[4 * s], i = spots[4 * s + 1], j = spots[4 * s + 2], t = spots[4 * s + 3];
+    if (b < 0 || b >= B || i < 0 || j < 0 || i >= N || j >= N) { atomicExch(bad, 1); continue; }
+    const int64_t p = i <= j ? pair_row_start(i, N) + (j - i) : 0;   // the reference's index table is 0 below the diagonal
+    bool last = true;
+    for (int u = s + 1; u < n && last; ++u) {
+      const int b2 = spots[4 * u], i2 = spots[4 * u + 1], j2 = spots[4 * u + 2];
+      const int64_t p2 = (i2 <= j2 && i2 >= 0 && j2 < N) ? pair_row_start(i2, N) + (j2 - i2) : 0;
+      if (b2 == b && p2 == p) last = false;
+    }
+    if (last) tags[(int64_t)b * P + p] = t;
+  }
+}
+
 }  // namespace peneo
 using namespace peneo;
 
@@ -1097,4 +1117,18 @@ extern "C" int peneo_spots_compact(const float* logits, int64_t P, int C, int N,
   PENEO_REQUIRE(P == (int64_t)N * (N + 1) / 2, "peneo_spots_compact: P != N(N+1)/2");
   hipLaunchKernelGGL(spots_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, P, C, N, spots_ijt, scores, count, max_spots);
   return check_launch("peneo_spots_compact");
+}
+
+extern "C" int peneo_spots_to_tags(const int32_t* spots_bijt, int n_spots, int B, int N, int64_t* tags, int32_t* status,
+                                   peneo_stream_t stream) {
+  PENEO_REQUIRE(tags && B > 0 && N > 0 && n_spots >= 0 && (n_spots == 0 || spots_bijt), "peneo_spots_to_tags: bad arguments");
+  const int64_t P = (int64_t)N * (N + 1) / 2;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(tags, 0, sizeof(int64_t) * B * P, st) != hipSuccess) { set_error("peneo_spots_to_tags: memset failed"); return PENEO_ERR_LAUNCH; }
+  if (n_spots == 0) return PENEO_OK;
+  PENEO_REQUIRE(status, "peneo_spots_to_tags: status word missing");
+  int blocks = (n_spots + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(spots_to_tags_kernel, dim3(blocks), dim3(256), 0, st, spots_bijt, n_spots, B, N, tags, status);
+  return check_launch("peneo_spots_to_tags");
 }

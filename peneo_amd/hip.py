@@ -101,6 +101,7 @@ SIGNATURES = {
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
     "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
 }
 

@@ -550,3 +550,16 @@ def spots_compact(logits: torch.Tensor, N: int, max_spots: int = 4096):
     if n > max_spots:
         return spots_compact(logits, N, max_spots=n)
     return spots[:n], scores[:n]
+
+
+def spots_to_tags(batch_spots, N: int, device) -> torch.Tensor:
+    """[[(i, j, tag), ...] per document] -> dense label maps [B, P] int64 built on the device (K13 input side)."""
+    B = len(batch_spots)
+    flat = [(b, int(sp[0]), int(sp[1]), int(sp[2])) for b, spots in enumerate(batch_spots) for sp in spots]
+    tags = torch.empty((B, N * (N + 1) // 2), dtype=torch.int64, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    sp = torch.tensor(flat, dtype=torch.int32).view(-1, 4).to(device) if flat else None
+    check(lib().peneo_spots_to_tags(ptr(sp), len(flat), B, N, ptr(tags), ptr(status), stream()), "peneo_spots_to_tags")
+    if flat and int(status) != 0:
+        raise IndexError("spot outside the [0, N) x [0, N) pair matrix")
+    return tags

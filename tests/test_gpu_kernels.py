@@ -623,3 +623,23 @@ def test_weighted_ce_and_spots(ops):
     ref = O.spots_from_logits(logits)
     assert [tuple(r) for r in spots.cpu().tolist()] == [(i, j, t) for i, j, t, _ in ref]
     assert rel_err(scores.cpu(), torch.tensor([s for *_, s in ref])) < 1e-5
+
+
+def test_spots_to_tags_matches_the_host_loop(ops):
+    from peneo_amd.model import HandshakingTaggingScheme as S
+    N = 37
+    g = torch.Generator().manual_seed(2)
+    batch = []
+    for b in range(3):
+        spots = []
+        for _ in range(40):
+            i = int(torch.randint(0, N, (1,), generator=g)); j = int(torch.randint(i, N, (1,), generator=g))
+            spots.append((i, j, int(torch.randint(1, 3, (1,), generator=g))))
+        spots.append(spots[3][:2] + (2,)); spots.append(spots[3][:2] + (1,))      # duplicates: the last one wins
+        batch.append(spots)
+    batch.append([])                                                             # a document without spots
+    want = S.spots2shaking_tag4batch(batch, seq_len=N)
+    got = S.spots2shaking_tag4batch_device(batch, N, DEV)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+    with pytest.raises(IndexError):
+        S.spots2shaking_tag4batch_device([[(0, N, 1)]], N, DEV)
