@@ -165,6 +165,20 @@ def main():
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) * 1e3 / nf
 
+    # side metric: the optimizer step that completes a training iteration (fused multi-tensor AdamW, reference groups);
+    # not part of `value` (the metric is fwd + bwd)
+    from peneo_amd.optim import FusedAdamW, peneo_param_groups
+    model.train()
+    step(0)
+    opt = FusedAdamW(peneo_param_groups(model, 5e-5, 0.01, 30.0))
+    opt.step()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(3):
+        opt.step()
+    torch.cuda.synchronize()
+    opt_ms = (time.perf_counter() - t2) * 1e3 / 3
+
     if rank == 0:
         docs = world * B * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
@@ -197,6 +211,7 @@ def main():
             "forward_only": {"ms_per_batch": round(fwd_ms, 3), "docs_per_s": round(B * 1e3 / fwd_ms, 1),
                              "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
                              "frac_of_mfma_peak": round(FWD_GFLOP_PER_DOC * B / fwd_ms / PEAK_BF16_TFLOPS, 4)},
+            "optimizer_step_ms": round(opt_ms, 3),
             "train_tflops_algorithmic": round(3 * FWD_GFLOP_PER_DOC * docs / elapsed / 1e3, 1),
         }
         if not args.no_cpu_baseline and world == 1 and args.size == "base" and args.backbone == "layoutlmv3":

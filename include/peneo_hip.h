@@ -316,6 +316,22 @@ int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* cla
  * the non-zero tags of one [P, C] map into (i, j, tag, score) spots in increasing p order.
  * count: device int (number found, may exceed max_spots; only max_spots are stored).
  * ------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step ("next" row f.4): fused multi-tensor AdamW with per-tensor learning rate and weight decay,
+ * i.e. the four parameter groups of PEneoTrainer.create_optimizer (pipeline/trainer.py:275-330: decoder
+ * parameters at lr x peneo_downstream_speedup_ratio, no decay on biases / LayerNorm) in ONE launch.
+ * Arithmetic of torch.optim.AdamW (decoupled decay, bias-corrected moments).  The table and the two chunk maps
+ * (chunk c covers elements [chunk_index[c] * peneo_adamw_chunk_elems(), ...) of tensor chunk_tensor[c]) live in
+ * device memory and are built once.  `step` counts from 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct peneo_adamw_tensor {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+  int64_t numel; float lr; float weight_decay;
+} peneo_adamw_tensor;
+int peneo_adamw_chunk_elems(void);
+int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                     int n_chunks, float beta1, float beta2, float eps, int step, peneo_stream_t stream);
+
 /* K13 input side ("next" row f.2): dense label maps [B, P] int64 from n sparse spots (b, i, j, tag) — replaces the
  * host loop of HandshakingTaggingScheme.spots2shaking_tag4batch (model/peneo_decoder.py:35-73, called per head by
  * data/collator.py:156-204) and the 5.2 MB/document host-to-device copy of its result.  Last spot wins, like the

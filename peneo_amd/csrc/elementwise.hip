@@ -1,4 +1,5 @@
 // Memory-bound plumbing kernels: dtype casts, strided 2-D copy (+dropout), column sums.
+#include <cmath>
 #include "common.h"
 
 namespace peneo {
@@ -160,8 +161,61 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* x, int64_t ldx
   }
 }
 
+// fused multi-tensor AdamW (decoupled weight decay, torch.optim.AdamW arithmetic): one launch for every parameter of
+// every group; block = one 4096-element chunk of one tensor, per-tensor lr / weight decay from the table
+constexpr int ADAMW_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adamw_kernel(const peneo_adamw_tensor* tab, const int32_t* chunk_tensor,
+                                                    const int32_t* chunk_index, float beta1, float beta2, float eps,
+                                                    float bc1, float rsqrt_bc2) {
+  const peneo_adamw_tensor t = tab[chunk_tensor[blockIdx.x]];
+  const int64_t base = (int64_t)chunk_index[blockIdx.x] * ADAMW_CHUNK;
+  const int64_t end = min(t.numel, base + ADAMW_CHUNK);
+  const float step_size = t.lr / bc1, decay = 1.0f - t.lr * t.weight_decay;
+  const bool vec = ((reinterpret_cast<uintptr_t>(t.param) | reinterpret_cast<uintptr_t>(t.grad) |
+                     reinterpret_cast<uintptr_t>(t.exp_avg) | reinterpret_cast<uintptr_t>(t.exp_avg_sq)) & 15) == 0;
+  for (int64_t i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+    float p[4], g[4], m[4], v[4];
+    const int cnt = (int)min((int64_t)4, end - i);
+    if (vec && cnt == 4) {
+      *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(t.param + i);
+      *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(t.grad + i);
+      *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(t.exp_avg + i);
+      *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
+    } else {
+      for (int e = 0; e < cnt; ++e) { p[e] = t.param[i + e]; g[e] = t.grad[i + e]; m[e] = t.exp_avg[i + e]; v[e] = t.exp_avg_sq[i + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[e] *= decay;
+      m[e] = m[e] + (1.0f - beta1) * (g[e] - m[e]);                 // lerp, as torch does
+      v[e] = beta2 * v[e] + (1.0f - beta2) * g[e] * g[e];
+      const float denom = sqrtf(v[e]) * rsqrt_bc2 + eps;
+      p[e] -= step_size * (m[e] / denom);
+    }
+    if (vec && cnt == 4) {
+      *reinterpret_cast<float4*>(t.param + i) = *reinterpret_cast<const float4*>(p);
+      *reinterpret_cast<float4*>(t.exp_avg + i) = *reinterpret_cast<const float4*>(m);
+      *reinterpret_cast<float4*>(t.exp_avg_sq + i) = *reinterpret_cast<const float4*>(v);
+    } else {
+      for (int e = 0; e < cnt; ++e) { t.param[i + e] = p[e]; t.exp_avg[i + e] = m[e]; t.exp_avg_sq[i + e] = v[e]; }
+    }
+  }
+}
+
 }  // namespace peneo
 using namespace peneo;
+
+extern "C" int peneo_adamw_chunk_elems(void) { return ADAMW_CHUNK; }
+
+extern "C" int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                                int n_chunks, float beta1, float beta2, float eps, int step, peneo_stream_t stream) {
+  PENEO_REQUIRE(table_dev && chunk_tensor_dev && chunk_index_dev && n_chunks > 0 && step >= 1, "peneo_adamw_step: bad arguments");
+  PENEO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "peneo_adamw_step: bad hyper-parameters");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, chunk_tensor_dev, chunk_index_dev,
+                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)));
+  return check_launch("peneo_adamw_step");
+}
 
 static inline bool ok_dt(int d) { return d == PENEO_F32 || d == PENEO_BF16; }
 

@@ -35,6 +35,11 @@ class GemmEpilogue(C.Structure):
     ]
 
 
+class AdamwTensor(C.Structure):
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("numel", _i64), ("lr", _f),
+                ("weight_decay", _f)]
+
+
 class EmbedTables(C.Structure):
     _fields_ = [("word", _vp), ("type0", _vp), ("pos", _vp), ("x", _vp), ("y", _vp), ("h", _vp), ("w", _vp),
                 ("coord_size", _i), ("shape_size", _i), ("max_2d", _i), ("vocab", _i), ("max_pos", _i)]
@@ -101,6 +106,8 @@ SIGNATURES = {
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
     "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "peneo_adamw_chunk_elems": (_i, []),
+    "peneo_adamw_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
     "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
 }

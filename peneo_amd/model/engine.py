@@ -9,6 +9,15 @@ import torch
 from .. import ops
 
 
+# Bumped by optimizers that update parameters through the C ABI (peneo_amd.optim.FusedAdamW): such in-place updates do not
+# touch torch's per-tensor version counters, so the caches below also key on this epoch.
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch() -> None:
+    PARAM_EPOCH[0] += 1
+
+
 class WeightCache:
     """fp32 master parameters -> working-precision copies (cast / concatenated / re-packed on the
     device by libpeneo_hip kernels), refreshed whenever a parameter's ``_version`` changes, i.e.
@@ -19,7 +28,7 @@ class WeightCache:
 
     @staticmethod
     def _stamp(params: Sequence[torch.Tensor]) -> Tuple:
-        return tuple((p.data_ptr(), p._version) for p in params)
+        return (PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
 
     def get(self, key: Tuple, params: Sequence[torch.Tensor], build):
         stamp = self._stamp(params)

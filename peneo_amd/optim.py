@@ -1,0 +1,110 @@
+"""Optimizer step of the training loop: fused multi-tensor AdamW on the C ABI
+(``peneo_adamw_step``) and the reference's four parameter groups.
+
+Reference: ``PEneoTrainer.create_optimizer`` (pipeline/trainer.py:275-330) — parameters whose name contains
+``"peneo_decoder"`` train at ``lr * peneo_downstream_speedup_ratio``; biases and LayerNorm weights get no weight
+decay (HF ``Trainer.get_decay_parameter_names``); optimizer = AdamW.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .hip import check, lib, ptr, stream
+from .model.engine import bump_param_epoch
+
+
+def decay_parameter_names(model: nn.Module) -> List[str]:
+    """Names that receive weight decay: everything except LayerNorm parameters and biases (the HF Trainer rule)."""
+    no_decay = set()
+    for mod_name, mod in model.named_modules():
+        if isinstance(mod, nn.LayerNorm):
+            for pn, _ in mod.named_parameters(recurse=False):
+                no_decay.add(f"{mod_name}.{pn}" if mod_name else pn)
+    return [n for n, _ in model.named_parameters() if n not in no_decay and "bias" not in n]
+
+
+def peneo_param_groups(model: nn.Module, lr: float, weight_decay: float, speedup_ratio: float) -> List[Dict]:
+    """The four groups of pipeline/trainer.py:286-322, in the reference's order."""
+    decay = set(decay_parameter_names(model))
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    sel = lambda d, s: [p for n, p in named if (n in decay) == d and ("peneo_decoder" in n) == s]
+    return [
+        {"params": sel(True, True), "weight_decay": weight_decay, "lr": lr * speedup_ratio},
+        {"params": sel(False, True), "weight_decay": 0.0, "lr": lr * speedup_ratio},
+        {"params": sel(True, False), "weight_decay": weight_decay, "lr": lr},
+        {"params": sel(False, False), "weight_decay": 0.0, "lr": lr},
+    ]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """AdamW over all groups in one kernel launch per step (fp32 master parameters, contiguous fp32 gradients).
+    Learning rates may be changed between steps through ``param_groups`` (schedulers work unchanged)."""
+
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = None
+        self._step = 0
+
+    def _build(self):
+        chunk = lib().peneo_adamw_chunk_elems()
+        entries, chunk_t, chunk_i, owners = [], [], [], []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise hip.PeneoHipError("FusedAdamW needs contiguous fp32 parameters on the GPU")
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                t = len(entries)
+                entries.append((p, st, gi))
+                for c in range((p.numel() + chunk - 1) // chunk):
+                    chunk_t.append(t)
+                    chunk_i.append(c)
+        dev = entries[0][0].device
+        self._entries = entries
+        self._chunk_t = torch.tensor(chunk_t, dtype=torch.int32, device=dev)
+        self._chunk_i = torch.tensor(chunk_i, dtype=torch.int32, device=dev)
+        self._host = (hip.AdamwTensor * len(entries))()
+        self._table = torch.empty(C.sizeof(self._host), dtype=torch.uint8, device=dev)
+        self._grads = [None] * len(entries)
+        self._tables = True
+
+    def _refresh(self):
+        dirty = False
+        for k, (p, st, gi) in enumerate(self._entries):
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                raise hip.PeneoHipError("FusedAdamW: every tracked parameter needs a contiguous fp32 .grad each step")
+            group = self.param_groups[gi]
+            e = self._host[k]
+            vals = (p.data_ptr(), g.data_ptr(), float(group["lr"]), float(group["weight_decay"]))
+            if self._grads[k] != vals:
+                e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                e.numel, e.lr, e.weight_decay = p.numel(), vals[2], vals[3]
+                self._grads[k] = vals
+                dirty = True
+        if dirty:   # pointer / lr table changed (new .grad tensors, scheduler step): one small H2D copy
+            src = torch.frombuffer(memoryview(self._host).cast("B"), dtype=torch.uint8)
+            self._table.copy_(src, non_blocking=False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if self._tables is None:
+            self._build()
+        self._refresh()
+        self._step += 1
+        g0 = self.param_groups[0]
+        check(lib().peneo_adamw_step(ptr(self._table), ptr(self._chunk_t), ptr(self._chunk_i), self._chunk_t.numel(),
+                                     float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), self._step, stream()),
+              "peneo_adamw_step")
+        bump_param_epoch()   # the parameters changed in place behind torch's version counters: invalidate the working copies
+        return loss

@@ -643,3 +643,33 @@ def test_spots_to_tags_matches_the_host_loop(ops):
     assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
     with pytest.raises(IndexError):
         S.spots2shaking_tag4batch_device([[(0, N, 1)]], N, DEV)
+
+
+def test_fused_adamw_matches_torch_adamw_over_the_reference_groups(ops):
+    """Four groups of pipeline/trainer.py:286-322 (decoder lr x ratio, no decay on biases / LayerNorm), 5 steps."""
+    from peneo_amd.optim import FusedAdamW, peneo_param_groups
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Sequential(torch.nn.Linear(33, 70), torch.nn.LayerNorm(70))
+            self.peneo_decoder = torch.nn.Sequential(torch.nn.Linear(70, 5001), torch.nn.LayerNorm(5001))
+    torch.manual_seed(0)
+    a, b = Toy().to(DEV), Toy().to(DEV)
+    b.load_state_dict(a.state_dict())
+    ga = peneo_param_groups(a, 1e-3, 0.05, 30.0)
+    gb = peneo_param_groups(b, 1e-3, 0.05, 30.0)
+    assert [len(g["params"]) for g in ga] == [1, 3, 1, 3] and ga[0]["lr"] == pytest.approx(0.03) and ga[1]["weight_decay"] == 0.0
+    oa = FusedAdamW(ga, betas=(0.9, 0.98), eps=1e-6)
+    ob = torch.optim.AdamW(gb, betas=(0.9, 0.98), eps=1e-6)
+    g = torch.Generator().manual_seed(1)
+    for step in range(5):
+        for (_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            gr = torch.randn(pa.shape, generator=g).to(DEV)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        if step == 3:                       # scheduler-style lr change between steps
+            for grp in oa.param_groups + ob.param_groups:
+                grp["lr"] *= 0.5
+        oa.step(); ob.step()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_err(pa.detach(), pb.detach()) < 2e-6, n

@@ -239,3 +239,21 @@ def test_full_width_shapes_match_the_oracle(which):
     for n, p in m.named_parameters():
         if p.requires_grad and p.grad is not None:
             assert torch.isfinite(p.grad).all(), n
+
+
+def test_fused_adamw_training_steps_reduce_the_loss():
+    """Three optimizer steps on one batch with the reference's parameter groups: the C-ABI update must invalidate the
+    working-precision weight copies (loss changes and goes down)."""
+    from peneo_amd.optim import FusedAdamW, peneo_param_groups
+    fx = load_golden("lmv3_tiny")
+    m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()   # eval: dropout off, deterministic
+    b = to_cuda(fx["batch"])
+    opt = FusedAdamW(peneo_param_groups(m, 2e-4, 0.01, fx["config"]["peneo_downstream_speedup_ratio"]))
+    losses = []
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        out = m(**b)
+        out["loss"].backward()
+        losses.append(float(out["loss"].detach()))
+        opt.step()
+    assert losses[1] < losses[0] and losses[3] < losses[1], losses
