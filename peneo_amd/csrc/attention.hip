@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* src, int64
 // forward
 // ================================================================================================
 template <typename T, int DP, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DP / 16, DT = DP / 32;
   char* sK = smem;                                   // [AK][DP]
