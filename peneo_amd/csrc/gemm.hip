@@ -710,6 +710,212 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
 }
 
 // ================================================================================================
+// Two-stage kernel with the LDS -> register fragment reads scheduled by hand: the compiler's schedule re-uses one
+// fragment register set and waits (lgkmcnt) for each k-step's reads right in front of its MFMAs, exposing the LDS
+// latency four times per k-tile.  Here the reads of k-step ks+1 are issued (inline asm, two register sets) before
+// the four MFMAs of k-step ks, with counted lgkmcnt waits.
+// ================================================================================================
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+#define PENEO_DSR128(dst_, addr_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(OFF_))
+#define PENEO_DSRTR(dst_, addr_, OFF_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(OFF_))
+#define PENEO_LGKM(n_)                                           \
+  {                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #n_ ")" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  }
+
+// one operand fragment (32 rows x 16 k) as 4 dwords; k-major: one b128 read, mn-major: two transpose reads
+struct PFrag { u32x4_t v; };
+template <bool KMAJ, int OFF>
+__device__ __forceinline__ void pfrag_read(PFrag& f, uint32_t addr) {
+  if constexpr (KMAJ) {
+    PENEO_DSR128(f.v, addr, OFF);
+  } else {
+    u32x2_t lo, hi;
+    PENEO_DSRTR(lo, addr, OFF);
+    PENEO_DSRTR(hi, addr, OFF + 512);
+    f.v = u32x4_t{lo.x, lo.y, hi.x, hi.y};
+  }
+}
+__device__ __forceinline__ void pmma(const PFrag& a, const PFrag& b, f32x16_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 2 * TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
+  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
+  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
+  const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
+  const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
+  DzPre dzpre = {};
+  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  const int ktiles = (p.K + 63) / 64;
+  int kt_begin = 0, kt_end = ktiles;
+  if (p.split_k > 1) {
+    kt_begin = zsplit * p.kt_per_split;
+    kt_end = min(ktiles, kt_begin + p.kt_per_split);
+  }
+  const bool ragged_k = (p.K & 63) != 0;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = lds_addr(smem);
+  const uint32_t lbase = lds0 + wave * 4096;
+  const int64_t stepA = AK ? 128 : (int64_t)64 * p.lda * 2, stepB = BK ? 128 : (int64_t)64 * p.ldb * 2;
+  DmaSrc sa, sb;
+  auto sources = [&](int kt) {
+    const bool guard = ragged_k && kt == ktiles - 1;
+    if (AK) dma_src_kmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
+    else dma_src_mnmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
+    if (BK) dma_src_kmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
+    else dma_src_mnmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
+  };
+  auto issue = [&](int buf) {
+    const uint32_t d = lbase + buf * STAGE;
+    lds_dma_1k<0>(sa.p[0], d);
+    lds_dma_1k<0>(sa.p[1], d + 1024);
+    lds_dma_1k<0>(sa.p[2], d + 2048);
+    lds_dma_1k<0>(sa.p[3], d + 3072);
+    lds_dma_1k<0>(sb.p[0], d + TILE_BYTES);
+    lds_dma_1k<0>(sb.p[1], d + TILE_BYTES + 1024);
+    lds_dma_1k<0>(sb.p[2], d + TILE_BYTES + 2048);
+    lds_dma_1k<0>(sb.p[3], d + TILE_BYTES + 3072);
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sa.p[j] += stepA; sb.p[j] += stepB; }
+  };
+
+  // LDS byte addresses of the fragments inside stage 0 (the stage and the second 32-row block are immediates):
+  //   k-major : one address per k-step (the XOR swizzle depends on ks), second row block = +4096
+  //   mn-major: one address per row block, k-step = +4096 (pieces), second transpose read = +512
+  uint32_t aaddr[4], baddr[4];
+  {
+    const int half = lane >> 5;
+    if (AK) {
+      const int row = wm * 64 + (lane & 31), swz = (row >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) aaddr[ks] = lds0 + row * ROWB + (((2 * ks + half) ^ swz) << 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = wm * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        aaddr[i] = lds0 + (half * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
+      }
+      aaddr[2] = aaddr[3] = 0;
+    }
+    if (BK) {
+      const int row = wn * 64 + (lane & 31), swz = (row >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) baddr[ks] = lds0 + TILE_BYTES + row * ROWB + (((2 * ks + half) ^ swz) << 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = wn * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        baddr[i] = lds0 + TILE_BYTES + (half * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 +
+                   (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
+      }
+      baddr[2] = baddr[3] = 0;
+    }
+  }
+  PFrag fa[2][2], fb[2][2];   // [register set][row block]
+#define PENEO_READ_STEP(SET_, KS_, BUFOFF_)                                                                     \
+  {                                                                                                            \
+    if constexpr (AK) {                                                                                        \
+      pfrag_read<true, BUFOFF_>(fa[SET_][0], aaddr[KS_]);                                                      \
+      pfrag_read<true, BUFOFF_ + 4096>(fa[SET_][1], aaddr[KS_]);                                               \
+    } else {                                                                                                   \
+      pfrag_read<false, BUFOFF_ + (KS_) * 4096>(fa[SET_][0], aaddr[0]);                                        \
+      pfrag_read<false, BUFOFF_ + (KS_) * 4096>(fa[SET_][1], aaddr[1]);                                        \
+    }                                                                                                          \
+    if constexpr (BK) {                                                                                        \
+      pfrag_read<true, BUFOFF_>(fb[SET_][0], baddr[KS_]);                                                      \
+      pfrag_read<true, BUFOFF_ + 4096>(fb[SET_][1], baddr[KS_]);                                               \
+    } else {                                                                                                   \
+      pfrag_read<false, BUFOFF_ + (KS_) * 4096>(fb[SET_][0], baddr[0]);                                        \
+      pfrag_read<false, BUFOFF_ + (KS_) * 4096>(fb[SET_][1], baddr[1]);                                        \
+    }                                                                                                          \
+  }
+#define PENEO_MMA_STEP(SET_)                 \
+  {                                          \
+    pmma(fa[SET_][0], fb[SET_][0], acc[0][0]); \
+    pmma(fa[SET_][0], fb[SET_][1], acc[0][1]); \
+    pmma(fa[SET_][1], fb[SET_][0], acc[1][0]); \
+    pmma(fa[SET_][1], fb[SET_][1], acc[1][1]); \
+  }
+  // DS instructions per read step (for the counted waits): 4 with two k-major operands, 8 with two mn-major ones
+  constexpr int RPS = (AK ? 2 : 4) + (BK ? 2 : 4);
+#define PENEO_WAIT_NEWER()                                      \
+  {                                                             \
+    if constexpr (RPS == 4) PENEO_LGKM(4)                       \
+    else if constexpr (RPS == 6) PENEO_LGKM(6)                  \
+    else PENEO_LGKM(8)                                          \
+  }
+#define PENEO_KTILE(BUFOFF_)             \
+  {                                      \
+    PENEO_READ_STEP(0, 0, BUFOFF_)       \
+    PENEO_READ_STEP(1, 1, BUFOFF_)       \
+    PENEO_WAIT_NEWER()                   \
+    PENEO_MMA_STEP(0)                    \
+    PENEO_READ_STEP(0, 2, BUFOFF_)       \
+    PENEO_WAIT_NEWER()                   \
+    PENEO_MMA_STEP(1)                    \
+    PENEO_READ_STEP(1, 3, BUFOFF_)       \
+    PENEO_WAIT_NEWER()                   \
+    PENEO_MMA_STEP(0)                    \
+    PENEO_LGKM(0)                        \
+    PENEO_MMA_STEP(1)                    \
+  }
+
+  if (kt_begin < kt_end) {
+    sources(kt_begin);
+    issue(0);
+  }
+  wait_vm<0>();
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    if (kt + 1 < kt_end) {
+      if (ragged_k && kt + 1 == ktiles - 1) sources(kt + 1); else advance();
+      issue(1);
+    }
+    PENEO_KTILE(0)
+    wait_vm<0>();
+    __syncthreads();
+    if (kt + 1 < kt_end) {
+      if (kt + 2 < kt_end) {
+        if (ragged_k && kt + 2 == ktiles - 1) sources(kt + 2); else advance();
+        issue(0);
+      }
+      PENEO_KTILE(32768)
+      wait_vm<0>();
+      __syncthreads();
+    }
+  }
+#undef PENEO_KTILE
+#undef PENEO_WAIT_NEWER
+#undef PENEO_MMA_STEP
+#undef PENEO_READ_STEP
+  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
+}
+
+// ================================================================================================
 // Same tile, deeper pipeline: k-tiles of 32 (64 B per row), FOUR 16 KiB stages, LDS-DMA three k-tiles ahead with
 // counted vmcnt and a raw s_barrier per k-tile.  The two-stage kernel above waits for a DMA it issued one k-tile
 // (512 MFMA cycles) earlier, far less than the L2/HBM latency under load, so its MFMA pipe idles about half the time;
@@ -893,6 +1099,20 @@ static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStre
   return check_launch("peneo_gemm");
 }
 
+static int launch_gemm_dma_pipe(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
+  size_t shmem = 4 * TILE_BYTES + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
+  if (p.dz_on) {
+    if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_pipe_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
+  }
+  if (ak && bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, true>), grid, dim3(256), shmem, st, p);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, false>), grid, dim3(256), shmem, st, p);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<false, true>), grid, dim3(256), shmem, st, p);
+  else hipLaunchKernelGGL((gemm_dma_pipe_kernel<false, false>), grid, dim3(256), shmem, st, p);
+  return check_launch("peneo_gemm");
+}
+
 static int launch_gemm_dma4(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
   size_t shmem = NST4 * STAGE4 + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
   if (p.dz_on) {
@@ -982,9 +1202,12 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
     // measured (tools/run_blas_ref.py, run_gemm_shapes.py): the 4-stage pipeline wins for wgrad (both operands mn-major,
     // +4-8 %), the 2-stage one for the k-major forward shapes (FFN2 fwd 49 vs 56 us, 4096^3 945 vs 768 TFLOP/s)
     static const int forced = getenv("PENEO_GEMM_STAGES") ? atoi(getenv("PENEO_GEMM_STAGES")) : 0;
-    const int stages = forced ? forced : ((!a_kmajor && !b_kmajor) ? 4 : 2);
+    // 3 = the two-stage kernel with hand-scheduled fragment reads: >= both others on every measured shape
+    // (4096^3: 980 TN / 964 NN TFLOP/s against 945 / 831 for the compiler-scheduled two-stage kernel)
+    const int stages = forced ? forced : 3;
     rc = stages == 2 ? launch_gemm_dma(p, a_kmajor != 0, b_kmajor != 0, grid, st)
-                     : launch_gemm_dma4(p, a_kmajor != 0, b_kmajor != 0, grid, st);
+         : stages == 3 ? launch_gemm_dma_pipe(p, a_kmajor != 0, b_kmajor != 0, grid, st)   // 3 = two stages, hand-scheduled reads
+                       : launch_gemm_dma4(p, a_kmajor != 0, b_kmajor != 0, grid, st);
   }
   else
     rc = dtype == PENEO_BF16 ? launch_gemm<bf16_t>(p, a_kmajor != 0, b_kmajor != 0, grid, st)

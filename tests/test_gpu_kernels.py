@@ -72,7 +72,7 @@ def test_gemm_bf16_lds_dma_path(ops, ak, bk, M, N, K, split):
     assert rel_err(out, ref) < 1e-5, rel_err(out, ref)
 
 
-@pytest.mark.parametrize("stages", ["2", "4"])
+@pytest.mark.parametrize("stages", ["2", "3", "4"])
 def test_gemm_bf16_both_pipelines(stages):
     """The 2-stage (k-tile 64) and 4-stage (k-tile 32) LDS-DMA kernels are chosen per layout; force each one for every
     layout in a subprocess (the choice is read once per process) on ragged shapes with a k tail and split-k."""
