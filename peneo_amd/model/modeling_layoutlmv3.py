@@ -348,18 +348,23 @@ class _LayerStage(torch.autograd.Function):
                 return fn()
 
         wgrad = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
-        dg2, db2 = f32(g2), f32(b2)
+        # all small fp32 accumulators of the stage (LayerNorm and bias gradients) carved from ONE zero-filled buffer:
+        # one fill launch instead of eight fills / memsets per layer
+        I = cfg.intermediate_size
+        pool = torch.zeros(4 * H + (H + I + H + 3 * H), dtype=torch.float32, device=dev)
+        dg2, db2, dg1, db1 = pool[:H], pool[H:2 * H], pool[2 * H:3 * H], pool[3 * H:4 * H]
+        o_ = 4 * H
+        dbo2, dbi, dbo, dbqkv = pool[o_:o_ + H], pool[o_ + H:o_ + H + I], pool[o_ + H + I:o_ + 2 * H + I], pool[o_ + 2 * H + I:]
         d_h2 = ops.layernorm_bwd(d_out, h2, g2, m2, r2, dg2, db2)
         d_dense2 = ops.copy2d(d_h2, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3)) if seeds.p_hidden > 0 else d_h2
-        dbo2, dwo2 = on_side(lambda: (ops.colsum(d_dense2), wgrad(d_dense2, inter)))
+        _, dwo2 = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)))
         d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
-        dbi, dwi = on_side(lambda: (ops.colsum(d_zi), wgrad(d_zi, a)))
+        _, dwi = on_side(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
         d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
 
-        dg1, db1 = f32(g1), f32(b1)
         d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1)
         d_dense1 = ops.copy2d(d_h1, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2)) if seeds.p_hidden > 0 else d_h1
-        dbo, dwo = on_side(lambda: (ops.colsum(d_dense1), wgrad(d_dense1, att)))
+        _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
         dqkv = torch.empty_like(qkv)
@@ -388,7 +393,7 @@ class _LayerStage(torch.autograd.Function):
             with torch.cuda.stream(rel_stream):
                 rel_stream.wait_event(ev)
                 model.reduce_rel_group(st, idx, hi, B, T)
-        dbqkv, dwqkv = on_side(lambda: (ops.colsum(dqkv), wgrad(dqkv, x)))
+        _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
         if side is not None:
             main.wait_stream(side)
