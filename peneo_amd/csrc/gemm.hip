@@ -196,15 +196,26 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if (e.preact) store8_any(e.preact, p.c_dtype, (int64_t)m * e.ld_preact + n, v);
+  const bool fast = p.c_dtype == PENEO_BF16;   // bf16 tiles: polynomial erf (1.5e-7) instead of the library erff
   if (e.act != PENEO_ACT_NONE) {
+    if (fast) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = act_f(e.act, v[i]);
+      for (int i = 0; i < 8; ++i) v[i] = act_t<true>(e.act, v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = act_t<false>(e.act, v[i]);
+    }
   }
   if (e.grad_src) {
     float g[8];
     load8_any(e.grad_src, p.c_dtype, (int64_t)m * e.ld_grad + n, g);
+    if (fast) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= act_grad_f(e.grad_act, g[i]);
+      for (int i = 0; i < 8; ++i) v[i] *= act_grad_t<true>(e.grad_act, g[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= act_grad_t<false>(e.grad_act, g[i]);
+    }
   }
   if (e.drop_p > 0.f) {
     const uint32_t thresh = (uint32_t)fminf(e.drop_p * 4294967296.0f, 4294967040.0f);
