@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void pair_x_bwd_b_kernel(const T* abd, int N, 
 struct DzParams {
   peneo_pair_dz_args a;
 };
-constexpr int DZ_SLOTS = 256;   // rows of the partial-sum workspace == max workgroups per launch
+constexpr int DZ_SLOTS = 1024;  // rows of the partial-sum workspace == max workgroups per launch (4 per CU)
 // z -> dz in place; every thread owns one 16-byte column vector of the [npairs, nh*D] matrix for a strided set of rows and
 // keeps its dW2 / db1 partial sums in registers; one plain read-modify-write of the block's workspace row at the end
 // (workspace [DZ_SLOTS][4 * nh*D]: rows c*ncol.. hold sum_p dlogits[p,c]*y[p,:] for c = 0..2, row 3*ncol.. holds sum_p dz).
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzPa
   const peneo_pair_dz_args& a = pp.a;
   const int ncol = a.num_heads * a.D;
   const int nvec = ncol / VEC;
-  float* slot = ws + (int64_t)blockIdx.x * 4 * ncol;
+  float* slot = ws + (int64_t)(blockIdx.x % DZ_SLOTS) * 4 * ncol;
   for (int v = threadIdx.x; v < nvec; v += 256) {
     const int col = v * VEC;
     const int h = col / a.D, k = col - h * a.D;
@@ -737,26 +737,39 @@ __global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzPa
     for (int e = 0; e < VEC; ++e) db1[e] = 0.f;
     const float sc = a.scale[h];
     const float* dl = a.dlogits[h];
-    for (int64_t r = blockIdx.x; r < npairs; r += gridDim.x) {
-      float zv[VEC], o[VEC];
-      unpack16<T>(*reinterpret_cast<const uint4*>(z + r * ncol + col), zv);
-      float g[3];
+    // four rows in flight per step (every load issued before the first use): the loop is latency-bound otherwise
+    for (int64_t r0 = blockIdx.x; r0 < npairs; r0 += 4 * (int64_t)gridDim.x) {
+      uint4 raw[4]; float g[4][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) g[c] = (c < C) ? dl[r * C + c] * sc : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = min(r0 + u * (int64_t)gridDim.x, npairs - 1);
+        raw[u] = *reinterpret_cast<const uint4*>(z + r * ncol + col);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float sg = sigmoid_f(zv[e]);
-        const float y = zv[e] * sg;
-        const float dy = g[0] * w2[0][e] + g[1] * w2[1][e] + g[2] * w2[2][e];
-        const float dz = dy * sg * (1.f + zv[e] * (1.f - sg));
-        dw2[0][e] += g[0] * y; dw2[1][e] += g[1] * y; dw2[2][e] += g[2] * y;
-        db1[e] += dz;
-        o[e] = dz;
+        for (int c = 0; c < 3; ++c) g[u][c] = (c < C) ? dl[r * C + c] * sc : 0.f;
       }
-      *reinterpret_cast<uint4*>(z + r * ncol + col) = pack16<T>(o);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u * (int64_t)gridDim.x;
+        if (r < npairs) {
+          float zv[VEC], o[VEC];
+          if constexpr (sizeof(T) == 2) unpack16<T>(raw[u], zv);
+          else unpack16<T>(raw[u], zv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float sg = sigmoid_f(zv[e]);
+            const float y = zv[e] * sg;
+            const float dy = fmaf(g[u][2], w2[2][e], fmaf(g[u][1], w2[1][e], g[u][0] * w2[0][e]));
+            const float dz = dy * (sg * fmaf(zv[e], 1.f - sg, 1.f));
+            dw2[0][e] = fmaf(g[u][0], y, dw2[0][e]); dw2[1][e] = fmaf(g[u][1], y, dw2[1][e]); dw2[2][e] = fmaf(g[u][2], y, dw2[2][e]);
+            db1[e] += dz;
+            o[e] = dz;
+          }
+          *reinterpret_cast<uint4*>(z + r * ncol + col) = pack16<T>(o);
+        }
+      }
     }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
+    for (int e = 0; e < VEC; ++e) {   // one block per slot row: plain read-modify-write
       slot[0 * ncol + col + e] += dw2[0][e];
       slot[1 * ncol + col + e] += dw2[1][e];
       slot[2 * ncol + col + e] += dw2[2][e];

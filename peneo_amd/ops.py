@@ -483,7 +483,7 @@ def pair_x_bwd(ab_doc: torch.Tensor, i0: int, i1: int, dx: torch.Tensor, d_ab_do
 
 
 def pair_dz_workspace(nh: int, D: int, device) -> torch.Tensor:
-    """Zeroed [256, 4 * nh * D] fp32 accumulator for pair_dz (sum its rows with colsum at the end)."""
+    """Zeroed [slots, 4 * nh * D] fp32 accumulator for pair_dz (sum its rows with colsum at the end)."""
     return torch.zeros((lib().peneo_pair_dz_workspace_bytes(nh, D) // (16 * nh * D), 4 * nh * D), dtype=torch.float32,
                        device=device)
 
