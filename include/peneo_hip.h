@@ -285,7 +285,7 @@ int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int i0, int i1
 /* For the [npairs, nh*D] pre-activations z of all heads' first layers (in place):
  *   y = SiLU(z);  dy[p, h*D+k] = sum_c scale_h * dlogits_h[p, c] * w2_h[c, k];  dz = dy * SiLU'(z)  (written over z)
  * and the reductions over pairs needed by the parameter gradients are accumulated into `workspace`
- * [256][4 * nh*D] fp32 (zero it once per step; sum its 256 rows with peneo_colsum at the end):
+ * [peneo_pair_dz_workspace_bytes / (16 * nh*D)][4 * nh*D] fp32 (zero it once per step; sum its rows with peneo_colsum at the end):
  *   row block c (c = 0..2): sum_p scale_h*dlogits_h[p,c] * y[p, :]   -> dW2_h[c, :] = block[c][h*D : (h+1)*D]
  *   row block 3            : sum_p dz[p, :]                          -> db1
  * scale[h] (= d(loss) * loss_ratio_h / den_h) is a device vector. */
