@@ -221,10 +221,11 @@ int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const
 /* dq/dk/dv share the q/k/v layout (ld_dqkv).  g_bias (fp32 [B, nh, T, bias_ld], may be NULL) is
  * accumulated with dS so the bias-table gradient can be reduced once per step.
  * `delta` is a [B, nh, T] fp32 scratch.
- * Two implementations: with dtype bf16 and `dq_accum` (fp32 scratch [B*T, nh*d], overwritten) the single-pass
- * kernel runs (S / dP computed once, dQ through fp32 atomics; kt / qt / dot are not read and may be NULL);
- * otherwise (fp32, or dq_accum NULL) the dQ kernel + the dK/dV kernel run and need the per-head
- * transposed copies kt / qt / dot from peneo_head_transpose.
+ * Implementations: with dtype bf16 and `ds_out` and/or `dq_accum` the single-pass kernel runs (S / dP computed once,
+ * dK / dV in registers; kt / qt / dot are not read and may be NULL).  dQ then comes from a second kernel that multiplies
+ * the stored dS^T slab with K (ds_out given, dq_accum NULL: the faster form) or from fp32 atomics into `dq_accum`
+ * (fp32 scratch [B*T, nh*d], overwritten).  Otherwise (fp32, or both NULL) the dQ kernel + the dK/dV kernel run and
+ * need the per-head transposed copies kt / qt / dot from peneo_head_transpose.
  * ds_out (single-pass only, may be NULL): bf16 [B, nh, T keys, Tp queries] receives this layer's dS^T (key-major,
  * unscaled); with one such buffer per layer the bias-table gradient is reduced once per step by
  * peneo_relpos_bias_bwd_layers instead of a read-modify-write of g_bias in every layer. */

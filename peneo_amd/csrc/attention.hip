@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
   const T* dO = reinterpret_cast<const T*>(p.d_out) + (int64_t)b * Tn * p.ld_out + h * d;
   const T* bias = HAS_BIAS ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
   float* G = (HAS_BIAS && p.g_bias) ? p.g_bias + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
-  float* DQ = dq_acc + (int64_t)b * Tn * ((int64_t)p.nh * d) + h * d;
+  float* DQ = dq_acc ? dq_acc + (int64_t)b * Tn * ((int64_t)p.nh * d) + h * d : nullptr;
   const int64_t ldq = (int64_t)p.nh * d;
   const int keyl = wave * 32 + (lane & 31);
   const int mykey = key0 + keyl;
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
       }
     }
     // dQ[q, dcol] += dS[q, keys] . K[keys, dcol]: 2 x DT output tiles of 32 x 32 over the 4 waves
-    for (int tile = wave; tile < 2 * DT; tile += 4) {
+    for (int tile = wave; tile < 2 * DT && dq_acc != nullptr; tile += 4) {   // (no accumulator: dQ comes from the stored dS^T)
       const int qt = tile / DT, dt = tile % DT;
       f32x16_t acc;
 #pragma unroll
@@ -960,6 +960,76 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
     store_rows<T, DP>(myO, which == 0 ? DK : DV, p.ld_d, key0 + wave * 32, Tn, d, lane);
     __syncthreads();
   }
+}
+
+// dQ[q, :] = scale * sum_key dS[q, key] K[key, :] from the stored dS^T slab of this layer (key-major [B, nh, T, Tp]):
+// workgroup = 128 queries of one (b, h), streams key tiles of 64; both operands are "reduction-index-major" tiles read
+// with the hardware transpose read.  Replaces the 6-fold fp32 atomic accumulation of the single-pass kernel (a quarter of
+// its run time) by one extra read of the slab and plain bf16 stores.
+template <int DP>
+__global__ __launch_bounds__(256, 2) void attn_dq_from_ds_kernel(AttnParams p) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DT = DP / 32;
+  constexpr int PA = AQ * 2 + 16;                 // dS^T tile [AK keys][AQ queries]
+  constexpr int PK = Pitch<T, DP>::v;             // K tile [AK keys][DP]
+  char* sA = smem;
+  char* sK = sA + AK * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
+  const int Tn = p.T, d = p.d, Tp = p.Tp;
+  const T* DS = reinterpret_cast<const T*>(p.ds_out) + ((int64_t)b * p.nh + h) * Tn * (int64_t)Tp;
+  const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * d;
+  const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((p.ld * 2) % 16 == 0) && (d == DP);
+  const bool a_full = q0 + AQ <= Tp;
+  f32x16_t acc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  TileRegs<T, AK, AQ> ra;
+  TileRegs<T, AK, DP> rk;
+  const int ntile = (Tn + AK - 1) / AK;
+#define DQS_PREFETCH(t_)                                                              \
+  {                                                                                   \
+    const int k0_ = (t_) * AK;                                                        \
+    tile_load<T, AK, AQ>(ra, DS, Tp, k0_, Tn, q0, Tp, tid, a_full && k0_ + AK <= Tn); \
+    tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + AK <= Tn);    \
+  }
+  DQS_PREFETCH(0)
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();
+    tile_store<T, AK, AQ>(ra, sA, tid);
+    tile_store<T, AK, DP>(rk, sK, tid);
+    __syncthreads();
+    DQS_PREFETCH(t + 1 < ntile ? t + 1 : t)
+#pragma unroll
+    for (int kk = 0; kk < AK / 16; ++kk) {
+      const int k0 = 16 * kk + 8 * half;
+      Frag<T> af = frag_tr<PA>(sA, wave * 32, k0, k0 + 4, lane);          // rows = q, reduction = keys
+#pragma unroll
+      for (int t2 = 0; t2 < DT; ++t2) {
+        Frag<T> bf = frag_tr<PK>(sK, t2 * 32, k0, k0 + 4, lane);          // cols = dcol, reduction = keys
+        mma_step(af, bf, acc[t2]);
+      }
+    }
+  }
+#undef DQS_PREFETCH
+  __syncthreads();
+  // acc: rows = q (register index), cols = dcol (lane) -> per-wave [32 q][DP] fp32 tile -> bf16 rows of dq
+  float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) myO[acc_row(r, lane) * (DP + 1) + t * 32 + (lane & 31)] = acc[t][r] * p.scale;
+  __syncthreads();
+  T* DQ = reinterpret_cast<T*>(p.dq) + (int64_t)b * Tn * p.ld_d + h * d;
+  store_rows<T, DP>(myO, DQ, p.ld_d, q0 + wave * 32, Tn, d, lane);
+}
+template <int DP> static size_t dqs_smem() {
+  size_t a = (size_t)AK * (AQ * 2 + 16) + (size_t)AK * Pitch<bf16_t, DP>::v;
+  size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
+  return a > o ? a : o;
 }
 
 // fp32 dQ accumulator [rows][cols] -> bf16 dq rows (leading dim ld)
@@ -1032,9 +1102,10 @@ static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
   if (rc) return rc;
   if constexpr (sizeof(T) == 2) {
     const int64_t cols = (int64_t)p.nh * p.d;
-    if (dq_acc) {   // eligibility was decided by peneo_attn_bwd
+    const bool dq_from_ds = dq_acc == nullptr && p.ds_out != nullptr;   // single pass, dQ by a second kernel from dS^T
+    if (dq_acc || dq_from_ds) {   // eligibility was decided by peneo_attn_bwd
       const int64_t R = (int64_t)p.B * p.T;
-      if (hipMemsetAsync(dq_acc, 0, sizeof(float) * R * cols, st) != hipSuccess) {
+      if (dq_acc && hipMemsetAsync(dq_acc, 0, sizeof(float) * R * cols, st) != hipSuccess) {
         set_error("peneo_attn_bwd: memset of the dQ accumulator failed");
         return PENEO_ERR_LAUNCH;
       }
@@ -1053,6 +1124,14 @@ static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
 #undef PENEO_LAUNCH_FUSED
       rc = check_launch("peneo_attn_bwd(fused)");
       if (rc) return rc;
+      if (dq_from_ds) {
+        size_t sq = dqs_smem<DP>();
+        rc = set_smem(attn_dq_from_ds_kernel<DP>, sq);
+        if (rc) return rc;
+        dim3 qgrid((p.T + AQ - 1) / AQ, p.nh, p.B);
+        hipLaunchKernelGGL((attn_dq_from_ds_kernel<DP>), qgrid, dim3(256), sq, st, p);
+        return check_launch("peneo_attn_bwd(dq from dS)");
+      }
       int64_t blocks = (R * (cols / 8) + 255) / 256;
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(dq_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dq_acc, R, (int)cols,
@@ -1144,7 +1223,7 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
   if (rc) return rc;
   PENEO_REQUIRE(q && k && v && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
   // single-pass eligibility (bf16, accumulator given, dq rows writable as 16-byte vectors); otherwise the two-kernel path
-  bool fused = dtype == PENEO_BF16 && dq_accum != nullptr && (((int64_t)nh * d) % 8 == 0) &&
+  bool fused = dtype == PENEO_BF16 && (dq_accum != nullptr || ds_out != nullptr) && (((int64_t)nh * d) % 8 == 0) &&
                ((reinterpret_cast<uintptr_t>(dq) & 15) == 0) && ((ld_dqkv * 2) % 16 == 0);
   if (!fused) dq_accum = nullptr;
   PENEO_REQUIRE(fused || (kt && qt && dot), "peneo_attn_bwd: the two-kernel path needs the transposed copies kt / qt / dot");

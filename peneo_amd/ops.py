@@ -381,7 +381,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int,
 
 def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_bias,
              dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0,
-             single_pass: Optional[bool] = None, ds_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             single_pass: Optional[bool] = None, ds_out: Optional[torch.Tensor] = None,
+             dq_atomic: bool = False) -> torch.Tensor:
     """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations).
     bf16 runs the single-pass kernel (fp32 dQ accumulator, no transposed copies); fp32 the dQ + dK/dV pair."""
     H = nh * d
@@ -394,7 +395,10 @@ def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: f
     kt = qt = dot = dq_acc = None
     if single_pass:
         assert q.dtype == torch.bfloat16, "the single-pass attention backward is bf16 only"
-        dq_acc = torch.empty((B * T, H), dtype=torch.float32, device=q.device)
+        if dq_atomic:      # dQ through fp32 atomics into an accumulator (kept for comparison: a quarter of the kernel's time)
+            dq_acc = torch.empty((B * T, H), dtype=torch.float32, device=q.device)
+        elif ds_out is None:   # dQ by a second kernel from the layer's dS^T: needs the slab even when nobody else wants it
+            ds_out = torch.empty((B, nh, T, attn_padded_len(T)), dtype=q.dtype, device=q.device)
     else:
         kt = head_transpose(k, B, nh, T, d)
         qt = head_transpose(q, B, nh, T, d)

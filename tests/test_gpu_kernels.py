@@ -429,19 +429,21 @@ def test_attention_bf16_single_pass_matches_two_kernel_path_with_dropout(ops, d)
     out, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 0.11, bias, None, drop_p=0.2, drop_seed=9)
     d_out = torch.randn(B * T, H, generator=g).to(DEV).to(torch.bfloat16)
     res = []
-    for single in (True, False):
+    for single, atomic in ((True, False), (False, False), (True, True)):
         dqkv = torch.zeros_like(qkv)
         gb = torch.zeros(bias.shape, dtype=torch.float32, device=DEV)
-        ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.11, bias, None, dqkv, gb, drop_p=0.2, drop_seed=9, single_pass=single)
+        ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.11, bias, None, dqkv, gb, drop_p=0.2, drop_seed=9, single_pass=single,
+                     dq_atomic=atomic)
         res.append((dqkv.float(), gb))
     assert rel_err(res[0][0], res[1][0]) < 2e-2
     assert rel_err(res[0][1], res[1][1]) < 2e-2
+    assert rel_err(res[2][0], res[1][0]) < 2e-2 and rel_err(res[2][1], res[1][1]) < 2e-2   # dQ through fp32 atomics
     # per-layer dS^T copy (key-major bf16) instead of the fp32 accumulator; padding columns stay zero
     Tp = bias.shape[-1]
     ds = torch.full((B, nh, T, Tp), 7.0, device=DEV, dtype=torch.bfloat16)
     dq2 = torch.zeros_like(qkv)
     ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.11, bias, None, dq2, None, drop_p=0.2, drop_seed=9, ds_out=ds)
-    assert rel_err(dq2.float(), res[0][0]) < 1e-6
+    assert rel_err(dq2.float(), res[0][0]) < 1e-6   # dQ from the stored dS^T either way
     assert rel_err(ds[..., :T].float().transpose(2, 3), res[0][1][..., :T]) < 1e-2
     assert float(ds[..., T:].abs().max()) == 0.0
     # ... and the table gradients reduced from two "layers" of it equal those from the fp32 accumulator

@@ -27,5 +27,6 @@ d_out = torch.randn(B * T, H, device="cuda").to(dt)
 dqkv = torch.empty_like(qkv)
 g = torch.zeros(bias.shape, dtype=torch.float32, device="cuda")
 bench("attn_bwd single pass (+G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, g, drop_p=drop, drop_seed=5), 2.5 * fl)
+bench("attn_bwd single pass, dQ atomics (no G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, None, drop_p=drop, drop_seed=5, dq_atomic=True), 2.5 * fl)
 bench("attn_bwd single pass (no G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, None, drop_p=drop, drop_seed=5), 2.5 * fl)
 bench("attn_bwd two kernels (+G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, g, drop_p=drop, drop_seed=5, single_pass=False), 2.5 * fl)
