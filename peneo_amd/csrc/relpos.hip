@@ -59,15 +59,19 @@ __global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const uint8_t* bk1
 // hits its own bank and its own address, so the LDS atomics neither bank-conflict nor serialise on popular buckets),
 // folded at the end into one global atomic per bin.
 constexpr int RB_REP = 32;
+// The LDS histograms accumulate in 64-bit fixed point (2^-32 units): on gfx950 an LDS float atomic add runs at ~0.2 T
+// lane-ops/s, the integer one (ds_add_u64) at ~4.6 T (tools/ubench/lds_atomic.hip), and integer sums are order-independent.
+__device__ __forceinline__ unsigned long long rb_fix(float v) { return (unsigned long long)__float2ll_rn(v * 4294967296.0f); }
+__device__ __forceinline__ float rb_unfix(unsigned long long q) { return (float)((double)(long long)q * (1.0 / 4294967296.0)); }
 __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, const uint8_t* bk1, const uint8_t* bkx,
                                                               const uint8_t* bky, float* dw1, int bins1, float* dwx, float* dwy,
                                                               int bins2, float scale, int nh, int Tn, int64_t ldg) {
-  extern __shared__ float hist[];  // [bins1 | bins2 | bins2][RB_REP]
-  float* h1 = hist;
-  float* hx = h1 + bins1 * RB_REP;
-  float* hy = hx + bins2 * RB_REP;
+  extern __shared__ unsigned long long hist[];  // [bins1 | bins2 | bins2][RB_REP], fixed point
+  unsigned long long* h1 = hist;
+  unsigned long long* hx = h1 + bins1 * RB_REP;
+  unsigned long long* hy = hx + bins2 * RB_REP;
   const int nb = bins1 + 2 * bins2;
-  for (int i = threadIdx.x; i < nb * RB_REP; i += blockDim.x) hist[i] = 0.f;
+  for (int i = threadIdx.x; i < nb * RB_REP; i += blockDim.x) hist[i] = 0ull;
   __syncthreads();
   const int rep = threadIdx.x & (RB_REP - 1);
   const int slabs = (Tn + 31) / 32;
@@ -90,17 +94,18 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, co
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (bk1) atomicAdd(h1 + c1[u] * RB_REP + rep, v[u]);
-        if (bkx) { atomicAdd(hx + cx[u] * RB_REP + rep, v[u]); atomicAdd(hy + cy[u] * RB_REP + rep, v[u]); }
+        const unsigned long long q = rb_fix(v[u]);
+        if (bk1) atomicAdd(h1 + c1[u] * RB_REP + rep, q);
+        if (bkx) { atomicAdd(hx + cx[u] * RB_REP + rep, q); atomicAdd(hy + cy[u] * RB_REP + rep, q); }
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-    float sum = 0.f;
+    unsigned long long acc = 0ull;
 #pragma unroll 8
-    for (int r = 0; r < RB_REP; ++r) sum += hist[i * RB_REP + ((r + i) & (RB_REP - 1))];
-    sum *= scale;
+    for (int r = 0; r < RB_REP; ++r) acc += hist[i * RB_REP + ((r + i) & (RB_REP - 1))];
+    const float sum = rb_unfix(acc) * scale;
     if (i < bins1) { if (dw1) atomicAdd(dw1 + h * bins1 + i, sum); }
     else if (i < bins1 + bins2) { if (dwx) atomicAdd(dwx + h * bins2 + (i - bins1), sum); }
     else if (dwy) atomicAdd(dwy + h * bins2 + (i - bins1 - bins2), sum);
@@ -112,12 +117,12 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_layers_kernel(const bf16_
                                                                      const uint8_t* bkx, const uint8_t* bky, float* dw1, int bins1,
                                                                      float* dwx, float* dwy, int bins2, float scale, int nh, int Tn,
                                                                      int Tp) {
-  extern __shared__ float hist[];  // [bins1 | bins2 | bins2][RB_REP]
-  float* h1 = hist;
-  float* hx = h1 + bins1 * RB_REP;
-  float* hy = hx + bins2 * RB_REP;
+  extern __shared__ unsigned long long hist[];  // [bins1 | bins2 | bins2][RB_REP], fixed point
+  unsigned long long* h1 = hist;
+  unsigned long long* hx = h1 + bins1 * RB_REP;
+  unsigned long long* hy = hx + bins2 * RB_REP;
   const int nb = bins1 + 2 * bins2;
-  for (int i = threadIdx.x; i < nb * RB_REP; i += blockDim.x) hist[i] = 0.f;
+  for (int i = threadIdx.x; i < nb * RB_REP; i += blockDim.x) hist[i] = 0ull;
   __syncthreads();
   const int rep = threadIdx.x & (RB_REP - 1);
   const int slabs = (Tn + 31) / 32;
@@ -137,16 +142,17 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_layers_kernel(const bf16_
         v += (bf16_to_f32(r0) + bf16_to_f32(r1)) + (bf16_to_f32(r2) + bf16_to_f32(r3));
       }
       for (; l < L; ++l) v += bf16_to_f32(row[(int64_t)l * lstride + i]);
-      if (bk1) atomicAdd(h1 + bk1[brow + i] * RB_REP + rep, v);
-      if (bkx) { atomicAdd(hx + bkx[brow + i] * RB_REP + rep, v); atomicAdd(hy + bky[brow + i] * RB_REP + rep, v); }
+      const unsigned long long q = rb_fix(v);
+      if (bk1) atomicAdd(h1 + bk1[brow + i] * RB_REP + rep, q);
+      if (bkx) { atomicAdd(hx + bkx[brow + i] * RB_REP + rep, q); atomicAdd(hy + bky[brow + i] * RB_REP + rep, q); }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-    float sum = 0.f;
+    unsigned long long acc = 0ull;
 #pragma unroll 8
-    for (int r = 0; r < RB_REP; ++r) sum += hist[i * RB_REP + ((r + i) & (RB_REP - 1))];
-    sum *= scale;
+    for (int r = 0; r < RB_REP; ++r) acc += hist[i * RB_REP + ((r + i) & (RB_REP - 1))];
+    const float sum = rb_unfix(acc) * scale;
     if (i < bins1) { if (dw1) atomicAdd(dw1 + h * bins1 + i, sum); }
     else if (i < bins1 + bins2) { if (dwx) atomicAdd(dwx + h * bins2 + (i - bins1), sum); }
     else if (dwy) atomicAdd(dwy + h * bins2 + (i - bins1 - bins2), sum);
@@ -163,7 +169,7 @@ extern "C" int peneo_relpos_bias_bwd_layers(const void* ds, int L, int64_t layer
   PENEO_REQUIRE(ds && L > 0 && B > 0 && nh > 0 && T > 0 && Tp >= T, "peneo_relpos_bias_bwd_layers: bad arguments");
   PENEO_REQUIRE((bkx_t != nullptr) == (bky_t != nullptr), "peneo_relpos_bias_bwd_layers: 2-D inputs mismatch");
   PENEO_REQUIRE(L == 1 || layer_stride >= (int64_t)B * nh * T * Tp, "peneo_relpos_bias_bwd_layers: layer stride too small");
-  size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2) * RB_REP;
+  size_t sh = sizeof(unsigned long long) * (size_t)(bins1 + 2 * bins2) * RB_REP;
   PENEO_REQUIRE(sh <= 64 * 1024, "peneo_relpos_bias_bwd_layers: tables too large for LDS");
   int slabs = (T + 31) / 32;
   dim3 grid((unsigned)((int64_t)B * nh * slabs));
@@ -209,7 +215,7 @@ extern "C" int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t*
   PENEO_REQUIRE(ldg >= T, "peneo_relpos_bias_bwd: ldg < T");
   PENEO_REQUIRE(g && B > 0 && nh > 0 && T > 0, "peneo_relpos_bias_bwd: bad arguments");
   PENEO_REQUIRE((bkx != nullptr) == (bky != nullptr), "peneo_relpos_bias_bwd: 2-D inputs mismatch");
-  size_t sh = sizeof(float) * (size_t)(bins1 + 2 * bins2) * RB_REP;
+  size_t sh = sizeof(unsigned long long) * (size_t)(bins1 + 2 * bins2) * RB_REP;
   PENEO_REQUIRE(sh <= 64 * 1024, "peneo_relpos_bias_bwd: tables too large for LDS");
   int slabs = (T + 31) / 32;
   dim3 grid((unsigned)((int64_t)B * nh * slabs));
