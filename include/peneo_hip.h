@@ -193,7 +193,8 @@ int peneo_relpos_bias_fwd(int dtype, const uint8_t* bk1, const uint8_t* bkx, con
 /* dw*[h,bin] += scale * sum_{b,i,j in bin} g[b,h,i,j]   (g rows have stride ldg >= T) */
 /* Bias-table gradients from L per-layer bf16 dS^T buffers (layout of peneo_attn_bwd's ds_out, `layer_stride`
  * elements apart): dS is summed over the layers in fp32, then binned.  The bucket maps are the TRANSPOSED ones,
- * bkT[b, j, i] = bucket(i, j) (peneo_relpos_buckets on negated positions yields exactly that). */
+ * bkT[b, j, i] = bucket(i, j) (peneo_relpos_buckets on negated positions yields exactly that), stored with row
+ * stride Tp: uint8 [B, T, Tp] (columns >= T are ignored), so that 8 buckets are one aligned 8-byte load. */
 int peneo_relpos_bias_bwd_layers(const void* ds, int L, int64_t layer_stride, const uint8_t* bk1_t, const uint8_t* bkx_t,
                                  const uint8_t* bky_t, float* dw1, int bins1, float* dwx, float* dwy, int bins2,
                                  float scale, int B, int nh, int T, int Tp, peneo_stream_t stream);

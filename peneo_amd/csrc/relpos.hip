@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* g, co
   }
 }
 
-// same reduction from L per-layer bf16 dS^T buffers [B, nh, T keys, Tp queries]: block = (b, h, 32-key slab)
+// same reduction from L per-layer bf16 dS^T buffers [B, nh, T keys, Tp queries]: block = (b, h, 32-key slab).
+// Work item = 8 consecutive queries of one key row: L 16-byte loads (one per layer) summed in fp32, three 8-byte bucket
+// loads (the transposed maps are padded to row stride Tp, so both are aligned), then the LDS integer atomics.
 __global__ __launch_bounds__(256) void relpos_bias_bwd_layers_kernel(const bf16_t* ds, int L, int64_t lstride, const uint8_t* bk1,
                                                                      const uint8_t* bkx, const uint8_t* bky, float* dw1, int bins1,
                                                                      float* dwx, float* dwy, int bins2, float scale, int nh, int Tn,
@@ -129,22 +131,50 @@ __global__ __launch_bounds__(256) void relpos_bias_bwd_layers_kernel(const bf16_
   const int slab = blockIdx.x % slabs;
   const int h = (blockIdx.x / slabs) % nh;
   const int64_t b = blockIdx.x / ((int64_t)slabs * nh);
-  const int j0 = slab * 32, j1 = min(Tn, j0 + 32);
-  for (int j = j0; j < j1; ++j) {
-    const bf16_t* row = ds + (((b * nh + h) * Tn + j) * (int64_t)Tp);
-    const int64_t brow = (b * Tn + j) * (int64_t)Tn;
-    for (int i = threadIdx.x; i < Tn; i += blockDim.x) {
-      float v = 0.f;
-      int l = 0;
-      for (; l + 4 <= L; l += 4) {   // four layers in flight per step (the loop is latency-bound otherwise)
-        const bf16_t r0 = row[(int64_t)l * lstride + i], r1 = row[(int64_t)(l + 1) * lstride + i];
-        const bf16_t r2 = row[(int64_t)(l + 2) * lstride + i], r3 = row[(int64_t)(l + 3) * lstride + i];
-        v += (bf16_to_f32(r0) + bf16_to_f32(r1)) + (bf16_to_f32(r2) + bf16_to_f32(r3));
+  const int j0 = slab * 32, nrow = min(Tn, j0 + 32) - j0;
+  const int vpr = Tp / 8;
+  for (int item = threadIdx.x; item < nrow * vpr; item += blockDim.x) {
+    const int j = j0 + item / vpr, i0 = (item % vpr) * 8;
+    if (i0 >= Tn) continue;
+    const bf16_t* row = ds + (((b * nh + h) * Tn + j) * (int64_t)Tp) + i0;
+    const int64_t brow = (b * Tn + j) * (int64_t)Tp + i0;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    int l = 0;
+    for (; l + 4 <= L; l += 4) {   // four layers in flight
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(row + (int64_t)(l + u) * lstride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack16<bf16_t>(r[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += f[e];
       }
-      for (; l < L; ++l) v += bf16_to_f32(row[(int64_t)l * lstride + i]);
-      const unsigned long long q = rb_fix(v);
-      if (bk1) atomicAdd(h1 + bk1[brow + i] * RB_REP + rep, q);
-      if (bkx) { atomicAdd(hx + bkx[brow + i] * RB_REP + rep, q); atomicAdd(hy + bky[brow + i] * RB_REP + rep, q); }
+    }
+    for (; l < L; ++l) {
+      float f[8];
+      unpack16<bf16_t>(*reinterpret_cast<const uint4*>(row + (int64_t)l * lstride), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+    const uint2 z2 = make_uint2(0u, 0u);
+    const uint2 c1 = bk1 ? *reinterpret_cast<const uint2*>(bk1 + brow) : z2;
+    const uint2 cx = bkx ? *reinterpret_cast<const uint2*>(bkx + brow) : z2;
+    const uint2 cy = bkx ? *reinterpret_cast<const uint2*>(bky + brow) : z2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (i0 + e < Tn) {
+        const unsigned long long q = rb_fix(v[e]);
+        const int sh = (e & 3) * 8;
+        if (bk1) atomicAdd(h1 + (((e < 4 ? c1.x : c1.y) >> sh) & 0xff) * RB_REP + rep, q);
+        if (bkx) {
+          atomicAdd(hx + (((e < 4 ? cx.x : cx.y) >> sh) & 0xff) * RB_REP + rep, q);
+          atomicAdd(hy + (((e < 4 ? cy.x : cy.y) >> sh) & 0xff) * RB_REP + rep, q);
+        }
+      }
     }
   }
   __syncthreads();
@@ -169,6 +199,10 @@ extern "C" int peneo_relpos_bias_bwd_layers(const void* ds, int L, int64_t layer
   PENEO_REQUIRE(ds && L > 0 && B > 0 && nh > 0 && T > 0 && Tp >= T, "peneo_relpos_bias_bwd_layers: bad arguments");
   PENEO_REQUIRE((bkx_t != nullptr) == (bky_t != nullptr), "peneo_relpos_bias_bwd_layers: 2-D inputs mismatch");
   PENEO_REQUIRE(L == 1 || layer_stride >= (int64_t)B * nh * T * Tp, "peneo_relpos_bias_bwd_layers: layer stride too small");
+  PENEO_REQUIRE(Tp % 8 == 0 && (reinterpret_cast<uintptr_t>(ds) & 15) == 0 && (layer_stride % 8) == 0,
+                "peneo_relpos_bias_bwd_layers: dS^T rows must be 16-byte aligned (Tp multiple of 8)");
+  PENEO_REQUIRE(((reinterpret_cast<uintptr_t>(bk1_t) | reinterpret_cast<uintptr_t>(bkx_t) | reinterpret_cast<uintptr_t>(bky_t)) & 7) == 0,
+                "peneo_relpos_bias_bwd_layers: bucket maps must be 8-byte aligned");
   size_t sh = sizeof(unsigned long long) * (size_t)(bins1 + 2 * bins2) * RB_REP;
   PENEO_REQUIRE(sh <= 64 * 1024, "peneo_relpos_bias_bwd_layers: tables too large for LDS");
   int slabs = (T + 31) / 32;

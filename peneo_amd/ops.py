@@ -335,8 +335,17 @@ def relpos_bias_fwd(dtype: torch.dtype, bk1, bkx, bky, w1, wx, wy, scale: float,
 
 
 def relpos_bias_bwd_layers(ds: torch.Tensor, bk1_t, bkx_t, bky_t, dw1, dwx, dwy, scale: float) -> None:
-    """ds: bf16 [L, B, nh, T, Tp] per-layer dS^T (attn_bwd's ds_out); bk*_t: transposed bucket maps [B, T, T]."""
+    """ds: bf16 [L, B, nh, T, Tp] per-layer dS^T (attn_bwd's ds_out); bk*_t: transposed bucket maps, [B, T, T] (padded
+    here to the kernel's row stride Tp) or already [B, T, Tp]."""
     L, B, nh, T, Tp = ds.shape
+
+    def padded(t):
+        if t is None or t.shape[-1] == Tp:
+            return t
+        out = torch.zeros((B, T, Tp), dtype=torch.uint8, device=t.device)
+        out[:, :, :T] = t
+        return out
+    bk1_t, bkx_t, bky_t = padded(bk1_t), padded(bkx_t), padded(bky_t)
     check(lib().peneo_relpos_bias_bwd_layers(ptr(_c(ds)), L, ds.stride(0), ptr(bk1_t), ptr(bkx_t), ptr(bky_t), ptr(dw1),
                                              dw1.shape[1] if dw1 is not None else 0, ptr(dwx), ptr(dwy),
                                              dwx.shape[1] if dwx is not None else 0, scale, B, nh, T, Tp, stream()),
