@@ -401,6 +401,39 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
   if (lane == 0) p.delta[row] = s;
 }
 
+// vector variant (head dim = 8 * 2^k elements of T-vectors): G = d / VEC lanes share one (token, head) row with 16-byte loads
+// and meet in G-lane shuffles; a wave covers 64 / G heads of consecutive (token, head) pairs -> full 128-byte lines
+template <typename T, int G>
+__global__ __launch_bounds__(256) void attn_delta_vec_kernel(AttnParams p) {
+  constexpr int VEC = Elem<T>::kVec;
+  const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;       // (b * T + q) * nh + h
+  const int sub = threadIdx.x % G;
+  const int64_t total = (int64_t)p.B * p.T * p.nh;
+  const bool ok = item < total;
+  const int64_t it = ok ? item : total - 1;
+  const int h = (int)(it % p.nh);
+  const int64_t tok = it / p.nh;                                             // b * T + q
+  const T* O = reinterpret_cast<const T*>(p.out) + tok * p.ld_out + h * p.d + sub * VEC;
+  const T* dO = reinterpret_cast<const T*>(p.d_out) + tok * p.ld_out + h * p.d + sub * VEC;
+  float a[VEC], g[VEC];
+  if constexpr (sizeof(T) == 2) {
+    unpack16<T>(*reinterpret_cast<const uint4*>(O), a);
+    unpack16<T>(*reinterpret_cast<const uint4*>(dO), g);
+  } else {
+    unpack16<T>(*reinterpret_cast<const uint4*>(O), a);
+    unpack16<T>(*reinterpret_cast<const uint4*>(dO), g);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s += a[e] * g[e];
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (ok && sub == 0) {
+    const int64_t b = tok / p.T, q = tok % p.T;
+    p.delta[(b * p.nh + h) * p.T + q] = s;
+  }
+}
+
 // ================================================================================================
 // backward, part 1: dQ (and the accumulated bias gradient).  Workgroup = 128 queries, streams key tiles.
 // ================================================================================================
@@ -1097,7 +1130,20 @@ static int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <typename T, int DP, bool DROP>
 static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
   int64_t rows = (int64_t)p.B * p.nh * p.T;
-  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  {
+    constexpr int VEC = Elem<T>::kVec;
+    const int g = p.d / VEC;
+    const bool vec = (p.d % VEC == 0) && (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) &&
+                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.d_out)) & 15) == 0 &&
+                     ((p.ld_out * (int64_t)sizeof(T)) % 16 == 0);
+    const unsigned vblocks = (unsigned)((rows * (g > 0 ? g : 1) + 255) / 256);
+    if (vec && g == 8) hipLaunchKernelGGL((attn_delta_vec_kernel<T, 8>), dim3(vblocks), dim3(256), 0, st, p);
+    else if (vec && g == 16) hipLaunchKernelGGL((attn_delta_vec_kernel<T, 16>), dim3(vblocks), dim3(256), 0, st, p);
+    else if (vec && g == 4) hipLaunchKernelGGL((attn_delta_vec_kernel<T, 4>), dim3(vblocks), dim3(256), 0, st, p);
+    else if (vec && g == 2) hipLaunchKernelGGL((attn_delta_vec_kernel<T, 2>), dim3(vblocks), dim3(256), 0, st, p);
+    else if (vec && g == 1) hipLaunchKernelGGL((attn_delta_vec_kernel<T, 1>), dim3(vblocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  }
   int rc = check_launch("peneo_attn_bwd(delta)");
   if (rc) return rc;
   if constexpr (sizeof(T) == 2) {
