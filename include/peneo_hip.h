@@ -122,13 +122,17 @@ int peneo_layernorm_fwd(int dtype, const void* x, int64_t x_rpb, int64_t x_bstri
                         const float* gamma, const float* beta, float eps,
                         float* mean, float* rstd, int64_t rows, int H,
                         float drop_p, uint32_t drop_seed, peneo_stream_t stream);
-/* dx may alias dy.  dgamma/dbeta (fp32, [H]) are accumulated into. */
+/* dx may alias dy.  dgamma/dbeta (fp32, [H]) are accumulated into.
+ * dx_dropped (may be NULL): a second, contiguous [rows, H] output = dx through the dropout mask (drop2_p, drop2_seed,
+ * element index r*H + c) of the GEMM that produced this LayerNorm's input — the gradient that GEMM's dgrad/wgrad need,
+ * without a separate masking pass. */
 int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bstride,
                         const void* x, int64_t x_rpb, int64_t x_bstride,
                         void* dx, int64_t dx_rpb, int64_t dx_bstride,
                         const float* gamma, const float* mean, const float* rstd,
                         float* dgamma, float* dbeta, int64_t rows, int H,
-                        float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+                        float drop_p, uint32_t drop_seed, void* dx_dropped, float drop2_p, uint32_t drop2_seed,
+                        peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1 — text embeddings (modeling_layoutlmv3.py:131-227, modeling_lilt.py:75-130,160-210)

@@ -73,12 +73,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                      const float* gamma, const float* mean, const float* rstd,
                                                      float* dgamma, float* dbeta, int64_t rows, int H, float drop_p,
-                                                     uint32_t seed) {
+                                                     uint32_t seed, T* dx2, float drop2_p, uint32_t seed2) {
   constexpr int VEC = Elem<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int nvec = H / VEC;
   const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint32_t thresh2 = (uint32_t)fminf(drop2_p * 4294967296.0f, 4294967040.0f);
+  const float keep2 = drop2_p > 0.f ? 1.0f / (1.0f - drop2_p) : 1.0f;
   float ag[LN_MAXNV][VEC], ab[LN_MAXNV][VEC];
 #pragma unroll
   for (int k = 0; k < LN_MAXNV; ++k)
@@ -125,6 +127,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, con
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
         *reinterpret_cast<uint4*>(dxr + vi * VEC) = pack16<T>(o);
+        if (dx2) {   // second output: dx through the dropout mask of the producer GEMM (contiguous [rows, H])
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            o[e] = (drop2_p > 0.f && !dropout_keep(seed2, (uint64_t)r * H + vi * VEC + e, thresh2)) ? 0.f : o[e] * keep2;
+          *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + vi * VEC) = pack16<T>(o);
+        }
       }
     }
   }
@@ -222,12 +230,14 @@ template <typename T, int NV, bool DROP>
 __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                        const float* gamma, const float* mean, const float* rstd,
                                                        float* dgamma, float* dbeta, int64_t rows, float drop_p,
-                                                       uint32_t seed) {
+                                                       uint32_t seed, T* dx2, float drop2_p, uint32_t seed2) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = 32 * NV * VEC;
   const int hl = threadIdx.x & 31;
   const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint32_t thresh2 = (uint32_t)fminf(drop2_p * 4294967296.0f, 4294967040.0f);
+  const float keep2 = drop2_p > 0.f ? 1.0f / (1.0f - drop2_p) : 1.0f;
   float gm[NV][VEC], ag[NV][VEC], ab[NV][VEC];
 #pragma unroll
   for (int k = 0; k < NV; ++k)
@@ -281,6 +291,12 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
       *reinterpret_cast<uint4*>(dxr + (hl + 32 * k) * VEC) = pack16<T>(o);
+      if (dx2) {   // second output: dx through the dropout mask of the producer GEMM (contiguous [rows, H])
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          o[e] = (drop2_p > 0.f && !dropout_keep(seed2, (uint64_t)r * H + (hl + 32 * k) * VEC + e, thresh2)) ? 0.f : o[e] * keep2;
+        *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + (hl + 32 * k) * VEC) = pack16<T>(o);
+      }
     }
   }
   // parameter gradients: 8 half-waves -> LDS -> one atomic per column per block
@@ -317,16 +333,16 @@ static void launch_ln_fwd32(hipStream_t st, const void* x, LnMap xm, void* y, Ln
 template <typename T, int NV>
 static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const void* x, LnMap xm, void* dx, LnMap dxm,
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                            int64_t rows, float drop_p, uint32_t seed) {
+                            int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2) {
   int64_t blocks = (rows + 7) / 8;
   if (blocks > 512) blocks = 512;
   dim3 grid((unsigned)blocks);
   if (drop_p > 0.f)
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed);
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2);
   else
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed);
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2);
 }
 
 // true when a fast instantiation exists for this row length
@@ -400,25 +416,29 @@ extern "C" int peneo_layernorm_fwd(int dtype, const void* x, int64_t x_rpb, int6
 extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bstride, const void* x,
                                    int64_t x_rpb, int64_t x_bstride, void* dx, int64_t dx_rpb, int64_t dx_bstride,
                                    const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                                   int64_t rows, int H, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+                                   int64_t rows, int H, float drop_p, uint32_t drop_seed, void* dx_dropped, float drop2_p,
+                                   uint32_t drop2_seed, peneo_stream_t stream) {
   int rc = ln_check("peneo_layernorm_bwd", dtype, rows, H);
   if (rc) return rc;
   PENEO_REQUIRE(dy && x && dx && gamma && mean && rstd, "peneo_layernorm_bwd: null pointer");
   LnMap dym{dy_rpb, dy_bstride}, xm{x_rpb, x_bstride}, dxm{dx_rpb, dx_bstride};
-  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_layernorm_bwd: drop_p out of range");
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f && drop2_p >= 0.f && drop2_p < 1.f, "peneo_layernorm_bwd: drop_p out of range");
+  PENEO_REQUIRE(!dx_dropped || (reinterpret_cast<uintptr_t>(dx_dropped) & 15) == 0, "peneo_layernorm_bwd: dx_dropped must be 16-byte aligned");
   if (ln_aligned(dy, dy_bstride, dtype) && ln_aligned(x, x_bstride, dtype) && ln_aligned(dx, dx_bstride, dtype)) {
     hipStream_t st = (hipStream_t)stream;
     bool done = dtype == PENEO_BF16
-        ? ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_bwd32<bf16_t, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed); })
-        : ln32_dispatch<float>(H, [&](auto nv) { launch_ln_bwd32<float, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed); });
+        ? ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_bwd32<bf16_t, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); })
+        : ln32_dispatch<float>(H, [&](auto nv) { launch_ln_bwd32<float, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); });
     if (done) return check_launch("peneo_layernorm_bwd");
   }
   dim3 grid(ln_grid(rows, 8));  // <= 256 blocks: each wave reduces several rows; one atomic per column per block
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dym,
-                       (const bf16_t*)x, xm, (bf16_t*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed);
+                       (const bf16_t*)x, xm, (bf16_t*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed,
+                       (bf16_t*)dx_dropped, drop2_p, drop2_seed);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dym,
-                       (const float*)x, xm, (float*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed);
+                       (const float*)x, xm, (float*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed,
+                       (float*)dx_dropped, drop2_p, drop2_seed);
   return check_launch("peneo_layernorm_bwd");
 }

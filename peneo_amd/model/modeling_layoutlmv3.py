@@ -355,15 +355,23 @@ class _LayerStage(torch.autograd.Function):
         dg2, db2, dg1, db1 = pool[:H], pool[H:2 * H], pool[2 * H:3 * H], pool[3 * H:4 * H]
         o_ = 4 * H
         dbo2, dbi, dbo, dbqkv = pool[o_:o_ + H], pool[o_ + H:o_ + H + I], pool[o_ + H + I:o_ + 2 * H + I], pool[o_ + 2 * H + I:]
-        d_h2 = ops.layernorm_bwd(d_out, h2, g2, m2, r2, dg2, db2)
-        d_dense2 = ops.copy2d(d_h2, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3)) if seeds.p_hidden > 0 else d_h2
+        # LayerNorm backward writes d_h (for the residual branch) and, in the same pass, d_h through the dropout mask of
+        # the dense layer that fed the LayerNorm (for that layer's dgrad / wgrad)
+        d_dense2 = torch.empty_like(h2) if seeds.p_hidden > 0 else None
+        d_h2 = ops.layernorm_bwd(d_out, h2, g2, m2, r2, dg2, db2, dx_dropped=d_dense2, drop2_p=seeds.p_hidden,
+                                 drop2_seed=seeds.seed(site + 3))
+        if d_dense2 is None:
+            d_dense2 = d_h2
         _, dwo2 = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)))
         d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
         _, dwi = on_side(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
         d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
 
-        d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1)
-        d_dense1 = ops.copy2d(d_h1, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2)) if seeds.p_hidden > 0 else d_h1
+        d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
+        d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1, dx_dropped=d_dense1, drop2_p=seeds.p_hidden,
+                                 drop2_seed=seeds.seed(site + 2))
+        if d_dense1 is None:
+            d_dense1 = d_h1
         _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 

@@ -214,7 +214,8 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
                   dgamma: torch.Tensor, dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop_p: float = 0.0,
-                  drop_seed: int = 0) -> torch.Tensor:
+                  drop_seed: int = 0, dx_dropped: Optional[torch.Tensor] = None, drop2_p: float = 0.0,
+                  drop2_seed: int = 0) -> torch.Tensor:
     H = x.shape[-1]
     rows, xr, xb = _rowmap(x, H)
     drows, dr, db = _rowmap(dy, H)
@@ -224,7 +225,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     _, gr, gb = _rowmap(dx, H)
     check(lib().peneo_layernorm_bwd(dtype_code(x.dtype), ptr(dy), dr, db, ptr(x), xr, xb, ptr(dx), gr, gb, ptr(gamma),
                                     ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), rows, H, drop_p,
-                                    drop_seed & 0xFFFFFFFF, stream()), "peneo_layernorm_bwd")
+                                    drop_seed & 0xFFFFFFFF, ptr(dx_dropped), drop2_p, drop2_seed & 0xFFFFFFFF, stream()),
+          "peneo_layernorm_bwd")
     return dx
 
 

@@ -222,6 +222,14 @@ def test_layernorm_dropout_fwd_bwd_share_the_mask(ops, dtype, H):
     dg2, db2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     dx2 = ops.layernorm_bwd(dy_masked, x, gamma, mean, rstd, dg2, db2)
     assert rel_err(dx, dx2) < tol(dtype) and rel_err(dg, dg2) < tol(dtype) and rel_err(db, db2) < tol(dtype)
+    # second output: dx through another dropout mask (the producer GEMM's) == a separate masking pass over dx
+    dxd = torch.empty_like(x)
+    dg3, db3 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx3 = ops.layernorm_bwd(dy_masked, x, gamma, mean, rstd, dg3, db3, dx_dropped=dxd, drop2_p=0.25, drop2_seed=77)
+    assert torch.equal(dx3, dx2)
+    ref_d = ops.copy2d(dx2, drop_p=0.25, drop_seed=77)
+    assert torch.equal(dxd == 0, ref_d == 0)                       # the same mask ...
+    assert rel_err(dxd, ref_d) < (1e-6 if dtype == torch.float32 else 1e-2)   # ... bf16: one rounding instead of two
 
 
 def test_layernorm_strided_rows_fast_path(ops):
