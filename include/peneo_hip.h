@@ -219,7 +219,9 @@ int peneo_attn_padded_len(int T);
 int peneo_attn_padded_dim(int d);
 int peneo_head_transpose(int dtype, const void* src, int64_t ld, int B, int nh, int T, int d, void* dst,
                          peneo_stream_t stream);
-int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const void* vt,
+/* v / vt: bf16 takes V in place (row stride ld_qk, like q and k) and reads V^T with the hardware transpose read, vt may
+ * be NULL; fp32 needs vt, the per-head transposed copy from peneo_head_transpose (v is then ignored). */
+int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qk, const void* vt,
                    int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
                    const float* key_bias, void* out, int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed,
                    peneo_stream_t stream);

@@ -68,6 +68,22 @@ template <int COLS> struct FragReader<float, COLS> {
   }
 };
 
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+// fragment for an MFMA operand whose row index is the contiguous LDS dimension: rows (lane&31) + col0, reduction
+// indices {k0..k0+3} and {k1..k1+3} (LDS rows) -> two transpose reads of a [4 k][16 rows] block per 16-lane group
+template <int PITCH>
+__device__ __forceinline__ Frag<bf16_t> frag_tr(const char* tile, int col0, int k0, int k1, int lane) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
+  const int c = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int kr = (lane & 15) >> 2;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + (k0 + kr) * PITCH + c * 2));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + (k1 + kr) * PITCH + c * 2));
+  uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  Frag<bf16_t> f;
+  f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
+  return f;
+}
+
 // pack_frag8 of 8 accumulator registers (r0..r0+7) of a C-layout tile gives a fragment whose element t is row
 // 2*r0 + (t&3) + 8*(t>>2) + 4*(lane>>5): exactly what FragReader::perm(col = 2*r0 + 4*half) reads on the A side.
 
@@ -242,20 +258,24 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* src, int64
 // ================================================================================================
 // forward
 // ================================================================================================
-template <typename T, int DP, bool DROP>
+// VTR (bf16): V comes as the row-major [keys][d] tile and the V^T operand is read with the hardware transpose read, so
+// no per-head transposed copy of V is made (peneo_attn_fwd then takes v instead of vt)
+template <typename T, int DP, bool DROP, bool VTR>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DP / 16, DT = DP / 32;
   char* sK = smem;                                   // [AK][DP]
   char* sVt = sK + AK * Pitch<T, DP>::v;             // [DP][AK]
-  char* sB = sVt + DP * Pitch<T, AK>::v;             // [AQ][AK] bias
+  constexpr int VT_BYTES = (DP * Pitch<T, AK>::v > AK * Pitch<T, DP>::v) ? DP * Pitch<T, AK>::v : AK * Pitch<T, DP>::v;
+  char* sB = sVt + VT_BYTES;                         // [AQ][AK] bias (after V^T [DP][AK] or, VTR, V [AK][DP])
   float* sKb = reinterpret_cast<float*>(sB + AQ * BiasPitch<T>::v);  // [AK] additive key bias (log2 units)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
   const int Tn = p.T, d = p.d, Tp = p.Tp;
   const T* Q = reinterpret_cast<const T*>(p.q) + (int64_t)b * Tn * p.ld + h * d;
   const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * d;
-  const T* Vt = reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.nh + h) * DP * Tp;
+  const T* Vt = VTR ? reinterpret_cast<const T*>(p.v) + (int64_t)b * Tn * p.ld + h * d
+                    : reinterpret_cast<const T*>(p.vt) + ((int64_t)b * p.nh + h) * DP * Tp;
   const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
   const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
@@ -278,13 +298,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
 
   TileRegs<T, AK, DP> rk;
   TileRegs<T, DP, AK> rv;
+  TileRegs<T, AK, DP> rv2;
   BiasRegs<T, AQ> rb;
+  const bool v_al = VTR && ((reinterpret_cast<uintptr_t>(Vt) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
   const int ntile = (Tn + AK - 1) / AK;
 #define FWD_PREFETCH(t_)                                                                 \
   {                                                                                      \
     const int k0_ = (t_) * AK;                                                           \
     tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + AK <= Tn);       \
-    tile_load<T, DP, AK>(rv, Vt, Tp, 0, DP, k0_, Tp, tid, true);                         \
+    if constexpr (VTR) tile_load<T, AK, DP>(rv2, Vt, p.ld, k0_, Tn, 0, d, tid, v_al && k0_ + AK <= Tn); \
+    else tile_load<T, DP, AK>(rv, Vt, Tp, 0, DP, k0_, Tp, tid, true);                    \
     if (bias) bias_load<T, AQ>(rb, bias, p.bias_ld, q0, Tn, k0_, tid);                   \
   }
   FWD_PREFETCH(0)
@@ -292,7 +315,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
     const int k0 = t * AK;
     __syncthreads();  // previous tile fully consumed
     tile_store<T, AK, DP>(rk, sK, tid);
-    tile_store<T, DP, AK>(rv, sVt, tid);
+    if constexpr (VTR) tile_store<T, AK, DP>(rv2, sVt, tid); else tile_store<T, DP, AK>(rv, sVt, tid);
     if (bias) bias_store<T, AQ>(rb, sB, tid);
     if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] * LOG2E : 0.f) : MASKED;
     __syncthreads();
@@ -359,7 +382,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
       Frag<T> pf = pack_frag8<T>(pv);
 #pragma unroll
       for (int t2 = 0; t2 < DT; ++t2) {
-        Frag<T> vf = FragReader<T, AK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+        Frag<T> vf;
+        if constexpr (VTR) vf = frag_tr<Pitch<T, DP>::v>(sVt, t2 * 32, 16 * kk + 4 * half, 16 * kk + 4 * half + 8, lane);
+        else vf = FragReader<T, AK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
         mma_step(vf, pf, o[t2]);
       }
     }
@@ -756,22 +781,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 // ================================================================================================
 constexpr int FQ = 64;     // queries per step
 constexpr int FKEYS = 128; // keys per workgroup
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-// fragment for an MFMA operand whose row index is the contiguous LDS dimension: rows (lane&31) + col0, reduction
-// indices {k0..k0+3} and {k1..k1+3} (LDS rows) -> two transpose reads of a [4 k][16 rows] block per 16-lane group
-template <int PITCH>
-__device__ __forceinline__ Frag<bf16_t> frag_tr(const char* tile, int col0, int k0, int k1, int lane) {
-  typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
-  const int c = col0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int kr = (lane & 15) >> 2;
-  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + (k0 + kr) * PITCH + c * 2));
-  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + (k1 + kr) * PITCH + c * 2));
-  uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-  Frag<bf16_t> f;
-  f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
-  return f;
-}
-
 // bias tile [FQ queries][FKEYS keys] of bf16: 16-byte vector i of thread tid (4 per thread).  Kept as four named
 // registers on purpose: as an array the set ended up in scratch memory.
 __device__ __forceinline__ uint4 fused_bias_load(const bf16_t* bias, int64_t ld, int q0, int Tn, int key0, int tid, int i) {
@@ -1086,7 +1095,8 @@ template <int DP> static size_t fused_smem() {
 }
 
 template <typename T, int DP> static size_t fwd_smem() {
-  size_t a = (size_t)AK * Pitch<T, DP>::v + (size_t)DP * Pitch<T, AK>::v + (size_t)AQ * BiasPitch<T>::v + AK * sizeof(float);
+  size_t vt = (size_t)DP * Pitch<T, AK>::v, vr = (size_t)AK * Pitch<T, DP>::v;
+  size_t a = (size_t)AK * Pitch<T, DP>::v + (vt > vr ? vt : vr) + (size_t)AQ * BiasPitch<T>::v + AK * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
@@ -1117,10 +1127,18 @@ static int set_smem(KernelT kern, size_t bytes) {
 template <typename T, int DP, bool DROP>
 static int launch_fwd_d(const AttnParams& p, hipStream_t st) {
   size_t sh = fwd_smem<T, DP>();
-  int rc = set_smem(attn_fwd_kernel<T, DP, DROP>, sh);
-  if (rc) return rc;
   dim3 grid((p.T + AQ - 1) / AQ, p.nh, p.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP>), grid, dim3(256), sh, st, p);
+  if constexpr (sizeof(T) == 2) {
+    if (p.vt == nullptr) {   // V given row-major: transpose reads
+      int rc = set_smem(attn_fwd_kernel<T, DP, DROP, true>, sh);
+      if (rc) return rc;
+      hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, true>), grid, dim3(256), sh, st, p);
+      return check_launch("peneo_attn_fwd");
+    }
+  }
+  int rc = set_smem(attn_fwd_kernel<T, DP, DROP, false>, sh);
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, false>), grid, dim3(256), sh, st, p);
   return check_launch("peneo_attn_fwd");
 }
 template <typename T, int DP>
@@ -1245,16 +1263,16 @@ static int attn_common_check(const char* who, int dtype, int B, int nh, int T, i
   return PENEO_OK;
 }
 
-extern "C" int peneo_attn_fwd(int dtype, const void* q, const void* k, int64_t ld_qk, const void* vt, int B, int nh, int T,
+extern "C" int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qk, const void* vt, int B, int nh, int T,
                               int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias, void* out,
                               int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
   int rc = attn_common_check("peneo_attn_fwd", dtype, B, nh, T, d, bias, bias_ld);
   if (rc) return rc;
-  PENEO_REQUIRE(q && k && vt && out, "peneo_attn_fwd: null pointer");
+  PENEO_REQUIRE(q && k && out && (vt || (v && dtype == PENEO_BF16)), "peneo_attn_fwd: null pointer (fp32 needs the transposed copy vt)");
   PENEO_REQUIRE(ld_qk >= (int64_t)nh * d && ld_out >= (int64_t)nh * d, "peneo_attn_fwd: leading dims too small");
   PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_attn_fwd: drop_p out of range");
   AttnParams p = {};
-  p.q = q; p.k = k; p.ld = ld_qk; p.vt = vt; p.B = B; p.nh = nh; p.T = T; p.d = d; p.Tp = peneo_attn_padded_len(T);
+  p.q = q; p.k = k; p.v = v; p.ld = ld_qk; p.vt = vt; p.B = B; p.nh = nh; p.T = T; p.d = d; p.Tp = peneo_attn_padded_len(T);
   p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias; p.out = out; p.ld_out = ld_out; p.lse = lse;
   p.drop_p = drop_p; p.seed = drop_seed;
   return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, false, (hipStream_t)stream) : dispatch<float>(p, false, (hipStream_t)stream);

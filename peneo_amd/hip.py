@@ -93,7 +93,7 @@ SIGNATURES = {
     "peneo_attn_padded_len": (_i, [_i]),
     "peneo_attn_padded_dim": (_i, [_i]),
     "peneo_head_transpose": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
-    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
+    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
     "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp,
                             _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _u32, _vp]),
     "peneo_pair_heads_packed_bytes": (_sz, [_i, _i, _i]),

@@ -380,11 +380,11 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int,
     """q/k/v: 2-D views [B*T, nh*d] with a common row stride (e.g. slices of a fused QKV buffer).
     bias: [B, nh, T, Tp] from relpos_bias_fwd (masking folded in); key_bias: fp32 [B, Tp] additive (0 / -1e30)."""
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
-    if vt is None:
+    if vt is None and q.dtype != torch.bfloat16:   # bf16 reads V in place (transpose reads); fp32 needs the transposed copy
         vt = head_transpose(v, B, nh, T, d)
     out = torch.empty((B * T, nh * d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
-    check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), q.stride(0), ptr(vt), B, nh, T, d, scale, ptr(bias),
+    check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(vt), B, nh, T, d, scale, ptr(bias),
                                bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(out), out.stride(0), ptr(lse),
                                drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_fwd")
     return out, lse
