@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# The step uses 4 HIP streams per process (main, weight gradients, decoder stage 2, bias-table reduction) plus RCCL's.
+# ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; one process per GPU runs the same with 2 or 8,
+# but two processes sharing ONE GPU (the gloo smoke test of the multi-process path) collapse 30x at the default.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
