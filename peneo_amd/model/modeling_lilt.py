@@ -110,27 +110,33 @@ def _post_attn_fwd(wc: WeightCache, key: str, dt, eps, seeds: DropoutSeeds, site
     return out, (att, h1, m1, r1, a, zi, inter, h2, m2, r2)
 
 
-def _post_attn_bwd(wc: WeightCache, key: str, dt, seeds: DropoutSeeds, site: int, d_out, saved, params):
-    """-> (d_att, d_x_residual, grads in parameter order)"""
+def _post_attn_bwd(wc: WeightCache, key: str, dt, seeds: DropoutSeeds, site: int, d_out, saved, params, on_side):
+    """-> (d_att, d_x_residual, grads in parameter order).  ``on_side(fn)`` runs the parameter-gradient work (wgrad
+    GEMMs, bias column sums) on the stage's second stream, off the activation-gradient critical path."""
     wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2 = params
     att, h1, m1, r1, a, zi, inter, h2, m2, r2 = saved
     Wo, Wi, Wo2 = wc.cast(key + ".o", wo, dt), wc.cast(key + ".i", wi, dt), wc.cast(key + ".o2", wo2, dt)
     dev = d_out.device
-    f32 = lambda p: torch.zeros(p.shape, dtype=torch.float32, device=dev)
-    dg2, db2 = f32(g2), f32(b2)
-    d_h2 = ops.layernorm_bwd(d_out.contiguous(), h2, g2, m2, r2, dg2, db2)
-    d_dense2 = ops.copy2d(d_h2, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 1)) if seeds.p_hidden > 0 else d_h2
-    dbo2 = ops.colsum(d_dense2)
-    dwo2 = ops.gemm(d_dense2, inter, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    Hs, Is = wo.shape[0], wi.shape[0]
+    wgrad = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    pool = torch.zeros(4 * Hs + (Hs + Is + Hs), dtype=torch.float32, device=dev)   # one fill for all small accumulators
+    dg2, db2, dg1, db1 = pool[:Hs], pool[Hs:2 * Hs], pool[2 * Hs:3 * Hs], pool[3 * Hs:4 * Hs]
+    dbo2, dbi, dbo = pool[4 * Hs:5 * Hs], pool[5 * Hs:5 * Hs + Is], pool[5 * Hs + Is:]
+    d_dense2 = torch.empty_like(h2) if seeds.p_hidden > 0 else None
+    d_h2 = ops.layernorm_bwd(d_out.contiguous(), h2, g2, m2, r2, dg2, db2, dx_dropped=d_dense2, drop2_p=seeds.p_hidden,
+                             drop2_seed=seeds.seed(site + 1))
+    if d_dense2 is None:
+        d_dense2 = d_h2
+    _, dwo2 = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)))
     d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
-    dbi = ops.colsum(d_zi)
-    dwi = ops.gemm(d_zi, a, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    _, dwi = on_side(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
     d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
-    dg1, db1 = f32(g1), f32(b1)
-    d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1)
-    d_dense1 = ops.copy2d(d_h1, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site)) if seeds.p_hidden > 0 else d_h1
-    dbo = ops.colsum(d_dense1)
-    dwo = ops.gemm(d_dense1, att, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
+    d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1, dx_dropped=d_dense1, drop2_p=seeds.p_hidden,
+                             drop2_seed=seeds.seed(site))
+    if d_dense1 is None:
+        d_dense1 = d_h1
+    _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
     d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
     return d_att, d_h1, (dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2)
 
@@ -265,8 +271,18 @@ class _LiltLayerStage(torch.autograd.Function):
         site = 32 * (idx + 1)
         dev = x.device
         R = x.shape[0]
-        d_att, d_x_res, gt = _post_attn_bwd(wc, f"L{idx}.t", dt, seeds, site + 2, d_xo, sv_t, tp)
-        d_latt, d_l_res, gl = _post_attn_bwd(wc, f"L{idx}.l", dt, seeds, site + 6, d_lo, sv_l, lp)
+        main = torch.cuda.current_stream()
+        side = model.side_stream(dev)
+
+        def on_side(fn):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                return fn()
+
+        d_att, d_x_res, gt = _post_attn_bwd(wc, f"L{idx}.t", dt, seeds, site + 2, d_xo, sv_t, tp, on_side)
+        d_latt, d_l_res, gl = _post_attn_bwd(wc, f"L{idx}.l", dt, seeds, site + 6, d_lo, sv_l, lp, on_side)
         d_attc = torch.empty((R, nh * dc), dtype=dt, device=dev)
         ops.head_concat(d_att, d_latt, nh, d_attc)
         qc, kc, vc = cat[:, :nh * dc], cat[:, nh * dc:2 * nh * dc], cat[:, 2 * nh * dc:]
@@ -280,11 +296,11 @@ class _LiltLayerStage(torch.autograd.Function):
         ops.head_split(dcat[:, 2 * nh * dc:], nh, dqkv[:, 2 * H:], dlqkv[:, 2 * Hl:])
         Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
         Wlqkv = wc.cat_rows(f"L{idx}.lqkv", [lwq, lwk, lwv], dt)
-        dbqkv, dblqkv = ops.colsum(dqkv), ops.colsum(dlqkv)
-        dwqkv = ops.gemm(dqkv, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
-        dwlqkv = ops.gemm(dlqkv, l, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        wg = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_x_res)
         d_l = ops.gemm(dlqkv, Wlqkv, b_kmajor=False, residual=d_l_res)
+        main.wait_stream(side)
         grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
                  dwlqkv[:Hl], dblqkv[:Hl], dwlqkv[Hl:2 * Hl], dblqkv[Hl:2 * Hl], dwlqkv[2 * Hl:], dblqkv[2 * Hl:]) + gt + gl
         grads = tuple(gr if p.requires_grad else None for gr, p in zip(grads, ctx.params))
@@ -330,6 +346,13 @@ class LiltModel(nn.Module):
         self.weight_cache = WeightCache()
         self.compute_dtype = torch.float32
         self._consts = {}
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        key = ("side", str(device))
+        if key not in self._consts:
+            self._consts[key] = torch.cuda.Stream(device=device)
+        return self._consts[key]
+
 
     def zeros(self, key, shape, dev):
         k = (key, str(shape), str(dev))
