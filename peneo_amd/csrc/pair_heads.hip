@@ -383,6 +383,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
   constexpr bool ASM_DMA = (VARIANT & 1) != 0, PIPE_EPI = (VARIANT & 2) != 0, DUAL = (VARIANT & 4) != 0;
   constexpr bool SGB = (VARIANT & 16) != 0;       // sched_group_barrier interleave: 1 MFMA : 1 ds_read : few VALU
   constexpr bool NOSTREAM = (VARIANT & 8) != 0;
+  constexpr bool G2 = (VARIANT & 128) != 0;       // 4 stages, ONE barrier per TWO slabs (needs ASM_DMA, NSTAGE == 4)
   constexpr bool NO_EPI = (VARIANT & 32) != 0, NO_LDS = (VARIANT & 64) != 0;   // ablations (wrong results)   // timing experiment only (wrong results): no DMA / barrier in the loop
   constexpr int NF = KS + 2;
   constexpr int PAYLOAD = NF * 64 * FragBytes<T>::v;
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
   const unsigned long long t1 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   // prologue: NSTAGE-1 slabs in flight
 #pragma unroll
-  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+  for (int s0 = 0; s0 < (G2 ? 2 : NSTAGE - 1); ++s0)
     if (s0 < nslab) dma(s0, s0);
 
   f32x16_t lg, zp;   // logits^T[class, pair]; first-layer accumulator of the previous slab
@@ -514,6 +515,16 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
 
   for (int slab = 0; slab < nslab; ++slab) {
     if constexpr (NOSTREAM) {
+    } else if constexpr (G2) {
+      // the waves meet only every second slab: between barriers they drift apart, so one wave's SiLU epilogue (VALU)
+      // runs under the other wave's MFMAs on the same SIMD instead of both doing the same phase at the same time
+      if ((slab & 1) == 0) {
+        wait_vm<0>();                        // slabs slab, slab+1 (issued two slabs ago) have landed
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (slab + 2 < nslab) dma(slab + 2, (slab + 2) % NSTAGE);
+        if (slab + 3 < nslab) dma(slab + 3, (slab + 3) % NSTAGE);
+      }
     } else if constexpr (ASM_DMA) {
       // slabs slab .. slab+NSTAGE-2 are in flight (only `slab` itself at the very end): wait for the oldest one
       if (NSTAGE > 2 && slab + 1 < nslab) wait_vm<(NSTAGE - 2) * UPW>(); else wait_vm<0>();
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
     } else {
       __syncthreads();   // hipcc places s_waitcnt vmcnt(0) in front of it while a DMA it knows of is in flight
     }
-    if (!NOSTREAM && slab + NSTAGE - 1 < nslab) dma(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE);
+    if (!NOSTREAM && !G2 && slab + NSTAGE - 1 < nslab) dma(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE);
     const char* wb = sW + (slab % NSTAGE) * SLAB_BYTES;
     if constexpr (PIPE_EPI) second_layer(zp, slab > 0 ? slab - 1 : 0, w2p0, w2p1);
     f32x16_t z, z2;
@@ -885,7 +896,7 @@ static int launch_pair_fwd_pipe(const PairFwdParams& p, hipStream_t st) {
 
 template <typename T, int KS, int VARIANT>
 static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
-  constexpr int NSTAGE = sizeof(T) == 2 ? 3 : 2;
+  constexpr int NSTAGE = (VARIANT & 128) ? 4 : (sizeof(T) == 2 ? 3 : 2);
   const size_t slab = (size_t)slab_stride_bytes(KS * 16, (int)sizeof(T));
   size_t sh = NSTAGE * slab + (size_t)p.num_heads * p.D * sizeof(float);
   if (sh < (size_t)PH_WAVES * 32 * sizeof(float)) sh = (size_t)PH_WAVES * 32 * sizeof(float);
@@ -921,6 +932,7 @@ static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
       case 8: return launch_pair_fwd_v<T, KS, 8>(p, st);
       case 12: return launch_pair_fwd_v<T, KS, 12>(p, st);
       case 14: return launch_pair_fwd_v<T, KS, 14>(p, st);
+      case 129: return launch_pair_fwd_v<T, KS, 129>(p, st);   // asm DMA + one barrier per two slabs
       case 16: return launch_pair_fwd_v<T, KS, 16>(p, st);
       case 17: return launch_pair_fwd_v<T, KS, 17>(p, st);
       case 18: return launch_pair_fwd_v<T, KS, 18>(p, st);
