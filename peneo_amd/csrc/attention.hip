@@ -29,6 +29,14 @@ constexpr float LOG2E = 1.4426950408889634f;
 // raw v_exp_f32: arguments here are <= 0 (or hugely negative for masked keys), results in [0, 1]; no denormal fix-up needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Attention-probability dropout: keep(q row, key) = mix32(rowhash ^ key) >= thresh with one hash per (b, h, q) row
+// (computed once per lane or per staged row), i.e. one mix32 (two quarter-rate 32-bit multiplies) per element instead
+// of the three of the generic (seed, 64-bit element index) form.  Forward and both backward paths share it.
+__device__ __forceinline__ uint32_t attn_rowhash(uint32_t seed, int64_t rowid) {
+  return mix32(seed ^ ((uint32_t)rowid * 0x9e3779b9u) ^ ((uint32_t)(rowid >> 32) * 0x85ebca6bu));
+}
+__device__ __forceinline__ bool attn_keep(uint32_t rowhash, int key, uint32_t thresh) { return mix32(rowhash ^ (uint32_t)key) >= thresh; }
+
 // ---- LDS tiles: row-major [rows][COLS] of T, pitch = COLS*sizeof(T) + 16 bytes (odd number of 16-byte
 //      slots => 16 consecutive rows hit 16 different slots: conflict-free b128 column reads)
 template <typename T, int COLS> struct Pitch { static constexpr int v = COLS * (int)sizeof(T) + 16; };
@@ -295,6 +303,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = MASKED, l_run = 0.f;
+  const uint32_t my_rh = attn_rowhash(p.seed, ((int64_t)b * p.nh + h) * Tn + myq);
 
   TileRegs<T, AK, DP> rk;
   TileRegs<T, DP, AK> rv;
@@ -359,11 +368,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
       for (int r = 0; r < 16; ++r) {
         float e = fast_exp2(s[kt][r] - m_new);
         ls += e;
-        if (DROP) {
-          const int key = k0 + kt * 32 + acc_row(r, lane);
-          uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)myq) * Tn + key;
-          e = dropout_keep(p.seed, idx, thresh) ? e * keep_scale : 0.f;
-        }
+        if (DROP) e = attn_keep(my_rh, k0 + kt * 32 + acc_row(r, lane), thresh) ? e * keep_scale : 0.f;
         s[kt][r] = e;
       }
     ls += __shfl_xor(ls, 32, 64);
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + myq;
   const float my_lse = myq < Tn ? p.lse[rowid] : 0.f;      // log2 units
   const float my_delta = myq < Tn ? p.delta[rowid] : 0.f;
+  const uint32_t my_rh = attn_rowhash(p.seed, rowid);
 
   f32x16_t dq[DT];
 #pragma unroll
@@ -559,10 +565,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
           const float v = fmaf(s[kt][4 * g + e], sc2, fmaf(bb[e], LOG2E, sKb[kl + e]));
           const float pr = (myq < Tn) ? fast_exp2(v - my_lse) : 0.f;
           float dpv = dp[kt][4 * g + e];
-          if (DROP) {
-            uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)myq) * Tn + (k0 + kl + e);
-            dpv = dropout_keep(p.seed, idx, thresh) ? dpv * keep_scale : 0.f;
-          }
+          if (DROP) dpv = attn_keep(my_rh, k0 + kl + e, thresh) ? dpv * keep_scale : 0.f;
           dsv[e] = pr * (dpv - my_delta);
           s[kt][4 * g + e] = dsv[e];
         }
@@ -621,7 +624,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   char* sdOt = sQt + DP * Pitch<T, AK>::v;            // [DP][AK q]
   float* sLse = reinterpret_cast<float*>(sdOt + DP * Pitch<T, AK>::v);  // [AK]
   float* sDelta = sLse + AK;                          // [AK]
-  char* sB = reinterpret_cast<char*>(sDelta + AK);    // bias: [AK q][AQ keys] T
+  uint32_t* sRh = reinterpret_cast<uint32_t*>(sDelta + AK);   // [AK] dropout row hashes
+  char* sB = reinterpret_cast<char*>(sRh + AK);       // bias: [AK q][AQ keys] T
   constexpr int BP = AQ * (int)sizeof(T) + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * AQ;
@@ -688,6 +692,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
       sLse[tid] = qq < Tn ? p.lse[rowid] : 0.f;
       sDelta[tid] = qq < Tn ? p.delta[rowid] : 0.f;
+      sRh[tid] = attn_rowhash(p.seed, rowid);
     }
     if (bias) {
 #pragma unroll
@@ -728,8 +733,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         float dpv = dp[qt][r];
         float pdrop = pv;
         if (DROP) {
-          uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)qq) * Tn + mykey;
-          bool keep = dropout_keep(p.seed, idx, thresh);
+          bool keep = attn_keep(sRh[ql], mykey, thresh);
           dpv = keep ? dpv * keep_scale : 0.f;
           pdrop = keep ? pv * keep_scale : 0.f;
         }
@@ -811,6 +815,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
   char* sB = sS + FKEYS * PS;                       // [FQ][FKEYS]  bias
   float* sLse = reinterpret_cast<float*>(sB + FQ * PB);   // [FQ]
   float* sDelta = sLse + FQ;                        // [FQ]
+  uint32_t* sRh = reinterpret_cast<uint32_t*>(sDelta + FQ);   // [FQ] dropout row hashes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * FKEYS;
   const int Tn = p.T, d = p.d, Tp = p.Tp;
@@ -876,6 +881,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
       const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
       sLse[tid] = qq < Tn ? p.lse[rowid] : 0.f;
       sDelta[tid] = qq < Tn ? p.delta[rowid] : 0.f;
+      if (DROP) sRh[tid] = attn_rowhash(p.seed, rowid);
     }
     if constexpr (HAS_BIAS) {
       fused_bias_store<PB>(rb0, sB, tid, 0);
@@ -907,6 +913,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
         const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb);
         const float4 d4 = *reinterpret_cast<const float4*>(sDelta + qb);
         const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
+        uint4 h4 = make_uint4(0, 0, 0, 0);
+        if (DROP) h4 = *reinterpret_cast<const uint4*>(sRh + qb);
+        const uint32_t rh4[4] = {h4.x, h4.y, h4.z, h4.w};
         float ds4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -918,8 +927,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
           float dpv = dp[r];
           float pdrop = pv;
           if (DROP) {
-            const uint64_t idx = (((uint64_t)b * p.nh + h) * Tn + (uint64_t)qq) * Tn + mykey;
-            const bool keep = dropout_keep(p.seed, idx, thresh);
+            const bool keep = attn_keep(rh4[e], mykey, thresh);
             dpv = keep ? dpv * keep_scale : 0.f;
             pdrop = keep ? pv * keep_scale : 0.f;
           }
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(256) void dq_finish_kernel(const float* acc, int64_
 
 template <int DP> static size_t fused_smem() {
   size_t a = (size_t)2 * FQ * Pitch<bf16_t, DP>::v + (size_t)FKEYS * Pitch<bf16_t, DP>::v + (size_t)FKEYS * (FQ * 2 + 16) +
-             (size_t)FQ * (FKEYS * 2 + 16) + 2 * FQ * sizeof(float);
+             (size_t)FQ * (FKEYS * 2 + 16) + 3 * FQ * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
@@ -1107,7 +1115,7 @@ template <typename T, int DP> static size_t dq_smem() {
   return a > o ? a : o;
 }
 template <typename T, int DP> static size_t dkv_smem() {
-  size_t a = (size_t)2 * AK * Pitch<T, DP>::v + (size_t)2 * DP * Pitch<T, AK>::v + 2 * AK * sizeof(float) +
+  size_t a = (size_t)2 * AK * Pitch<T, DP>::v + (size_t)2 * DP * Pitch<T, AK>::v + 3 * AK * sizeof(float) +
              (size_t)AK * (AQ * sizeof(T) + 16);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
