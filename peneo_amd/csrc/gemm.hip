@@ -220,9 +220,9 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
   if (e.drop_p > 0.f) {
     const uint32_t thresh = (uint32_t)fminf(e.drop_p * 4294967296.0f, 4294967040.0f);
     const float ks = 1.0f / (1.0f - e.drop_p);
+    const uint32_t keep = dropout_keep8(e.drop_seed, (uint64_t)m * (uint64_t)p.N + n, thresh);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      v[i] = dropout_keep(e.drop_seed, (uint64_t)m * (uint64_t)p.N + n + i, thresh) ? v[i] * ks : 0.f;
+    for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * ks : 0.f;
   }
   if (e.residual) {
     float r[8];

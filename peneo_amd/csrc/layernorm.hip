@@ -216,10 +216,11 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* 
       *reinterpret_cast<float4*>(gm + e) = *reinterpret_cast<const float4*>(gamma + c0 + e);
       *reinterpret_cast<float4*>(bt + e) = *reinterpret_cast<const float4*>(beta + c0 + e);
     }
+    const uint32_t dbase = DROP ? dropout_base(seed, (uint64_t)r * H + c0) : 0u;   // a 16-byte vector never straddles 2^32
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float t = (v[k][e] - mu) * rs * gm[e] + bt[e];
-      if (DROP) t = dropout_keep(seed, (uint64_t)r * H + c0 + e, thresh) ? t * keep_scale : 0.f;
+      if (DROP) t = dropout_keep_b(dbase, (uint32_t)((uint64_t)r * H + c0 + e), thresh) ? t * keep_scale : 0.f;
       o[e] = t;
     }
     *reinterpret_cast<uint4*>(yr + c0) = pack16<T>(o);
@@ -269,10 +270,11 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
       float d[VEC], xv[VEC];
       unpack16<T>(rd[k], d);
       unpack16<T>(rx[k], xv);
+      const uint32_t dbase = DROP ? dropout_base(seed, (uint64_t)r * H + (hl + 32 * k) * VEC) : 0u;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float dd = d[e];
-        if (DROP) dd = dropout_keep(seed, (uint64_t)r * H + (hl + 32 * k) * VEC + e, thresh) ? dd * keep_scale : 0.f;
+        if (DROP) dd = dropout_keep_b(dbase, (uint32_t)((uint64_t)r * H + (hl + 32 * k) * VEC + e), thresh) ? dd * keep_scale : 0.f;
         const float h = (xv[e] - mu) * rs;
         xh[k][e] = h;
         ag[k][e] += dd * h;
@@ -292,9 +294,10 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
       for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
       *reinterpret_cast<uint4*>(dxr + (hl + 32 * k) * VEC) = pack16<T>(o);
       if (dx2) {   // second output: dx through the dropout mask of the producer GEMM (contiguous [rows, H])
+        const uint32_t b2 = dropout_base(seed2, (uint64_t)r * H + (hl + 32 * k) * VEC);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          o[e] = (drop2_p > 0.f && !dropout_keep(seed2, (uint64_t)r * H + (hl + 32 * k) * VEC + e, thresh2)) ? 0.f : o[e] * keep2;
+          o[e] = (drop2_p > 0.f && !dropout_keep_b(b2, (uint32_t)((uint64_t)r * H + (hl + 32 * k) * VEC + e), thresh2)) ? 0.f : o[e] * keep2;
         *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + (hl + 32 * k) * VEC) = pack16<T>(o);
       }
     }
