@@ -257,3 +257,35 @@ def test_fused_adamw_training_steps_reduce_the_loss():
         losses.append(float(out["loss"].detach()))
         opt.step()
     assert losses[1] < losses[0] and losses[3] < losses[1], losses
+
+
+@pytest.mark.parametrize("env", [{"PENEO_ENC_SPLIT": "2"}, {"PENEO_WGRAD_STREAM": "0"}, {"PENEO_BWD_CHUNK_PAIRS": "300", "PENEO_DEC_STREAMS": "3"}])
+def test_optional_execution_modes_keep_the_gradients(env):
+    """Stream / chunking options (document-group streams through the encoder, weight gradients on the main stream, small
+    decoder-backward chunks on three streams) are read at import time: run the bf16 gradient check of the tiny golden in a
+    subprocess per setting."""
+    import os, subprocess, sys
+    code = """
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_golden
+from peneo_amd.model import PEneoConfig, PEneoModel
+fx = load_golden("lmv3_tiny")
+m = PEneoModel(PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"}))
+m.load_state_dict(fx["state_dict"], strict=True)
+m = m.cuda().set_compute_dtype(torch.bfloat16).eval()
+b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in fx["batch"].items()}
+out = m(**b); out["loss"].backward()
+assert abs(float(out["loss"]) - float(fx["outputs"]["loss"])) < 2e-2 * float(fx["outputs"]["loss"])
+bad = []
+for n, p in m.named_parameters():
+    g = fx["grads"].get(n)
+    if g is None or float(g.norm()) < 1e-6: continue
+    a, r = p.grad.float().cpu().flatten(), g.flatten()
+    cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-12))
+    if cos < 0.98: bad.append((n, cos))
+assert not bad, bad
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
