@@ -307,6 +307,15 @@ size_t peneo_pair_dz_workspace_bytes(int num_heads, int D);
 int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, float* workspace,
                   peneo_stream_t stream);
 
+/* dz of the pairs of rows i0..i1 of one document WITHOUT x or z in memory (bf16 only): x = SiLU(a_i + b_j) is rebuilt in
+ * registers, z = x W1cat^T + b1 comes off the matrix cores with lane = hidden column, and the same kernel turns it into
+ * dz [npairs, nh*D] and adds the dW2 / db1 column sums to `workspace` (layout of peneo_pair_dz).  `w_packed` is the
+ * fragment-packed weight buffer of peneo_pair_heads_pack (its second-layer fragments are not used here).
+ * Replaces peneo_pair_x_fwd (for z) + the first-layer GEMM + peneo_pair_dz of the chunked backward
+ * (the autograd graph through model/peneo_decoder.py:269-336). */
+int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* w_packed, const float* b1,
+                        const peneo_pair_dz_args* args, void* dz, float* workspace, peneo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K13 — loss finish: reduces the per-workgroup partial rows of peneo_pair_heads_fwd:
  *   loss_h = num_h / den_h ; total = sum_h ratio_h * loss_h ; scale_h = ratio_h / den_h (the factor the

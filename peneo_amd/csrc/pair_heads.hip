@@ -964,6 +964,224 @@ static int dispatch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
   }
 }
 
+// ================================================================================================
+// dz of one pair chunk without x or z in memory.  Same skeleton as pair_heads_fwd_kernel (x = SiLU(a_i + b_j) kept as
+// fragments in registers, first-layer weight slabs streamed L2 -> LDS), but the MFMA operands are swapped so that the
+// accumulator holds z[pair, hidden] with lane = hidden column and the 16 registers = 16 pairs:
+//   * the per-column constants (b1, the three W2 rows) are one 16-byte LDS read per lane per slab,
+//   * dW2[c, k] = sum_p g[p, c] y[p, k] and db1[k] = sum_p dz[p, k] reduce over REGISTERS (+ one half-wave swap),
+//   * dz leaves as 64-byte row segments straight from the accumulator layout.
+// The 8 waves' column sums of a slab meet in LDS and one wave adds them to the workspace (fp32 atomics, 128 per slab).
+// ================================================================================================
+struct DzFusedParams {
+  const bf16_t* abd; int N, D; int64_t pbase, npairs;
+  const void* wp; const float* b1;
+  peneo_pair_dz_args a;
+  bf16_t* out; float* ws;
+};
+constexpr int DZF_SLOTS = 256;
+
+template <int KS>
+__global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFusedParams p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NSTAGE = 3;
+  constexpr int NF = KS + 2;
+  constexpr int PAYLOAD = NF * 64 * FragBytes<T>::v;
+  constexpr int UPW = (PAYLOAD / 1024 + PH_WAVES - 1) / PH_WAVES;
+  constexpr int SLAB_BYTES = UPW * PH_WAVES * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
+  char* sW = smem;                                                         // [NSTAGE][SLAB_BYTES]
+  float4* sCol = reinterpret_cast<float4*>(smem + NSTAGE * SLAB_BYTES);    // [ncol]: W2 rows 0..2 of the column, b1
+  float4* sG = sCol + ncol;                                                // [PH_WAVES][32]: scale * dlogits of the wave's pairs
+  float4* sPart = sG + PH_WAVES * 32;                                      // [2][PH_WAVES][32]: column sums of one slab
+  const int64_t lp0 = (int64_t)blockIdx.x * PH_PAIRS + wave * 32;          // first local pair of the wave
+  const int64_t lp = lp0 + (lane & 31);
+  const bool pair_ok = lp < p.npairs;
+  int pi, pj;
+  pair_decode(p.pbase + (pair_ok ? lp : p.npairs - 1), N, pi, pj);
+  const int nslab = ncol / 32, spb = D / 32;
+
+  for (int n = tid; n < ncol; n += PH_WAVES * 64) {
+    const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
+    sCol[n] = make_float4(p.a.w2[h][k], Cn > 1 ? p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? p.a.w2[h][(int64_t)2 * D + k] : 0.f,
+                          p.b1[n]);
+  }
+
+  const T* arow = p.abd + (int64_t)pi * 2 * D;
+  const T* brow = p.abd + (int64_t)pj * 2 * D + D;
+  Frag<T> xf[KS];
+  if constexpr (KS % 4 == 0) {
+    uint4 ra[2][4], rb[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
+      rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
+    }
+#pragma unroll
+    for (int g = 0; g < KS / 4; ++g) {
+      if (g + 1 < KS / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (4 * (g + 1) + i) + 8 * half);
+          rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (4 * (g + 1) + i) + 8 * half);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a[8], bb[8];
+        unpack16<T>(ra[g & 1][i], a);
+        unpack16<T>(rb[g & 1][i], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+        xf[4 * g + i] = pack_frag8<T>(a);
+        asm volatile("" : "+v"(xf[4 * g + i].v.x), "+v"(xf[4 * g + i].v.y), "+v"(xf[4 * g + i].v.z), "+v"(xf[4 * g + i].v.w) :: "memory");
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = 16 * ks + 8 * half;
+      float a[8], bb[8];
+      unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
+      unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+      xf[ks] = pack_frag8<T>(a);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                          // sCol visible
+
+  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
+  const uint32_t wdst = lds_addr(sW) + wave * (UPW * 1024);
+  auto dma = [&](int slab_, int buf_) {
+    lds_dma_units<0, UPW>(wsrc + (int64_t)slab_ * SLAB_BYTES, __builtin_amdgcn_readfirstlane(wdst + buf_ * SLAB_BYTES));
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nslab) dma(s0, s0);
+
+  float* slot = p.ws + (int64_t)(blockIdx.x % DZF_SLOTS) * 4 * ncol;
+  // the wave that owns slab s adds the eight waves' column sums of that slab to the workspace
+  auto flush = [&](int s) {
+    if (wave == (s & (PH_WAVES - 1)) && lane < 32) {
+      const float4* src = sPart + (s & 1) * (PH_WAVES * 32) + lane;
+      float4 t = src[0];
+#pragma unroll
+      for (int w = 1; w < PH_WAVES; ++w) { const float4 u = src[w * 32]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      float* dst = slot + s * 32 + lane;
+      atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
+    }
+  };
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 one2 = f2{1.f, 1.f}, nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
+  const float4* myG = sG + wave * 32;
+  const int nrows = (int)min((int64_t)32, p.npairs - lp0);   // valid pairs of this wave's tile (may be <= 0)
+
+  // dz of a slab is stored at the START of the next slab (right behind the DMA issue): the stores then have a whole slab
+  // of compute to retire before the next vmcnt(0), instead of being waited for the moment they are issued
+  // (pend[j]: even lanes hold row 2j' of columns (c, c+1), odd lanes row 2j'+1 of columns (c-1, c): 4-byte stores)
+  uint32_t pend[8];
+  bf16_t* orow2 = p.out + lp0 * ncol + ((lane & 31) & ~1);
+  auto store_pending = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = acc_row(2 * j, lane) + (lane & 1);
+      if (row < nrows) *reinterpret_cast<uint32_t*>(orow2 + (int64_t)row * ncol + s * 32) = pend[j];
+    }
+  };
+  for (int slab = 0; slab < nslab; ++slab) {
+    // counted wait although stores and atomics share the vm counter (and may retire out of order with respect to loads):
+    // loads retire in order among themselves, so while a piece of slab `slab` is missing all UPW pieces of the younger
+    // slab+1 are missing too and the counter stays above UPW whatever the stores do
+    if (slab + 1 < nslab) wait_vm<UPW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (slab + NSTAGE - 1 < nslab) dma(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE);
+    if (slab > 0) { store_pending(slab - 1); flush(slab - 1); }
+    if (slab % spb == 0) {
+      const int h = slab / spb, Cn = p.a.classes[h];
+      if (lane < 32) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (pair_ok) {
+          const float sc = p.a.scale[h];
+          const float* dl = p.a.dlogits[h] + lp * Cn;
+          gx = dl[0] * sc;
+          if (Cn > 1) gy = dl[1] * sc;
+          if (Cn > 2) gz = dl[2] * sc;
+        }
+        // two adjacent pairs share 8 floats {g0, g0', g1, g1', g2, g2', -, -}: the packed-fp32 operands come out of LDS
+        // already paired
+        float* gp = reinterpret_cast<float*>(sG + wave * 32) + (lane >> 1) * 8 + (lane & 1);
+        gp[0] = gx; gp[2] = gy; gp[4] = gz;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const char* wb = sW + (slab % NSTAGE) * SLAB_BYTES;
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
+      mma_step(xf[ks], wf, z);                       // rows = pairs, columns = hidden units
+    }
+    const int col = slab * 32 + (lane & 31);
+    const float4 cw = sCol[col];
+    const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
+    f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r0 = 2 * j, row0 = acc_row(r0, lane);     // registers 2j, 2j+1 are the adjacent pairs row0, row0 + 1
+      const float4 g01 = myG[row0];                       // (row0 is even: float4 slots row0, row0 + 1 = that pair's 8 floats)
+      const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
+      const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
+      const f2 zz = f2{z[r0], z[r0 + 1]} + b1;
+      const f2 t = zz * nl2e;
+      const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+      const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+      const f2 y = zz * sg;
+      const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
+      const f2 dz = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
+      s0 = __builtin_elementwise_fma(g0, y, s0);
+      s1 = __builtin_elementwise_fma(g1, y, s1);
+      s2 = __builtin_elementwise_fma(g2, y, s2);
+      sb = sb + dz;
+      // neighbour lanes trade one value so that each holds two adjacent columns of ONE pair
+      const float give = (lane & 1) ? dz.x : dz.y;
+      const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+      pend[j] = (lane & 1) ? pack_bf16x2(got, dz.y) : pack_bf16x2(dz.x, got);
+    }
+    float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
+    part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
+    part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
+    if (lane < 32) sPart[(slab & 1) * (PH_WAVES * 32) + wave * 32 + lane] = part;
+  }
+  store_pending(nslab - 1);
+  __syncthreads();
+  flush(nslab - 1);
+}
+
+template <int KS>
+static int launch_pair_dz_fused(const DzFusedParams& p, hipStream_t st) {
+  const int ncol = p.a.num_heads * p.D;
+  const size_t sh = 3 * (size_t)slab_stride_bytes(KS * 16, 2) + (size_t)ncol * 16 + (size_t)PH_WAVES * 32 * 16 * 3;
+  if (sh > 160 * 1024) { set_error("peneo_pair_dz_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
+  if (sh > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dz_fused_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_error("peneo_pair_dz_fused: cannot raise dynamic LDS to %zu bytes", sh);
+    return PENEO_ERR_LAUNCH;
+  }
+  const int64_t blocks = (p.npairs + PH_PAIRS - 1) / PH_PAIRS;
+  hipLaunchKernelGGL(pair_dz_fused_kernel<KS>, dim3((unsigned)blocks), dim3(PH_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_dz_fused");
+}
+
 // label maps from sparse spots (b, i, j, tag): the dense [B, P] int64 maps the collator builds on the host
 // (data/collator.py:156-204 -> spots2shaking_tag4batch, model/peneo_decoder.py:35-73) scattered on the device instead.
 // "Last spot wins" like the host loop: a spot is skipped when a later one addresses the same cell.
@@ -1096,6 +1314,36 @@ extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int
   else { if (premultiplied) PENEO_XBWD(float, true) else PENEO_XBWD(float, false) }
 #undef PENEO_XBWD
   return check_launch("peneo_pair_x_bwd");
+}
+
+extern "C" int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* w_packed,
+                                   const float* b1, const peneo_pair_dz_args* args, void* dz, float* workspace,
+                                   peneo_stream_t stream) {
+  PENEO_REQUIRE(dtype == PENEO_BF16, "peneo_pair_dz_fused: bf16 only (the fp32 path runs peneo_gemm with a pair_dz epilogue)");
+  PENEO_REQUIRE(ab_doc && w_packed && b1 && args && dz && workspace, "peneo_pair_dz_fused: null argument");
+  PENEO_REQUIRE(N > 0 && i0 >= 0 && i1 > i0 && i1 <= N, "peneo_pair_dz_fused: bad row range [%d, %d) of %d", i0, i1, N);
+  PENEO_REQUIRE(args->D == D && D % 32 == 0, "peneo_pair_dz_fused: D=%d (args D=%d) must be a multiple of 32", D, args->D);
+  PENEO_REQUIRE(args->num_heads >= 1 && args->num_heads <= PENEO_MAX_HEADS && args->scale, "peneo_pair_dz_fused: bad head arguments");
+  for (int h = 0; h < args->num_heads; ++h)
+    PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3,
+                  "peneo_pair_dz_fused: head %d arguments invalid (classes must be 1..3)", h);
+  PENEO_REQUIRE((reinterpret_cast<uintptr_t>(ab_doc) & 15) == 0, "peneo_pair_dz_fused: ab must be 16-byte aligned");
+  DzFusedParams p;
+  p.abd = reinterpret_cast<const bf16_t*>(ab_doc); p.N = N; p.D = D;
+  p.pbase = pair_row_start(i0, N); p.npairs = pair_row_start(i1, N) - p.pbase;
+  p.wp = w_packed; p.b1 = b1; p.a = *args; p.out = reinterpret_cast<bf16_t*>(dz); p.ws = workspace;
+  hipStream_t st = (hipStream_t)stream;
+  switch (D / 16) {
+    case 2: return launch_pair_dz_fused<2>(p, st);
+    case 4: return launch_pair_dz_fused<4>(p, st);
+    case 6: return launch_pair_dz_fused<6>(p, st);
+    case 8: return launch_pair_dz_fused<8>(p, st);
+    case 12: return launch_pair_dz_fused<12>(p, st);
+    case 16: return launch_pair_dz_fused<16>(p, st);
+    case 24: return launch_pair_dz_fused<24>(p, st);
+    case 32: return launch_pair_dz_fused<32>(p, st);
+    default: set_error("peneo_pair_dz_fused: D=%d not supported (D/16 in {2,4,6,8,12,16,24,32})", D); return PENEO_ERR_INVALID;
+  }
 }
 
 extern "C" size_t peneo_pair_dz_workspace_bytes(int num_heads, int D) { return (size_t)DZ_SLOTS * 4 * num_heads * D * sizeof(float); }

@@ -250,6 +250,11 @@ class _DecoderStage(torch.autograd.Function):
         zbuf = [torch.empty((maxp, nh * D), dtype=dt, device=dev) for _ in range(2)]
         dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
         w2d = [w.detach().contiguous() for w in w2s]
+        fused_dz = (dec.fused_dz and not dec.three_streams and dt == torch.bfloat16 and D % 32 == 0
+                    and D // 16 in (2, 4, 6, 8, 12, 16, 24, 32))
+        if fused_dz:
+            wp = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
+                                                                                 [w.detach() for w in w2s]))
         main = torch.cuda.current_stream()
         side = dec.side_stream(dev)
         third = dec.side_stream(dev, 1) if dec.three_streams else None   # the weight-gradient GEMM on its own stream
@@ -271,10 +276,15 @@ class _DecoderStage(torch.autograd.Function):
                     main.wait_event(done[k])         # stage 2 of chunk idx-2 has released x[k] / z[k]
                     if third is not None:
                         main.wait_event(done_w[k])
-                ops.pair_x_fwd(ab[b], i0, i1, x, pre)
-                # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
                 dza = ops.pair_dz_args(D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, scale)
-                ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
+                if fused_dz:
+                    # dz straight from ab: x lives in registers, z in the MFMA accumulators (x / pre are only needed by
+                    # stage 2 and are produced there, on the side stream)
+                    ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws)
+                else:
+                    ops.pair_x_fwd(ab[b], i0, i1, x, pre)
+                    # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
+                    ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
                 ready[k].record(main)
                 if third is not None:
                     with torch.cuda.stream(third):
@@ -282,6 +292,8 @@ class _DecoderStage(torch.autograd.Function):
                         ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
                         done_w[k].record(third)
                 with torch.cuda.stream(side):
+                    if fused_dz:
+                        ops.pair_x_fwd(ab[b], i0, i1, x, pre)   # x[k] / pre[k] were released by this stream's own chunk idx-2
                     side.wait_event(ready[k])
                     if idx > 0:
                         side.wait_event(done_x)      # dxbuf is single-buffered: the previous chunk's scatter has read it
@@ -385,6 +397,7 @@ class PEneoDecoder(nn.Module):
         # 288 GB of HBM), and long launches amortise tile tails and the split-k reduction of the weight-gradient GEMM
         self.bwd_chunk_pairs = int(os.environ.get("PENEO_BWD_CHUNK_PAIRS", 1 << 18))
         self.three_streams = os.environ.get("PENEO_DEC_STREAMS", "2") == "3"   # measured: no gain over two
+        self.fused_dz = os.environ.get("PENEO_DZ_FUSED", "1") != "0"            # bf16: dz without x / z in memory
         self._ratio = {}
 
     def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:

@@ -520,6 +520,15 @@ def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogit
     check(lib().peneo_pair_dz(dtype_code(z.dtype), ptr(z), npairs, C.byref(a), ptr(workspace), stream()), "peneo_pair_dz")
 
 
+def pair_dz_fused(ab_doc: torch.Tensor, i0: int, i1: int, wp: torch.Tensor, b1: torch.Tensor, args: "hip.PairDzArgs",
+                  dz: torch.Tensor, workspace: torch.Tensor) -> None:
+    """dz [npairs, nh*D] of rows i0..i1 of one document straight from ab (bf16): no x / z round trip through memory."""
+    N, D2 = ab_doc.shape
+    with kernel_timer("pair_dz_fused"):
+        check(lib().peneo_pair_dz_fused(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(wp), ptr(b1),
+                                        C.byref(args), ptr(dz), ptr(workspace), stream()), "peneo_pair_dz_fused")
+
+
 def pair_dz_finish(workspace: torch.Tensor, nh: int, D: int, classes: Sequence[int]):
     """-> (dw2 list of [C_h, D] fp32, db1 [nh * D] fp32) from the accumulated workspace."""
     vec = colsum(workspace)                     # [4 * nh * D]

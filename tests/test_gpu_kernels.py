@@ -641,6 +641,57 @@ def test_pair_backward_blocks(ops, dtype):
         assert rel_err(dw2b[h], dw2a[h]) < (1e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("N,D,rows", [(45, 128, (7, 30)), (45, 128, (0, 45)), (70, 384, (0, 70)), (33, 64, (30, 33)),
+                                      (40, 96, (5, 6))])
+def test_pair_dz_fused_matches_the_gemm_epilogue(ops, N, D, rows):
+    """peneo_pair_dz_fused (x and z never in memory) against pair_x_fwd + the z GEMM with the pair-dz epilogue."""
+    dtype, classes = torch.bfloat16, [2, 3, 3, 3, 3]
+    nh = len(classes)
+    g = torch.Generator().manual_seed(N * 1000 + D)
+    ab = torch.randn(N, 2 * D, generator=g).to(DEV).to(dtype)
+    i0, i1 = rows
+    p0, p1 = i0 * N - i0 * (i0 - 1) // 2, i1 * N - i1 * (i1 - 1) // 2
+    npairs = p1 - p0
+    w1 = [(torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV) for _ in classes]
+    w2 = [torch.randn(c, D, generator=g).to(DEV) for c in classes]
+    b1cat = (0.1 * torch.randn(nh * D, generator=g)).to(DEV)
+    dl = [torch.randn(npairs, c, generator=g).to(DEV) for c in classes]
+    scale = torch.rand(nh, generator=g).to(DEV) + 0.5
+    w1cat = torch.cat(w1).to(dtype)
+    wp = ops.pair_heads_pack(dtype, w1, w2)
+    args = ops.pair_dz_args(D, classes, dl, w2, scale)
+    x = torch.empty(npairs, D, device=DEV, dtype=dtype)
+    ops.pair_x_fwd(ab, i0, i1, x)
+    ws_a = ops.pair_dz_workspace(nh, D, DEV)
+    za = torch.empty(npairs, nh * D, device=DEV, dtype=dtype)
+    ops.gemm(x, w1cat, bias=b1cat, out=za, pair_dz=args, pair_dz_ws=ws_a)
+    ws_b = ops.pair_dz_workspace(nh, D, DEV)
+    zb = torch.full((npairs + 3, nh * D), 7.0, device=DEV, dtype=dtype)     # guard rows behind the chunk
+    ops.pair_dz_fused(ab, i0, i1, wp, b1cat, args, zb, ws_b)
+    torch.cuda.synchronize()
+    assert bool((zb[npairs:] == 7.0).all())
+    assert rel_err(zb[:npairs], za) < 2e-2
+    dw2a, db1a = ops.pair_dz_finish(ws_a, nh, D, classes)
+    dw2b, db1b = ops.pair_dz_finish(ws_b, nh, D, classes)
+    assert rel_err(db1b, db1a) < 2e-2
+    for h in range(nh):
+        assert rel_err(dw2b[h], dw2a[h]) < 2e-2
+    # and against fp32 autograd of the same block
+    abf = ab.float()
+    ii, jj = torch.triu_indices(N, N, device=DEV)
+    xr = F.silu(abf[ii, :D] + abf[jj, D:])[p0:p1].to(dtype).float()
+    zr = (xr @ w1cat.float().t() + b1cat).requires_grad_(True)
+    w2r = [w.clone().requires_grad_(True) for w in w2]
+    tot = 0
+    for h in range(nh):
+        tot = tot + ((F.silu(zr[:, h * D:(h + 1) * D]) @ w2r[h].t()) * dl[h] * scale[h]).sum()
+    tot.backward()
+    assert rel_err(zb[:npairs], zr.grad) < 2e-2
+    assert rel_err(db1b, zr.grad.sum(0)) < 2e-2
+    for h in range(nh):
+        assert rel_err(dw2b[h], w2r[h].grad) < 2e-2
+
+
 def test_weighted_ce_and_spots(ops):
     from oracle import peneo_oracle as O
     N = 40

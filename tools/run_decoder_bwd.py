@@ -37,6 +37,19 @@ fl = 2.0 * npairs * nh * D * D
 bench("pair_x_fwd", lambda: ops.pair_x_fwd(ab, i0, i1, x))
 bench("gemm z (plain)", lambda: ops.gemm(x, w1, bias=b1, out=z))
 bench("gemm z + dz epilogue", lambda: ops.gemm(x, w1, bias=b1, out=z, pair_dz=dza, pair_dz_ws=ws))
+w1l = [w1[h * D:(h + 1) * D].float() for h in range(nh)]
+wp = ops.pair_heads_pack(dt, w1l, w2)
+bench("pair_dz_fused (no x / z)", lambda: ops.pair_dz_fused(ab, i0, i1, wp, b1, dza, z, ws))
+if os.environ.get("FULL"):
+    i1f = N
+    npf = N * (N + 1) // 2
+    zf = torch.empty(npf, nh * D, device=dev, dtype=dt)
+    dlf = [torch.randn(npf, c, device=dev) for c in classes]
+    dzaf = ops.pair_dz_args(D, classes, dlf, w2, scale)
+    bench("pair_dz_fused whole document", lambda: ops.pair_dz_fused(ab, 0, N, wp, b1, dzaf, zf, ws))
+    xf_ = torch.empty(npf, D, device=dev, dtype=dt)
+    ops.pair_x_fwd(ab, 0, N, xf_)
+    bench("gemm z + dz epilogue whole document", lambda: ops.gemm(xf_, w1, bias=b1, out=zf, pair_dz=dzaf, pair_dz_ws=ws))
 bench("pair_dz (separate)", lambda: ops.pair_dz(z, npairs, D, classes, dl, w2, ws, scale))
 bench("gemm dW += dz^T x", lambda: ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW, accumulate=True))
 bench("gemm dx = dz W1", lambda: ops.gemm(z, w1, b_kmajor=False, out=dx))
