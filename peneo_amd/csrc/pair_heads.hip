@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace peneo {
 
@@ -973,6 +974,9 @@ static int dispatch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
 //   * dz leaves as 64-byte row segments straight from the accumulator layout.
 // The 8 waves' column sums of a slab meet in LDS and one wave adds them to the workspace (fp32 atomics, 128 per slab).
 // ================================================================================================
+#ifndef DZF_ABLATE
+#define DZF_ABLATE 0   // timing experiments only (tools/): 1 no stores, 2 no dz arithmetic, 4 no g reads, 8 no exp/rcp, 16 no MFMA
+#endif
 struct DzFusedParams {
   const bf16_t* abd; int N, D; int64_t pbase, npairs;
   const void* wp; const float* b1;
@@ -981,11 +985,11 @@ struct DzFusedParams {
 };
 constexpr int DZF_SLOTS = 256;
 
-template <int KS>
+template <int KS, bool PIPE>
 __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFusedParams p) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NSTAGE = 3;
+  constexpr int NSTAGE = KS > 24 ? 2 : 3;   // D = 512: two stages, or the ring + the column table overflow the LDS
   constexpr int NF = KS + 2;
   constexpr int PAYLOAD = NF * 64 * FragBytes<T>::v;
   constexpr int UPW = (PAYLOAD / 1024 + PH_WAVES - 1) / PH_WAVES;
@@ -1081,105 +1085,149 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
   const float4* myG = sG + wave * 32;
   const int nrows = (int)min((int64_t)32, p.npairs - lp0);   // valid pairs of this wave's tile (may be <= 0)
 
-  // dz of a slab is stored at the START of the next slab (right behind the DMA issue): the stores then have a whole slab
-  // of compute to retire before the next vmcnt(0), instead of being waited for the moment they are issued
-  // (pend[j]: even lanes hold row 2j' of columns (c, c+1), odd lanes row 2j'+1 of columns (c-1, c): 4-byte stores)
-  uint32_t pend[8];
-  bf16_t* orow2 = p.out + lp0 * ncol + ((lane & 31) & ~1);
-  auto store_pending = [&](int s) {
+  // Software pipeline inside every wave: iteration s issues the first-layer MFMAs of slab s (3 per step for D = 384)
+  // BETWEEN the eight steps of the dz arithmetic of slab s-1, so the matrix pipe works in the shadow of the VALU-bound
+  // epilogue instead of alternating with it.  dz leaves as 4-byte stores: even lanes hold columns (c, c+1) of pair row 2j',
+  // odd lanes columns (c-1, c) of row 2j'+1 (neighbour lanes trade one value).
+  bf16_t* orow2 = p.out + lp0 * ncol + (int64_t)(4 * half + (lane & 1)) * ncol + ((lane & 31) & ~1);
+  const bool full_tile = nrows >= 32;
+  const bool odd = (lane & 1) != 0;
+  f32x16_t zp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zp[r] = 0.f;
+
+  auto stage_g = [&](int h) {
+    const int Cn = p.a.classes[h];
+    if (lane < 32) {
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+      if (pair_ok) {
+        const float sc = p.a.scale[h];
+        const float* dl = p.a.dlogits[h] + lp * Cn;
+        gx = dl[0] * sc;
+        if (Cn > 1) gy = dl[1] * sc;
+        if (Cn > 2) gz = dl[2] * sc;
+      }
+      // two adjacent pairs share 8 floats {g0, g0', g1, g1', g2, g2', -, -}: the packed-fp32 operands come out of LDS
+      // already paired
+      float* gp = reinterpret_cast<float*>(sG + wave * 32) + (lane >> 1) * 8 + (lane & 1);
+      gp[0] = gx; gp[2] = gy; gp[4] = gz;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // one iteration: MMA -> first layer of slab s into z ; EPI -> dz arithmetic of slab s-1 on zp
+  auto step = [&](auto mma_c, auto epi_c, int s) {
+    constexpr bool MMA = decltype(mma_c)::value, EPI = decltype(epi_c)::value;
+    const char* wb = sW + (s % NSTAGE) * SLAB_BYTES;
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    const int es = s - 1;
+    float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI) cw = sCol[es * 32 + (lane & 31)];
+    const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
+    f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
+    bf16_t* ocol = orow2 + es * 32;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int row = acc_row(2 * j, lane) + (lane & 1);
-      if (row < nrows) *reinterpret_cast<uint32_t*>(orow2 + (int64_t)row * ncol + s * 32) = pend[j];
+      if constexpr (MMA) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          if (ks * 8 / KS == j) {
+            Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
+            if constexpr (DZF_ABLATE & 16) { z[ks & 15] += __uint_as_float(wf.v.x); }
+            else mma_step(xf[ks], wf, z);                  // rows = pairs, columns = hidden units
+          }
+      }
+      if constexpr (EPI) {
+        const int r0 = 2 * j, rowc = (r0 & 3) + 8 * (r0 >> 2);   // accumulator registers 2j, 2j+1: pair rows rowc + 4*half + {0, 1}
+        const int row0 = rowc + 4 * half;
+        const float4 g01 = (DZF_ABLATE & 4) ? cw : myG[row0];   // (row0 is even: float4 slots row0, row0 + 1 = that pair's 8 floats)
+        const float2 g2v = (DZF_ABLATE & 4) ? make_float2(cw.x, cw.y) : *reinterpret_cast<const float2*>(myG + row0 + 1);
+        const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
+        const f2 zz = f2{zp[r0], zp[r0 + 1]} + b1;
+        const f2 t = zz * nl2e;
+        const f2 den = (DZF_ABLATE & 8) ? t + one2 : f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+        const f2 sg = (DZF_ABLATE & 8) ? den * nl2e : f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f2 y = zz * sg;
+        f2 dz;
+        if constexpr (DZF_ABLATE & 2) { dz = zz * g0; sb = sb + dz; }
+        else {
+          const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
+          dz = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
+          s0 = __builtin_elementwise_fma(g0, y, s0);
+          s1 = __builtin_elementwise_fma(g1, y, s1);
+          s2 = __builtin_elementwise_fma(g2, y, s2);
+          sb = sb + dz;
+        }
+        const float give = odd ? dz.x : dz.y;
+        const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+        const uint32_t packed = odd ? pack_bf16x2(got, dz.y) : pack_bf16x2(dz.x, got);
+        if constexpr (DZF_ABLATE & 1) { sb.x += __uint_as_float(packed) * 1e-30f; }
+        else if (full_tile || row0 + (lane & 1) < nrows)
+          *reinterpret_cast<uint32_t*>(ocol + (int64_t)rowc * ncol) = packed;
+      }
     }
+    if constexpr (EPI) {
+      float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
+      part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
+      part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
+      if (lane < 32) sPart[(es & 1) * (PH_WAVES * 32) + wave * 32 + lane] = part;
+    }
+    if constexpr (MMA) zp = z;
   };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+
   for (int slab = 0; slab < nslab; ++slab) {
     // counted wait although stores and atomics share the vm counter (and may retire out of order with respect to loads):
     // loads retire in order among themselves, so while a piece of slab `slab` is missing all UPW pieces of the younger
     // slab+1 are missing too and the counter stays above UPW whatever the stores do
-    if (slab + 1 < nslab) wait_vm<UPW>(); else wait_vm<0>();
+    if (NSTAGE > 2 && slab + 1 < nslab) wait_vm<(NSTAGE - 2) * UPW>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (slab + NSTAGE - 1 < nslab) dma(slab + NSTAGE - 1, (slab + NSTAGE - 1) % NSTAGE);
-    if (slab > 0) { store_pending(slab - 1); flush(slab - 1); }
-    if (slab % spb == 0) {
-      const int h = slab / spb, Cn = p.a.classes[h];
-      if (lane < 32) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        if (pair_ok) {
-          const float sc = p.a.scale[h];
-          const float* dl = p.a.dlogits[h] + lp * Cn;
-          gx = dl[0] * sc;
-          if (Cn > 1) gy = dl[1] * sc;
-          if (Cn > 2) gz = dl[2] * sc;
-        }
-        // two adjacent pairs share 8 floats {g0, g0', g1, g1', g2, g2', -, -}: the packed-fp32 operands come out of LDS
-        // already paired
-        float* gp = reinterpret_cast<float*>(sG + wave * 32) + (lane >> 1) * 8 + (lane & 1);
-        gp[0] = gx; gp[2] = gy; gp[4] = gz;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (PIPE) {
+      if (slab > 1) flush(slab - 2);                         // its eight partial rows were written before this barrier
+      if (slab > 0 && (slab - 1) % spb == 0) stage_g((slab - 1) / spb);
+      if (slab == 0) step(yes{}, no{}, slab); else step(yes{}, yes{}, slab);
+    } else {
+      if (slab > 0) flush(slab - 1);
+      if (slab % spb == 0) stage_g(slab / spb);
+      step(yes{}, no{}, slab);
+      step(no{}, yes{}, slab + 1);
     }
-    const char* wb = sW + (slab % NSTAGE) * SLAB_BYTES;
-    f32x16_t z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
-      mma_step(xf[ks], wf, z);                       // rows = pairs, columns = hidden units
-    }
-    const int col = slab * 32 + (lane & 31);
-    const float4 cw = sCol[col];
-    const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
-    f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r0 = 2 * j, row0 = acc_row(r0, lane);     // registers 2j, 2j+1 are the adjacent pairs row0, row0 + 1
-      const float4 g01 = myG[row0];                       // (row0 is even: float4 slots row0, row0 + 1 = that pair's 8 floats)
-      const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
-      const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
-      const f2 zz = f2{z[r0], z[r0 + 1]} + b1;
-      const f2 t = zz * nl2e;
-      const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
-      const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-      const f2 y = zz * sg;
-      const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
-      const f2 dz = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
-      s0 = __builtin_elementwise_fma(g0, y, s0);
-      s1 = __builtin_elementwise_fma(g1, y, s1);
-      s2 = __builtin_elementwise_fma(g2, y, s2);
-      sb = sb + dz;
-      // neighbour lanes trade one value so that each holds two adjacent columns of ONE pair
-      const float give = (lane & 1) ? dz.x : dz.y;
-      const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-      pend[j] = (lane & 1) ? pack_bf16x2(got, dz.y) : pack_bf16x2(dz.x, got);
-    }
-    float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
-    part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
-    part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
-    if (lane < 32) sPart[(slab & 1) * (PH_WAVES * 32) + wave * 32 + lane] = part;
   }
-  store_pending(nslab - 1);
+  if constexpr (PIPE) {
+    __syncthreads();
+    if (nslab > 1) flush(nslab - 2);
+    if ((nslab - 1) % spb == 0) stage_g((nslab - 1) / spb);
+    step(no{}, yes{}, nslab);
+  }
   __syncthreads();
   flush(nslab - 1);
 }
 
-template <int KS>
-static int launch_pair_dz_fused(const DzFusedParams& p, hipStream_t st) {
+template <int KS, bool PIPE>
+static int launch_pair_dz_fused_v(const DzFusedParams& p, hipStream_t st) {
   const int ncol = p.a.num_heads * p.D;
-  const size_t sh = 3 * (size_t)slab_stride_bytes(KS * 16, 2) + (size_t)ncol * 16 + (size_t)PH_WAVES * 32 * 16 * 3;
+  const size_t sh = (KS > 24 ? 2 : 3) * (size_t)slab_stride_bytes(KS * 16, 2) + (size_t)ncol * 16 + (size_t)PH_WAVES * 32 * 16 * 3;
   if (sh > 160 * 1024) { set_error("peneo_pair_dz_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (sh > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dz_fused_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_dz_fused_kernel<KS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
     set_error("peneo_pair_dz_fused: cannot raise dynamic LDS to %zu bytes", sh);
     return PENEO_ERR_LAUNCH;
   }
   const int64_t blocks = (p.npairs + PH_PAIRS - 1) / PH_PAIRS;
-  hipLaunchKernelGGL(pair_dz_fused_kernel<KS>, dim3((unsigned)blocks), dim3(PH_WAVES * 64), sh, st, p);
+  hipLaunchKernelGGL((pair_dz_fused_kernel<KS, PIPE>), dim3((unsigned)blocks), dim3(PH_WAVES * 64), sh, st, p);
   return check_launch("peneo_pair_dz_fused");
+}
+template <int KS>
+static int launch_pair_dz_fused(const DzFusedParams& p, hipStream_t st) {
+  static const bool pipe = [] { const char* e = getenv("PENEO_DZF_PIPE"); return e ? atoi(e) != 0 : true; }();
+  return pipe ? launch_pair_dz_fused_v<KS, true>(p, st) : launch_pair_dz_fused_v<KS, false>(p, st);
 }
 
 // label maps from sparse spots (b, i, j, tag): the dense [B, P] int64 maps the collator builds on the host

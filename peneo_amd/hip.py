@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpeneo_hip.so")
+LIB_PATH = os.environ.get("PENEO_HIP_LIB") or os.path.join(_HERE, "lib", "libpeneo_hip.so")   # override: tools/ experiments
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2

@@ -642,7 +642,7 @@ def test_pair_backward_blocks(ops, dtype):
 
 
 @pytest.mark.parametrize("N,D,rows", [(45, 128, (7, 30)), (45, 128, (0, 45)), (70, 384, (0, 70)), (33, 64, (30, 33)),
-                                      (40, 96, (5, 6))])
+                                      (40, 96, (5, 6)), (37, 512, (0, 37)), (20, 32, (0, 20))])
 def test_pair_dz_fused_matches_the_gemm_epilogue(ops, N, D, rows):
     """peneo_pair_dz_fused (x and z never in memory) against pair_x_fwd + the z GEMM with the pair-dz epilogue."""
     dtype, classes = torch.bfloat16, [2, 3, 3, 3, 3]
