@@ -309,12 +309,16 @@ int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_
 
 /* dz of the pairs of rows i0..i1 of one document WITHOUT x or z in memory (bf16 only): x = SiLU(a_i + b_j) is rebuilt in
  * registers, z = x W1cat^T + b1 comes off the matrix cores with lane = hidden column, and the same kernel turns it into
- * dz [npairs, nh*D] and adds the dW2 / db1 column sums to `workspace` (layout of peneo_pair_dz).  `w_packed` is the
+ * dz [npairs, nh*D] and adds the dW2 / db1 column sums to `workspace` (layout of peneo_pair_dz; only its first 256 rows
+ * are touched, as by the pair_dz epilogue of peneo_gemm: 256 rows suffice for a workspace these two share).  `w_packed` is the
  * fragment-packed weight buffer of peneo_pair_heads_pack (its second-layer fragments are not used here).
- * Replaces peneo_pair_x_fwd (for z) + the first-layer GEMM + peneo_pair_dz of the chunked backward
+ * With x_out / pre_out it also leaves x = SiLU(a_i + b_j) and a_i + b_j for the dW1 / dx GEMMs (no peneo_pair_x_fwd pass).
+ * Replaces peneo_pair_x_fwd + the first-layer GEMM + peneo_pair_dz of the chunked backward
  * (the autograd graph through model/peneo_decoder.py:269-336). */
 int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* w_packed, const float* b1,
-                        const peneo_pair_dz_args* args, void* dz, float* workspace, peneo_stream_t stream);
+                        const peneo_pair_dz_args* args, void* dz, float* workspace,
+                        void* x_out /* optional [npairs, D]: what peneo_pair_x_fwd would write */,
+                        void* pre_out /* given together with x_out */, peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K13 — loss finish: reduces the per-workgroup partial rows of peneo_pair_heads_fwd:

@@ -982,6 +982,7 @@ struct DzFusedParams {
   const void* wp; const float* b1;
   peneo_pair_dz_args a;
   bf16_t* out; float* ws;
+  bf16_t* x_out; bf16_t* pre_out;   // optional [npairs, D]: SiLU(a_i + b_j) and a_i + b_j for the dW1 / dx GEMMs
 };
 constexpr int DZF_SLOTS = 256;
 
@@ -1016,6 +1017,10 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
 
   const T* arow = p.abd + (int64_t)pi * 2 * D;
   const T* brow = p.abd + (int64_t)pj * 2 * D + D;
+  // the fragments are also what the dW1 / dx GEMMs need as x and a_i + b_j: each lane owns 16 contiguous bytes per k-step
+  const bool want_x = p.x_out != nullptr && pair_ok;
+  bf16_t* x_row = p.x_out + lp * D + 8 * half;
+  bf16_t* pre_row = p.pre_out + lp * D + 8 * half;
   Frag<T> xf[KS];
   if constexpr (KS % 4 == 0) {
     uint4 ra[2][4], rb[2][4];
@@ -1039,9 +1044,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
         unpack16<T>(ra[g & 1][i], a);
         unpack16<T>(rb[g & 1][i], bb);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+        for (int e = 0; e < 8; ++e) a[e] += bb[e];
+        if (want_x) *reinterpret_cast<uint4*>(pre_row + 16 * (4 * g + i)) = pack_frag8<T>(a).v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e]);
         xf[4 * g + i] = pack_frag8<T>(a);
         asm volatile("" : "+v"(xf[4 * g + i].v.x), "+v"(xf[4 * g + i].v.y), "+v"(xf[4 * g + i].v.z), "+v"(xf[4 * g + i].v.w) :: "memory");
+        if (want_x) *reinterpret_cast<uint4*>(x_row + 16 * (4 * g + i)) = xf[4 * g + i].v;
       }
     }
   } else {
@@ -1052,11 +1061,15 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
       unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
       unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+      for (int e = 0; e < 8; ++e) a[e] += bb[e];
+      if (want_x) *reinterpret_cast<uint4*>(pre_row + 16 * ks) = pack_frag8<T>(a).v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e]);
       xf[ks] = pack_frag8<T>(a);
+      if (want_x) *reinterpret_cast<uint4*>(x_row + 16 * ks) = xf[ks].v;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (no vmcnt(0) here: the x / pre stores may still be in flight; the counted DMA waits below are safe next to stores)
   __syncthreads();                                          // sCol visible
 
   const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
@@ -1366,7 +1379,10 @@ extern "C" int peneo_pair_x_bwd(int dtype, const void* ab_doc, int N, int D, int
 
 extern "C" int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int i1, const void* w_packed,
                                    const float* b1, const peneo_pair_dz_args* args, void* dz, float* workspace,
-                                   peneo_stream_t stream) {
+                                   void* x_out, void* pre_out, peneo_stream_t stream) {
+  PENEO_REQUIRE((x_out == nullptr) == (pre_out == nullptr), "peneo_pair_dz_fused: x_out and pre_out come together");
+  PENEO_REQUIRE(((reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(pre_out)) & 15) == 0,
+                "peneo_pair_dz_fused: x_out / pre_out must be 16-byte aligned");
   PENEO_REQUIRE(dtype == PENEO_BF16, "peneo_pair_dz_fused: bf16 only (the fp32 path runs peneo_gemm with a pair_dz epilogue)");
   PENEO_REQUIRE(ab_doc && w_packed && b1 && args && dz && workspace, "peneo_pair_dz_fused: null argument");
   PENEO_REQUIRE(N > 0 && i0 >= 0 && i1 > i0 && i1 <= N, "peneo_pair_dz_fused: bad row range [%d, %d) of %d", i0, i1, N);
@@ -1380,6 +1396,7 @@ extern "C" int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, 
   p.abd = reinterpret_cast<const bf16_t*>(ab_doc); p.N = N; p.D = D;
   p.pbase = pair_row_start(i0, N); p.npairs = pair_row_start(i1, N) - p.pbase;
   p.wp = w_packed; p.b1 = b1; p.a = *args; p.out = reinterpret_cast<bf16_t*>(dz); p.ws = workspace;
+  p.x_out = reinterpret_cast<bf16_t*>(x_out); p.pre_out = reinterpret_cast<bf16_t*>(pre_out);
   hipStream_t st = (hipStream_t)stream;
   switch (D / 16) {
     case 2: return launch_pair_dz_fused<2>(p, st);

@@ -103,7 +103,7 @@ SIGNATURES = {
     "peneo_pair_x_bwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "peneo_pair_dz_workspace_bytes": (_sz, [_i, _i]),
     "peneo_pair_dz": (_i, [_i, _vp, _i64, C.POINTER(PairDzArgs), _vp, _vp]),
-    "peneo_pair_dz_fused": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(PairDzArgs), _vp, _vp, _vp]),
+    "peneo_pair_dz_fused": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(PairDzArgs), _vp, _vp, _vp, _vp, _vp]),
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
     "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),

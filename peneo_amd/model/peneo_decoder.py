@@ -237,7 +237,7 @@ class _DecoderStage(torch.autograd.Function):
         W1cat = wc.cat_rows("dec.w1cat", w1s, dt)                      # [nh*D, D]
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         dW1cat = torch.zeros((nh * D, D), dtype=torch.float32, device=dev)
-        dz_ws = ops.pair_dz_workspace(nh, D, dev)
+        dz_ws = ops.pair_dz_workspace(nh, D, dev, slots=256)   # rows both dz producers used here spread their atomics over
         d_ab = torch.zeros((B, N, 2 * D), dtype=torch.float32, device=dev)
         P = N * (N + 1) // 2
         chunks = _row_chunks(N, dec.bwd_chunk_pairs)
@@ -258,9 +258,10 @@ class _DecoderStage(torch.autograd.Function):
         # measured (docs/s, B = 8): x on main + dW1 on main 368.8, x on side + dW1 on main 368.4, x on main 366.6, both on side 362.5
         x_on_side = os.environ.get("PENEO_DZ_X_SIDE", "0") != "0"
         dw_on_main = os.environ.get("PENEO_DZ_DW_MAIN", "1") != "0"
+        x_from_dz = fused_dz and os.environ.get("PENEO_DZ_WRITES_X", "0") != "0"   # no separate pair_x_fwd pass at all
         x_ready = [torch.cuda.Event() for _ in range(2)]
         main = torch.cuda.current_stream()
-        side = dec.side_stream(dev)
+        side = main if os.environ.get("PENEO_DEC_STREAMS", "2") == "1" else dec.side_stream(dev)   # "1": strictly serial
         third = dec.side_stream(dev, 1) if dec.three_streams else None   # the weight-gradient GEMM on its own stream
         ready = [torch.cuda.Event() for _ in range(2)]
         done = [torch.cuda.Event() for _ in range(2)]
@@ -284,11 +285,14 @@ class _DecoderStage(torch.autograd.Function):
                 if fused_dz:
                     # dz straight from ab: x lives in registers, z in the MFMA accumulators; x / pre are only needed by
                     # the dW1 / dx GEMMs.  Which stream produces x and which runs the dW1 GEMM only balances the two queues.
-                    if not x_on_side:
+                    if not x_on_side and not x_from_dz:
                         ops.pair_x_fwd(ab[b], i0, i1, x, pre)
-                    ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws)
+                    if x_from_dz:
+                        ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws, x, pre)   # x / pre from its fragments
+                    else:
+                        ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws)
                     if dw_on_main:
-                        if x_on_side:
+                        if x_on_side and not x_from_dz:
                             with torch.cuda.stream(side):
                                 ops.pair_x_fwd(ab[b], i0, i1, x, pre)
                                 x_ready[k].record(side)
@@ -305,7 +309,7 @@ class _DecoderStage(torch.autograd.Function):
                         ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
                         done_w[k].record(third)
                 with torch.cuda.stream(side):
-                    if fused_dz and x_on_side and not dw_on_main:
+                    if fused_dz and x_on_side and not dw_on_main and not x_from_dz:
                         ops.pair_x_fwd(ab[b], i0, i1, x, pre)   # x[k] / pre[k] were released by this stream's own chunk idx-2
                     side.wait_event(ready[k])
                     if idx > 0:

@@ -497,10 +497,11 @@ def pair_x_bwd(ab_doc: torch.Tensor, i0: int, i1: int, dx: torch.Tensor, d_ab_do
                                  int(premultiplied), stream()), "peneo_pair_x_bwd")
 
 
-def pair_dz_workspace(nh: int, D: int, device) -> torch.Tensor:
-    """Zeroed [slots, 4 * nh * D] fp32 accumulator for pair_dz (sum its rows with colsum at the end)."""
-    return torch.zeros((lib().peneo_pair_dz_workspace_bytes(nh, D) // (16 * nh * D), 4 * nh * D), dtype=torch.float32,
-                       device=device)
+def pair_dz_workspace(nh: int, D: int, device, slots: Optional[int] = None) -> torch.Tensor:
+    """Zeroed [slots, 4 * nh * D] fp32 accumulator for pair_dz (sum its rows with colsum at the end).  The stand-alone
+    peneo_pair_dz needs the full size (default); the GEMM epilogue and peneo_pair_dz_fused only touch the first 256 rows."""
+    full = lib().peneo_pair_dz_workspace_bytes(nh, D) // (16 * nh * D)
+    return torch.zeros((full if slots is None else min(slots, full), 4 * nh * D), dtype=torch.float32, device=device)
 
 
 def pair_dz_args(D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor], w2: Sequence[torch.Tensor],
@@ -521,12 +522,15 @@ def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogit
 
 
 def pair_dz_fused(ab_doc: torch.Tensor, i0: int, i1: int, wp: torch.Tensor, b1: torch.Tensor, args: "hip.PairDzArgs",
-                  dz: torch.Tensor, workspace: torch.Tensor) -> None:
-    """dz [npairs, nh*D] of rows i0..i1 of one document straight from ab (bf16): no x / z round trip through memory."""
+                  dz: torch.Tensor, workspace: torch.Tensor, x: Optional[torch.Tensor] = None,
+                  pre: Optional[torch.Tensor] = None) -> None:
+    """dz [npairs, nh*D] of rows i0..i1 of one document straight from ab (bf16): no x / z round trip through memory.
+    `x` / `pre` ([npairs, D], together) optionally receive what pair_x_fwd would write."""
     N, D2 = ab_doc.shape
     with kernel_timer("pair_dz_fused"):
         check(lib().peneo_pair_dz_fused(dtype_code(ab_doc.dtype), ptr(_c(ab_doc)), N, D2 // 2, i0, i1, ptr(wp), ptr(b1),
-                                        C.byref(args), ptr(dz), ptr(workspace), stream()), "peneo_pair_dz_fused")
+                                        C.byref(args), ptr(dz), ptr(workspace), ptr(x), ptr(pre), stream()),
+              "peneo_pair_dz_fused")
 
 
 def pair_dz_finish(workspace: torch.Tensor, nh: int, D: int, classes: Sequence[int]):

@@ -670,6 +670,15 @@ def test_pair_dz_fused_matches_the_gemm_epilogue(ops, N, D, rows):
     ops.pair_dz_fused(ab, i0, i1, wp, b1cat, args, zb, ws_b)
     torch.cuda.synchronize()
     assert bool((zb[npairs:] == 7.0).all())
+    # the same call can leave x and a_i + b_j (what pair_x_fwd writes) for the dW1 / dx GEMMs
+    pre = torch.empty_like(x)
+    ops.pair_x_fwd(ab, i0, i1, x, pre)
+    zc = torch.empty_like(za)
+    xc = torch.full((npairs + 2, D), 3.0, device=DEV, dtype=dtype)
+    pc = torch.full((npairs + 2, D), 3.0, device=DEV, dtype=dtype)
+    ops.pair_dz_fused(ab, i0, i1, wp, b1cat, args, zc, ops.pair_dz_workspace(nh, D, DEV), xc, pc)
+    assert torch.equal(zc, zb[:npairs]) and torch.equal(xc[:npairs], x) and torch.equal(pc[:npairs], pre)
+    assert bool((xc[npairs:] == 3.0).all()) and bool((pc[npairs:] == 3.0).all())
     assert rel_err(zb[:npairs], za) < 2e-2
     dw2a, db1a = ops.pair_dz_finish(ws_a, nh, D, classes)
     dw2b, db1b = ops.pair_dz_finish(ws_b, nh, D, classes)

@@ -26,3 +26,24 @@ for name, fn in (("train step", step), ("eval forward", lambda: m(**b))):
     torch.cuda.synchronize()
     t_total = (time.perf_counter() - t0) / 5
     print(f"{name}: host issue {t_issue * 1e3:.2f} ms, wall {t_total * 1e3:.2f} ms per step")
+
+# how far ahead of the GPU is the host at the phase boundaries of a train step?  (lead ~ 0 => the GPU waits for launches)
+m.train(); torch.set_grad_enabled(True)
+for _ in range(2): step()
+torch.cuda.synchronize()
+marks = []
+def mark(tag):
+    e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((tag, time.perf_counter(), e))
+mark("start")
+for i in range(4):
+    for p in m.parameters(): p.grad = None
+    mark(f"s{i} fwd issue begins")
+    out = m(**b)
+    mark(f"s{i} fwd issued")
+    out["loss"].backward()
+    mark(f"s{i} bwd issued")
+torch.cuda.synchronize()
+t0h, e0 = marks[0][1], marks[0][2]
+for tag, th, e in marks[1:]:
+    tg = e0.elapsed_time(e)
+    print(f"{tag:22s} host {1e3 * (th - t0h):8.2f} ms   gpu {tg:8.2f} ms   gpu-behind-host {tg - 1e3 * (th - t0h):7.2f} ms")
