@@ -2,6 +2,7 @@
 // vectors (coalesced 1 KiB per wave-instruction), wavefront shuffles for the mean/variance and for
 // the two backward row-reductions.  fp32 statistics regardless of the storage dtype.
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 
 namespace peneo {
@@ -247,22 +248,29 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
       gm[k][e] = gamma[(hl + 32 * k) * VEC + e];
       ag[k][e] = 0.f; ab[k][e] = 0.f;
     }
-  for (int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); r < rows; r += (int64_t)gridDim.x * 8) {
-    const T* dyr = dy + ln_row_off(r, dym, H);
-    const T* xr = x + ln_row_off(r, xm, H);
+  // the rows of a half-wave are software-pipelined: the loads of its next row are in flight while this one is reduced
+  const int64_t rstep = (int64_t)gridDim.x * 8;
+  int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  uint4 nd[NV], nx[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int64_t rr) {
+    const T* dyr = dy + ln_row_off(rr, dym, H);
+    const T* xr = x + ln_row_off(rr, xm, H);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      nd[k] = *reinterpret_cast<const uint4*>(dyr + (hl + 32 * k) * VEC);
+      nx[k] = *reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC);
+    }
+    nmu = mean[rr]; nrs = rstd[rr];
+  };
+  if (r < rows) fetch(r);
+  for (; r < rows; r += rstep) {
     T* dxr = dx + ln_row_off(r, dxm, H);
     uint4 rd[NV], rx[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      if constexpr (sizeof(T) == 2) {
-        rd[k] = *reinterpret_cast<const uint4*>(dyr + (hl + 32 * k) * VEC);
-        rx[k] = *reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC);
-      } else {
-        rd[k] = *reinterpret_cast<const uint4*>(dyr + (hl + 32 * k) * VEC);
-        rx[k] = *reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC);
-      }
-    }
-    const float mu = mean[r], rs = rstd[r];
+    for (int k = 0; k < NV; ++k) { rd[k] = nd[k]; rx[k] = nx[k]; }
+    const float mu = nmu, rs = nrs;
+    if (r + rstep < rows) fetch(r + rstep);
     float g[NV][VEC], xh[NV][VEC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -337,8 +345,9 @@ template <typename T, int NV>
 static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const void* x, LnMap xm, void* dx, LnMap dxm,
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                             int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2) {
+  static const int64_t cap = [] { const char* e = getenv("PENEO_LN_BWD_BLOCKS"); return (int64_t)(e ? atoi(e) : 256); }();   // 256: fewer same-address atomics on dgamma / dbeta (measured 64..1024)
   int64_t blocks = (rows + 7) / 8;
-  if (blocks > 512) blocks = 512;
+  if (blocks > cap) blocks = cap;
   dim3 grid((unsigned)blocks);
   if (drop_p > 0.f)
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
