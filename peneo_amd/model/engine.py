@@ -101,3 +101,17 @@ class DropoutSeeds:
 
 def zeros_like_param(p: torch.Tensor) -> torch.Tensor:
     return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+
+
+def zeros_like_params(params) -> dict:
+    """{id(p): zeroed fp32 gradient buffer}: views of ONE zero-filled allocation (one fill launch instead of one per
+    parameter); every view starts on a 16-byte boundary."""
+    params = [p for p in params if p is not None]
+    if not params:
+        return {}
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+    return {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import ops
 from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
 from .configuration_peneo import LayoutLMv3Config
-from .engine import DropoutSeeds, WeightCache, zeros_like_param
+from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
 from .relpos import bucket_lut, visual_xy
 
 
@@ -117,13 +117,13 @@ class _FwdState:
         self.dims = None       # (B, S, T)
         self.children = None   # per-stream slices of this state when the encoder runs document groups on several streams
 
-    def child(self, k: int, n: int) -> "_FwdState":
-        """State of document group k of n (documents are independent): slices of the shared tensors, own gradient buffers,
-        own dropout streams."""
+    def child(self, k: int, lo: int, hi: int) -> "_FwdState":
+        """State of document group k = documents lo..hi-1 (documents are independent): slices of the shared tensors, own
+        gradient buffers, own dropout streams."""
         import copy
         B, S, T = self.dims
-        Bh = B // n
-        sl = slice(k * Bh, (k + 1) * Bh)
+        Bh = hi - lo
+        sl = slice(lo, hi)
         c = _FwdState()
         c.dtype, c.dims = self.dtype, (Bh, S, T)
         c.bias = self.bias[sl] if self.bias is not None else None
@@ -235,7 +235,7 @@ class _EmbedStage(torch.autograd.Function):
         H = cfg.hidden_size
         seeds = st.seeds
         d_emb = d_emb.contiguous().view(B, T, H)
-        g = {id(p): zeros_like_param(p) for p in ctx.params}
+        g = zeros_like_params(ctx.params)
         if sv["has_img"]:
             d_cat = ops.layernorm_bwd(d_emb, sv["cat"], LN_g, sv["m2"], sv["r2"], g[id(LN_g)], g[id(LN_b)],
                                       drop_p=seeds.p_hidden, drop_seed=seeds.seed(2))
@@ -447,6 +447,7 @@ class LayoutLMv3Model(nn.Module):
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
         self.enc_split = int(os.environ.get("PENEO_ENC_SPLIT", "1"))   # document groups (HIP streams) through the encoder
+        self.enc_groups = [int(v) for v in os.environ.get("PENEO_ENC_GROUPS", "").split(",") if v.strip()]   # uneven groups
         self.rel_group = int(os.environ.get("PENEO_REL_GROUP", "1000"))   # layers per bias-table reduction; groups of 4 run beside the
         # remaining layers but measured slower (285 vs 302 docs/s): the histogram kernel crowds the GEMMs off the CUs
         self._luts = {}
@@ -544,7 +545,14 @@ class LayoutLMv3Model(nn.Module):
         x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(), attention_mask.contiguous(), image,
                               *self.embed_params())
         _, _, T = st.dims
-        n = self.enc_split if (self.enc_split > 1 and B % self.enc_split == 0) else 1
+        # document groups: PENEO_ENC_GROUPS = "7,1" (sizes, must add up to the batch) or PENEO_ENC_SPLIT = n equal groups
+        sizes = [B]
+        if self.enc_groups and sum(self.enc_groups) == B and len(self.enc_groups) > 1:
+            sizes = list(self.enc_groups)
+        elif self.enc_split > 1 and B % self.enc_split == 0:
+            sizes = [B // self.enc_split] * self.enc_split
+        n = len(sizes)
+        bounds = [sum(sizes[:k]) for k in range(n + 1)]
         if n == 1:
             for i, layer in enumerate(self.encoder.layer):
                 x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
@@ -562,15 +570,14 @@ class LayoutLMv3Model(nn.Module):
             self.weight_cache.cast(f"L{i}.i", layer.intermediate.dense.weight, dt)
             self.weight_cache.cast(f"L{i}.o2", layer.output.dense.weight, dt)
         main = torch.cuda.current_stream()
-        st.children = [st.child(k, n) for k in range(n)]
-        Bh = B // n
+        st.children = [st.child(k, bounds[k], bounds[k + 1]) for k in range(n)]
         x3 = x.view(B, T, H)
         streams = [self.side_stream(dev, f"enc{k}") for k in range(n)]
         parts = []
         for k in range(n):
             streams[k].wait_stream(main)
             with torch.cuda.stream(streams[k]):
-                parts.append(x3[k * Bh:(k + 1) * Bh].reshape(Bh * T, H))
+                parts.append(x3[bounds[k]:bounds[k + 1]].reshape(sizes[k] * T, H))
         for i, layer in enumerate(self.encoder.layer):
             params = layer_params(layer)
             for k in range(n):
@@ -578,5 +585,5 @@ class LayoutLMv3Model(nn.Module):
                     parts[k] = _LayerStage.apply(self, st.children[k], i, parts[k], *params)
         for k in range(n):
             main.wait_stream(streams[k])
-        x = torch.cat([p.view(Bh, T, H) for p in parts], dim=0)
+        x = torch.cat([p.view(sizes[k], T, H) for k, p in enumerate(parts)], dim=0)
         return (x,)

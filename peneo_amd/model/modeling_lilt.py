@@ -24,7 +24,7 @@ import torch.nn as nn
 from .. import ops
 from ..hip import ACT_GELU, PeneoHipError
 from .configuration_peneo import LiltConfig
-from .engine import DropoutSeeds, WeightCache, zeros_like_param
+from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
 
 
 class _SelfParams(nn.Module):
@@ -196,7 +196,7 @@ class _LiltEmbedStage(torch.autograd.Function):
         B, S = input_ids.shape
         H, Hl = cfg.hidden_size, cfg.hidden_size // cfg.channel_shrink_ratio
         seeds = st.seeds
-        g = {id(p): zeros_like_param(p) for p in ctx.params}
+        g = zeros_like_params(ctx.params)
         d_x0 = ops.layernorm_bwd(d_x.contiguous(), x0, ln_g, m1, r1, g[id(ln_g)], g[id(ln_b)], drop_p=seeds.p_hidden,
                                  drop_seed=seeds.seed(1))
         ops.embed_bwd(d_x0, B, S, H, input_ids=input_ids, pos_ids=pid, g_word=g[id(word)], g_pos=g[id(pos_w)],

@@ -3,7 +3,7 @@ import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from peneo_amd import ops
-B, nh, T, d = 8, 12, 709, 64
+B, nh, T, d = int(os.environ.get("B", "8")), 12, 709, 64
 H = nh * d
 dt = torch.bfloat16
 drop = float(os.environ.get("DROP", "0.1"))
