@@ -115,6 +115,7 @@ class _FwdState:
         self.seeds: Optional[DropoutSeeds] = None
         self.dtype = torch.float32
         self.dims = None       # (B, S, T)
+        self.grad_pools = None  # [layers, pool] fp32 accumulators of the layer stages' backward (one zero fill per step)
         self.children = None   # per-stream slices of this state when the encoder runs document groups on several streams
 
     def child(self, k: int, lo: int, hi: int) -> "_FwdState":
@@ -351,7 +352,11 @@ class _LayerStage(torch.autograd.Function):
         # all small fp32 accumulators of the stage (LayerNorm and bias gradients) carved from ONE zero-filled buffer:
         # one fill launch instead of eight fills / memsets per layer
         I = cfg.intermediate_size
-        pool = torch.zeros(4 * H + (H + I + H + 3 * H), dtype=torch.float32, device=dev)
+        psz = 4 * H + (H + I + H + 3 * H)
+        nl = len(model.encoder.layer)
+        if getattr(st, "grad_pools", None) is None or idx == nl - 1:   # the last layer runs backward first: it zero-fills all pools
+            st.grad_pools = torch.zeros((nl, psz), dtype=torch.float32, device=dev)
+        pool = st.grad_pools[idx]
         dg2, db2, dg1, db1 = pool[:H], pool[H:2 * H], pool[2 * H:3 * H], pool[3 * H:4 * H]
         o_ = 4 * H
         dbo2, dbi, dbo, dbqkv = pool[o_:o_ + H], pool[o_ + H:o_ + H + I], pool[o_ + H + I:o_ + 2 * H + I], pool[o_ + 2 * H + I:]
