@@ -87,6 +87,20 @@ int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, int K,
                void* C, int64_t ldc, int c_dtype, const peneo_gemm_epilogue* ep,
                int split_k, void* workspace, size_t workspace_bytes, peneo_stream_t stream);
 
+/* Up to 4 independent bf16 GEMMs C_i = op(A_i) op(B_i) of ONE operand layout in ONE launch (tiles of all problems side by
+ * side, full K per tile, no split-k, no epilogue besides fp32 accumulate).  Operands must satisfy the LDS-DMA conditions
+ * of peneo_gemm's bf16 path (16-byte aligned bases and row strides).  Used for the four weight gradients
+ * dW = dy^T x of an encoder layer (autograd of the nn.Linear calls at modeling_layoutlmv3.py:292-294,335-360). */
+typedef struct peneo_gemm_problem {
+  int M, N, K;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  int accumulate;           /* C += A B (c_dtype must be PENEO_F32) */
+} peneo_gemm_problem;
+int peneo_gemm_group(int dtype, int a_kmajor, int b_kmajor, int c_dtype, const peneo_gemm_problem* problems, int n,
+                     peneo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Element-wise plumbing
  * ------------------------------------------------------------------------------------------ */

@@ -753,19 +753,14 @@ __device__ __forceinline__ void pmma(const PFrag& a, const PFrag& b, f32x16_t& a
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
 }
 
+// the tile (m0, n0, split slice) is chosen by the __global__ wrappers below: one problem per launch, or several
+// independent problems side by side in one launch (peneo_gemm_group)
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* smem, const int m0, const int n0, const int zsplit) {
   constexpr int STAGE = 2 * TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
-  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
-  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
-  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
-  const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
-  const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
   DzPre dzpre = {};
   if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
 
@@ -924,6 +919,41 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
 #undef PENEO_MMA_STEP
 #undef PENEO_READ_STEP
   tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
+  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
+  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
+  const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
+  gemm_dma_pipe_body<AK, BK>(p, smem, (tile / gx) * GB, (tile % gx) * GB, zsplit);
+}
+
+// Several independent GEMMs of one operand layout in ONE launch (no split-k): the tiles of all problems are numbered
+// consecutively, the XCD-aware order runs over the whole launch.  Used for the four weight gradients of an encoder layer:
+// 432 tiles with the full K = tokens each, instead of four split-k launches of ~450 short workgroups plus four reductions.
+constexpr int GEMM_GROUP_MAX = 4;
+struct GemmGroup {
+  GemmParams p[GEMM_GROUP_MAX];
+  int first_tile[GEMM_GROUP_MAX + 1];
+  int gx[GEMM_GROUP_MAX];
+  int n;
+};
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm_dma_pipe_group_kernel(GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int total = gridDim.x, lin = blockIdx.x;
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
+  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GEMM_GROUP_MAX; ++k)
+    if (k < g.n && tile3 >= g.first_tile[k]) i = k;
+  const int tile = tile3 - g.first_tile[i], gx = g.gx[i];
+  gemm_dma_pipe_body<AK, BK>(g.p[i], smem, (tile / gx) * GB, (tile % gx) * GB, 0);
 }
 
 // ================================================================================================
@@ -1159,6 +1189,59 @@ using namespace peneo;
 extern "C" size_t peneo_gemm_workspace_bytes(int M, int N, int K, int split_k) {
   (void)K;
   return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int peneo_gemm_group(int dtype, int a_kmajor, int b_kmajor, int c_dtype, const peneo_gemm_problem* problems, int n,
+                                peneo_stream_t stream) {
+  PENEO_REQUIRE(dtype == PENEO_BF16, "peneo_gemm_group: bf16 operands only");
+  PENEO_REQUIRE(c_dtype == PENEO_F32 || c_dtype == PENEO_BF16, "peneo_gemm_group: bad c_dtype %d", c_dtype);
+  PENEO_REQUIRE(problems && n >= 1 && n <= GEMM_GROUP_MAX, "peneo_gemm_group: 1..%d problems (got %d)", GEMM_GROUP_MAX, n);
+  auto dma_ok = [](const void* ptr, int64_t ld, bool kmajor, int rows, int k) {
+    return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (ld % 8) == 0 && ((kmajor ? k : rows) % 8) == 0 && rows >= 8;
+  };
+  GemmGroup g;
+  g.n = n;
+  int tiles = 0;
+  for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
+    const peneo_gemm_problem& q = problems[i < n ? i : n - 1];
+    if (i < n) {
+      PENEO_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.A && q.B && q.C, "peneo_gemm_group: problem %d is empty or has a null operand", i);
+      PENEO_REQUIRE(q.lda >= (a_kmajor ? q.K : q.M) && q.ldb >= (b_kmajor ? q.K : q.N) && q.ldc >= q.N,
+                    "peneo_gemm_group: problem %d: leading dim too small", i);
+      PENEO_REQUIRE(dma_ok(q.A, q.lda, a_kmajor != 0, q.M, q.K) && dma_ok(q.B, q.ldb, b_kmajor != 0, q.N, q.K),
+                    "peneo_gemm_group: problem %d: operands must be 16-byte aligned with extents in whole 16-byte chunks", i);
+      PENEO_REQUIRE(!q.accumulate || c_dtype == PENEO_F32, "peneo_gemm_group: accumulate needs an fp32 C");
+    }
+    GemmParams& p = g.p[i];
+    p.A = q.A; p.B = q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = q.K;
+    p.c_dtype = c_dtype;
+    peneo_gemm_epilogue z = {};
+    p.ep = z; p.ep.alpha = 1.f; p.ep.accumulate = q.accumulate;
+    p.split_k = 1; p.ws = nullptr; p.kt_per_split = (q.K + 63) / 64; p.dz_on = 0; p.dz_ws = nullptr;
+    peneo_pair_dz_args za = {};
+    p.dz = za;
+    g.first_tile[i] = tiles;
+    g.gx[i] = (q.N + GB - 1) / GB;
+    if (i < n) tiles += g.gx[i] * ((q.M + GB - 1) / GB);
+  }
+  g.first_tile[GEMM_GROUP_MAX] = tiles;
+  for (int i = n; i < GEMM_GROUP_MAX; ++i) g.first_tile[i] = tiles;
+  const int shmem = 2 * 2 * TILE_BYTES;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool ak = a_kmajor != 0, bk = b_kmajor != 0;
+#define PENEO_GROUP_LAUNCH(AK_, BK_)                                                                                         \
+  {                                                                                                                          \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_pipe_group_kernel<AK_, BK_>),  \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, shmem);                   \
+    if (attr != hipSuccess) { set_error("peneo_gemm_group: cannot raise dynamic LDS to %d bytes", shmem); return PENEO_ERR_LAUNCH; } \
+    hipLaunchKernelGGL((gemm_dma_pipe_group_kernel<AK_, BK_>), dim3((unsigned)tiles), dim3(256), shmem, st, g);              \
+  }
+  if (ak && bk) PENEO_GROUP_LAUNCH(true, true)
+  else if (ak && !bk) PENEO_GROUP_LAUNCH(true, false)
+  else if (!ak && bk) PENEO_GROUP_LAUNCH(false, true)
+  else PENEO_GROUP_LAUNCH(false, false)
+#undef PENEO_GROUP_LAUNCH
+  return check_launch("peneo_gemm_group");
 }
 
 extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, int K, const void* A, int64_t lda,

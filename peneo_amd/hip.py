@@ -35,6 +35,11 @@ class GemmEpilogue(C.Structure):
     ]
 
 
+class GemmProblem(C.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("K", _i), ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
+                ("accumulate", _i)]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("numel", _i64), ("lr", _f),
                 ("weight_decay", _f)]
@@ -68,6 +73,7 @@ SIGNATURES = {
     "peneo_version": (_i, []),
     "peneo_last_error": (C.c_char_p, []),
     "peneo_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "peneo_gemm_group": (_i, [_i, _i, _i, _i, C.POINTER(GemmProblem), _i, _vp]),
     "peneo_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, C.POINTER(GemmEpilogue), _i, _vp,
                         _sz, _vp]),
     "peneo_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),

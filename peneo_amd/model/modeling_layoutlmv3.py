@@ -348,7 +348,18 @@ class _LayerStage(torch.autograd.Function):
                 side.wait_event(ev)
                 return fn()
 
-        wgrad = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+        # optional (PENEO_WGRAD_GROUP=1): weight gradients dW = dy^T x collected into one grouped launch (full K per tile,
+        # no split-k reductions)
+        group_ok = model.wgrad_group and dt == torch.bfloat16 and H % 8 == 0 and cfg.intermediate_size % 8 == 0
+        jobs = []
+
+        def wgrad(dy, xin):
+            nonlocal group_ok
+            if not group_ok:
+                return ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+            out = torch.empty((dy.shape[1], xin.shape[1]), dtype=torch.float32, device=dev)
+            jobs.append((dy, xin, out))
+            return out
         # all small fp32 accumulators of the stage (LayerNorm and bias gradients) carved from ONE zero-filled buffer:
         # one fill launch instead of eight fills / memsets per layer
         I = cfg.intermediate_size
@@ -378,6 +389,13 @@ class _LayerStage(torch.autograd.Function):
         if d_dense1 is None:
             d_dense1 = d_h1
         _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
+        if jobs:
+            # FFN2, FFN1 and the attention output projection (324 tiles) run beside the attention backward; the QKV weight
+            # gradient needs dqkv and goes out alone afterwards (split-k), or the stage would end waiting for the group
+            first = list(jobs)
+            on_side(lambda: ops.gemm_group(first, a_kmajor=False, b_kmajor=False))
+            jobs.clear()
+            group_ok = False
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
         dqkv = torch.empty_like(qkv)
@@ -451,6 +469,9 @@ class LayoutLMv3Model(nn.Module):
         self.weight_cache = WeightCache()
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
+        # one grouped launch (peneo_gemm_group) for three of a layer's four wgrads: 2x faster alone (97 vs 190 us for all four),
+        # but in the step the long full-K workgroups crowd the critical path: enc. backward 7.9 vs 7.6 ms -> off by default
+        self.wgrad_group = os.environ.get("PENEO_WGRAD_GROUP", "0") != "0"
         self.enc_split = int(os.environ.get("PENEO_ENC_SPLIT", "1"))   # document groups (HIP streams) through the encoder
         self.enc_groups = [int(v) for v in os.environ.get("PENEO_ENC_GROUPS", "").split(",") if v.strip()]   # uneven groups
         self.rel_group = int(os.environ.get("PENEO_REL_GROUP", "1000"))   # layers per bias-table reduction; groups of 4 run beside the

@@ -63,6 +63,25 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------------------------
+def gemm_group(problems: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], *, a_kmajor: bool = True,
+               b_kmajor: bool = True, accumulate: bool = False) -> None:
+    """Up to 4 independent bf16 GEMMs out_i = op(A_i) op(B_i) (one operand layout) in ONE launch, each tile with its full K.
+    problems: (A, B, out) with out preallocated [M, N] (fp32 or bf16, all the same dtype)."""
+    n = len(problems)
+    arr = (hip.GemmProblem * n)()
+    for q, (A, B, out) in zip(arr, problems):
+        M = A.shape[0] if a_kmajor else A.shape[1]
+        K = A.shape[1] if a_kmajor else A.shape[0]
+        N = B.shape[0] if b_kmajor else B.shape[1]
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and out.shape == (M, N)
+        q.M, q.N, q.K = M, N, K
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0)
+        q.accumulate = int(accumulate)
+    with kernel_timer("gemm_group"):
+        check(lib().peneo_gemm_group(dtype_code(torch.bfloat16), int(a_kmajor), int(b_kmajor), dtype_code(problems[0][2].dtype),
+                                     arr, n, stream()), "peneo_gemm_group")
+
+
 def choose_split_k(M: int, N: int, K: int, dtype: torch.dtype) -> int:
     """Split the reduction only when the output grid cannot fill the 256 CUs."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)

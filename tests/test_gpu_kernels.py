@@ -701,6 +701,42 @@ def test_pair_dz_fused_matches_the_gemm_epilogue(ops, N, D, rows):
         assert rel_err(dw2b[h], w2r[h].grad) < 2e-2
 
 
+@pytest.mark.parametrize("layout", ["nn_t", "nt", "tn"])
+def test_gemm_group_matches_single_launches(ops, layout):
+    """peneo_gemm_group: several problems in one launch == the same problems one by one (and fp32 matmul)."""
+    g = torch.Generator().manual_seed(11)
+    dt = torch.bfloat16
+    T = 1000                                               # ragged against the 128 tile and the 64 k-tile
+    shapes = [(384, 256), (128, 128), (520, 136), (72, 264)]   # (rows of out, cols of out)
+    probs, refs = [], []
+    for (m, n) in shapes:
+        if layout == "nn_t":      # wgrad: out[m, n] = dy^T x, both operands stored [tokens, *]
+            A = torch.randn(T, m, generator=g).to(DEV).to(dt); B = torch.randn(T, n, generator=g).to(DEV).to(dt)
+            ref = A.float().t() @ B.float(); kw = dict(a_kmajor=False, b_kmajor=False)
+        elif layout == "nt":      # forward: out = x W^T
+            A = torch.randn(m, T, generator=g).to(DEV).to(dt); B = torch.randn(n, T, generator=g).to(DEV).to(dt)
+            ref = A.float() @ B.float().t(); kw = dict(a_kmajor=True, b_kmajor=True)
+        else:                     # dgrad: out = dy W
+            A = torch.randn(m, T, generator=g).to(DEV).to(dt); B = torch.randn(T, n, generator=g).to(DEV).to(dt)
+            ref = A.float() @ B.float(); kw = dict(a_kmajor=True, b_kmajor=False)
+        probs.append((A, B, torch.full((m, n), 5.0, device=DEV, dtype=torch.float32)))
+        refs.append(ref)
+    for k in (1, 3, 4):
+        for _, _, o in probs: o.fill_(5.0)
+        ops.gemm_group(probs[:k], **kw)
+        for i, ((A, B, o), ref) in enumerate(zip(probs, refs)):
+            if i < k:
+                single = ops.gemm(A, B, out_dtype=torch.float32, **kw)
+                assert rel_err(o, ref) < 2e-3 and rel_err(o, single) < 1e-5
+            else:
+                assert bool((o == 5.0).all())
+    ops.gemm_group(probs, accumulate=True, **kw)            # out += A B
+    for (A, B, o), ref in zip(probs, refs):
+        assert rel_err(o, 2 * ref) < 2e-3
+    with pytest.raises(Exception):
+        ops.gemm_group(probs + probs[:1], **kw)             # more than 4 problems
+
+
 def test_weighted_ce_and_spots(ops):
     from oracle import peneo_oracle as O
     N = 40

@@ -261,7 +261,7 @@ def test_fused_adamw_training_steps_reduce_the_loss():
 
 @pytest.mark.parametrize("env", [{"PENEO_ENC_SPLIT": "2"}, {"PENEO_WGRAD_STREAM": "0"}, {"PENEO_BWD_CHUNK_PAIRS": "300", "PENEO_DEC_STREAMS": "3"},
                                  {"PENEO_DZ_FUSED": "0"}, {"PENEO_DZ_X_SIDE": "1", "PENEO_DZ_DW_MAIN": "0", "PENEO_BWD_CHUNK_PAIRS": "300"},
-                                 {"PENEO_DZF_PIPE": "0", "PENEO_DZ_X_SIDE": "1", "PENEO_DZ_WRITES_X": "0"}, {"PENEO_DZ_WRITES_X": "0"}])
+                                 {"PENEO_DZF_PIPE": "0", "PENEO_DZ_X_SIDE": "1", "PENEO_DZ_WRITES_X": "0"}, {"PENEO_DZ_WRITES_X": "1"}, {"PENEO_WGRAD_GROUP": "1"}, {"PENEO_ENC_GROUPS": "1,1"}])
 def test_optional_execution_modes_keep_the_gradients(env):
     """Stream / chunking options (document-group streams through the encoder, weight gradients on the main stream, small
     decoder-backward chunks on three streams) are read at import time: run the bf16 gradient check of the tiny golden in a
