@@ -395,14 +395,18 @@ def head_transpose(x: torch.Tensor, B: int, nh: int, T: int, d: int) -> torch.Te
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int, T: int, d: int, scale: float,
              bias: Optional[torch.Tensor], key_bias: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
-             vt: Optional[torch.Tensor] = None):
+             vt: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
     """q/k/v: 2-D views [B*T, nh*d] with a common row stride (e.g. slices of a fused QKV buffer).
-    bias: [B, nh, T, Tp] from relpos_bias_fwd (masking folded in); key_bias: fp32 [B, Tp] additive (0 / -1e30)."""
+    bias: [B, nh, T, Tp] from relpos_bias_fwd (masking folded in); key_bias: fp32 [B, Tp] additive (0 / -1e30).
+    out [B*T, nh*d] / lse [B, nh, T] may be given (e.g. row slices of larger buffers)."""
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
     if vt is None and q.dtype != torch.bfloat16:   # bf16 reads V in place (transpose reads); fp32 needs the transposed copy
         vt = head_transpose(v, B, nh, T, d)
-    out = torch.empty((B * T, nh * d), dtype=q.dtype, device=q.device)
-    lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty((B * T, nh * d), dtype=q.dtype, device=q.device)
+    if lse is None:
+        lse = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    assert out.shape == (B * T, nh * d) and out.stride(1) == 1 and lse.is_contiguous() and lse.shape == (B, nh, T)
     check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(vt), B, nh, T, d, scale, ptr(bias),
                                bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(out), out.stride(0), ptr(lse),
                                drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_fwd")
