@@ -205,7 +205,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{'LayoutLMv3' if args.backbone == 'layoutlmv3' else 'LiLT'}-{args.size} PEneo, synthetic RFUND-shaped batch seq{args.seq_len}/"
                                    f"{args.lines} lines, {B} docs/GPU, train mode (dropout 0.1), fwd+loss+bwd"
-                                   f"{' + RCCL grad all-reduce (DDP, bf16 buckets)' if world > 1 else ''}",
+                                   f"{' + RCCL grad all-reduce (one flat bf16 buffer per step)' if world > 1 else ''}",
                        "docs_per_gpu": B, "seq_len": args.seq_len, "lines": args.lines,
                        "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma", "kernel": f"pair_heads_fwd_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},{pcfg['backbone_config']['hidden_size'] // 32}>",

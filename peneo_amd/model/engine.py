@@ -115,3 +115,26 @@ def zeros_like_params(params) -> dict:
         total += (p.numel() + 3) // 4 * 4
     flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
     return {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+
+
+# ---- side streams ------------------------------------------------------------------------------------------------
+# All extra HIP streams of the step come from ONE small pool per device.  More than four streams with work in flight
+# (ours + RCCL's) make the step collapse on this stack (measured: a fifth stream costs 35-45 % of the throughput even
+# with GPU_MAX_HW_QUEUES=8), so the roles can share streams (PENEO_SIDE_STREAMS = 1..3): the decoder's second stage never
+# overlaps in time with the encoder's weight gradients or the bias-table reduction.
+_SIDE_STREAMS: dict = {}
+_ROLE_SLOT = {"wgrad": 0, "rel": 1, "dec": 2}
+
+
+def side_stream(device, role: str) -> "torch.cuda.Stream":
+    import os
+    limit = int(os.environ.get("PENEO_SIDE_STREAMS", "2"))
+    slot = _ROLE_SLOT.get(role)
+    if slot is None:                                   # optional experiments (third decoder stream, encoder groups ...)
+        key = (str(device), role)
+    else:
+        key = (str(device), min(slot, max(limit, 1) - 1))
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+

@@ -23,6 +23,7 @@ from .. import ops
 from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
 from .configuration_peneo import LayoutLMv3Config
 from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
+from .engine import side_stream as engine_side_stream
 from .relpos import bucket_lut, visual_xy
 
 
@@ -486,10 +487,7 @@ class LayoutLMv3Model(nn.Module):
         return self._luts[key]
 
     def side_stream(self, device, which: str = "wgrad") -> "torch.cuda.Stream":
-        key = ("side", which, str(device))
-        if key not in self._luts:
-            self._luts[key] = torch.cuda.Stream(device=device)
-        return self._luts[key]
+        return engine_side_stream(device, which)
 
     def reduce_rel_group(self, st, lo: int, hi: int, B: int, T: int) -> None:
         """Bias-table gradients of layers lo..hi-1 from their bf16 dS^T slabs (runs on the caller's current stream)."""

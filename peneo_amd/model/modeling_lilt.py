@@ -25,6 +25,7 @@ from .. import ops
 from ..hip import ACT_GELU, PeneoHipError
 from .configuration_peneo import LiltConfig
 from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
+from .engine import side_stream as engine_side_stream
 
 
 class _SelfParams(nn.Module):
@@ -348,10 +349,7 @@ class LiltModel(nn.Module):
         self._consts = {}
 
     def side_stream(self, device) -> "torch.cuda.Stream":
-        key = ("side", str(device))
-        if key not in self._consts:
-            self._consts[key] = torch.cuda.Stream(device=device)
-        return self._consts[key]
+        return engine_side_stream(device, "wgrad")
 
 
     def zeros(self, key, shape, dev):

@@ -364,11 +364,8 @@ class PEneoDecoder(nn.Module):
 
     def side_stream(self, device, which: int = 0) -> "torch.cuda.Stream":
         """Extra HIP streams of the chunked backward (created once per device)."""
-        key = (str(device), which)
-        streams = self.__dict__.setdefault("_side_streams", {})
-        if key not in streams:
-            streams[key] = torch.cuda.Stream(device=device)
-        return streams[key]
+        from .engine import side_stream
+        return side_stream(device, "dec" if which == 0 else f"dec{which}")
 
     def __init__(self, config, input_size: int) -> None:
         super().__init__()

@@ -14,7 +14,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, impl):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from peneo_amd.parallel import (all_gather_counts, init_distributed, max_over_ranks, shard_documents,
@@ -23,12 +23,15 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
-    ddp = wrap_data_parallel(net, device_ids=None, bucket_cap_mb=1)
+    ddp = wrap_data_parallel(net, device_ids=None, bucket_cap_mb=1, impl=impl)
     docs = torch.arange(10 * 8, dtype=torch.float32).view(10, 8) / 50.0
     mine = shard_documents(10, rank, world)
     x = docs[list(mine)]
-    loss = ddp(x).pow(2).mean()
-    loss.backward()
+    for _ in range(2):                               # the second step checks that the wrapper re-arms itself
+        for p in net.parameters():
+            p.grad = None
+        loss = ddp(x).pow(2).mean()
+        loss.backward()
     g = torch.cat([p.grad.flatten() for p in net.parameters()])
     # reference: average of the two ranks' local gradients computed without DDP
     ref_net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
@@ -46,12 +49,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ddp_gradient_average_and_gathers():
+@pytest.mark.parametrize("impl", ["flat", "ddp"])
+def test_ddp_gradient_average_and_gathers(impl):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, impl)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
