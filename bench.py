@@ -7,7 +7,7 @@
 
 One "step" = forward + loss + backward of `--docs-per-gpu` synthetic RFUND-shaped documents per GPU in
 train mode (dropout on), bf16 MFMA inputs / fp32 accumulate, fp32 master weights re-cast every step, and
-for N > 1 the RCCL all-reduce of all 127 M gradients (DDP, bf16 buckets).  No optimizer step (the metric
+for N > 1 the RCCL all-reduce of all 127 M gradients (one flat bf16 buffer).  No optimizer step (the metric
 is fwd+bwd).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
