@@ -291,3 +291,46 @@ print("ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_flat_grad_data_parallel_over_rccl_world_of_one():
+    """The data-parallel wrapper on the real backend (RCCL) with a single rank: gradients pass through the bf16 wire buffer
+    and the all-reduce unchanged up to bf16 rounding, on two consecutive steps."""
+    import os, subprocess, sys
+    code = """
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+import torch.distributed as dist
+from conftest import load_golden
+from peneo_amd.model import PEneoConfig, PEneoModel
+from peneo_amd.parallel import wrap_data_parallel, FlatGradDataParallel
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+fx = load_golden("lmv3_tiny")
+m = PEneoModel(PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"}))
+m.load_state_dict(fx["state_dict"], strict=True)
+m = m.cuda().set_compute_dtype(torch.bfloat16).eval()
+b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in fx["batch"].items()}
+def grads(net):
+    for p in m.parameters(): p.grad = None
+    out = net(**b); out["loss"].backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+ref = grads(m)
+net = wrap_data_parallel(m, device_ids=[0])
+assert isinstance(net, FlatGradDataParallel) and net.flat.dtype == torch.bfloat16
+for step in range(2):
+    got = grads(net)
+    assert set(got) == set(ref)
+    for n in ref:
+        err = float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12))
+        assert err < 1e-2, (step, n, err)
+with net.no_sync():
+    got = grads(net)
+assert all(float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12)) < 5e-4 for n in ref)   # no wire round trip (fp32 atomics reorder sums)
+dist.destroy_process_group()
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
