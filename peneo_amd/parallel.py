@@ -104,12 +104,13 @@ class FlatGradDataParallel(torch.nn.Module):
         if have:
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         dist.all_reduce(self.flat)
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)         # one pass over the wire buffer (half the bytes of the fp32 gradients)
         if have:
             torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
-            torch._foreach_mul_([p.grad for p, _ in have], 1.0 / self.world)
         for p, v in zip(self.params, self.views):
             if p.grad is None:                       # unused on this rank, used elsewhere
-                p.grad = v.to(torch.float32) / self.world
+                p.grad = v.to(torch.float32)
 
 
 def wrap_data_parallel(model: torch.nn.Module, device_ids=None, bucket_cap_mb: int = 128, compress: str = "bf16",
