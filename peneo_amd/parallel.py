@@ -63,6 +63,7 @@ class FlatGradDataParallel(torch.nn.Module):
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, offs)]
         self.require_sync = True
         self._armed = False
+        self.sync_calls = 0                          # all-reduces issued so far (tests)
         with torch.no_grad():                       # every rank starts from rank 0's parameters and buffers
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0)
@@ -97,6 +98,7 @@ class FlatGradDataParallel(torch.nn.Module):
     def sync_gradients(self) -> None:
         """Average the gradients over the ranks (runs by itself at the end of backward())."""
         self._armed = False
+        self.sync_calls += 1
         have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
         for p, v in zip(self.params, self.views):
             if p.grad is None:

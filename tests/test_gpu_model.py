@@ -326,8 +326,10 @@ for step in range(2):
     for n in ref:
         err = float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12))
         assert err < 1e-2, (step, n, err)
+assert net.sync_calls == 2, net.sync_calls        # armed from the PEneoOutput fields, once per backward
 with net.no_sync():
     got = grads(net)
+assert net.sync_calls == 2
 assert all(float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12)) < 5e-4 for n in ref)   # no wire round trip (fp32 atomics reorder sums)
 dist.destroy_process_group()
 print("ok")
