@@ -308,7 +308,8 @@ class _LayerStage(torch.autograd.Function):
                                 drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
         h1 = ops.gemm(att, Wo, bias=bo, residual=x, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2))
         a, m1, r1 = ops.layernorm_fwd(h1, g1, b1, cfg.layer_norm_eps)
-        zi = torch.empty((B * T, cfg.intermediate_size), dtype=dt, device=x.device)
+        # the GELU pre-activation is only needed by the backward: inference (no input needs a gradient) skips its 35 MB store
+        zi = torch.empty((B * T, cfg.intermediate_size), dtype=dt, device=x.device) if any(ctx.needs_input_grad) else None
         inter = ops.gemm(a, Wi, bias=bi, act=ACT_GELU, preact=zi)
         h2 = ops.gemm(inter, Wo2, bias=bo2, residual=a, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3))
         out, m2, r2 = ops.layernorm_fwd(h2, g2, b2, cfg.layer_norm_eps)
