@@ -64,6 +64,24 @@ class FlatGradDataParallel(torch.nn.Module):
         self.require_sync = True
         self._armed = False
         self.sync_calls = 0                          # all-reduces issued so far (tests)
+        # Optional overlap (PENEO_DP_CHUNKS=2, off by default: it cannot be measured on one GPU).  Gradients arrive in
+        # roughly reverse parameter order, so the upper half of the flat buffer (by bytes) is complete long before the
+        # embedding tables: it is packed and all-reduced asynchronously as soon as the parameter just below the split has
+        # its gradient, while the backward of the lower half is still running.
+        self._split = None
+        self._early = None
+        self.early_calls = 0
+        chunks = int(os.environ.get("PENEO_DP_CHUNKS", "1"))
+        if chunks >= 2 and len(self.params) >= 2:
+            half, acc, split = total // 2, 0, len(self.params) - 1
+            for i in range(len(self.params) - 1, 0, -1):
+                acc += self.params[i].numel()
+                if acc >= half:
+                    split = i
+                    break
+            self._split = max(1, split)
+            self._split_off = offs[self._split]
+            self.params[self._split - 1].register_post_accumulate_grad_hook(self._upper_half_ready)
         with torch.no_grad():                       # every rank starts from rank 0's parameters and buffers
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0)
@@ -95,17 +113,36 @@ class FlatGradDataParallel(torch.nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self.sync_gradients)
         return grad
 
+    def _pack(self, lo: int, hi: int) -> None:
+        have = [(p, v) for p, v in zip(self.params[lo:hi], self.views[lo:hi]) if p.grad is not None]
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+            if p.grad is None:
+                v.zero_()
+        if have:
+            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+
+    def _upper_half_ready(self, _param) -> None:
+        if self._armed and self.require_sync and self._early is None:
+            self._pack(self._split, len(self.params))
+            self._early = dist.all_reduce(self.flat[self._split_off:], async_op=True)
+            self.early_calls += 1
+
     def sync_gradients(self) -> None:
         """Average the gradients over the ranks (runs by itself at the end of backward())."""
         self._armed = False
         self.sync_calls += 1
         have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-        if have:
-            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
-        dist.all_reduce(self.flat)
+        if self._split is not None:
+            if self._early is None:                  # the hook did not fire on this rank: same two collectives, same order
+                self._pack(self._split, len(self.params))
+                self._early = dist.all_reduce(self.flat[self._split_off:], async_op=True)
+            self._pack(0, self._split)               # the upper half is already on the wire
+            dist.all_reduce(self.flat[:self._split_off])
+            self._early.wait()
+            self._early = None
+        else:
+            self._pack(0, len(self.params))
+            dist.all_reduce(self.flat)
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)         # one pass over the wire buffer (half the bytes of the fp32 gradients)
         if have:

@@ -23,7 +23,12 @@ def _worker(rank, world, port, q, impl):
     assert (r, w) == (rank, world)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
+    if impl == "flat2":                              # the upper half of the gradients goes on the wire during the backward
+        os.environ["PENEO_DP_CHUNKS"] = "2"
+        impl = "flat"
     ddp = wrap_data_parallel(net, device_ids=None, bucket_cap_mb=1, impl=impl)
+    if os.environ.get("PENEO_DP_CHUNKS") == "2":
+        assert ddp._split is not None
     docs = torch.arange(10 * 8, dtype=torch.float32).view(10, 8) / 50.0
     mine = shard_documents(10, rank, world)
     x = docs[list(mine)]
@@ -32,6 +37,8 @@ def _worker(rank, world, port, q, impl):
             p.grad = None
         loss = ddp(x).pow(2).mean()
         loss.backward()
+    if os.environ.get("PENEO_DP_CHUNKS") == "2":
+        assert ddp.early_calls == 2 and ddp.sync_calls == 2
     g = torch.cat([p.grad.flatten() for p in net.parameters()])
     # reference: average of the two ranks' local gradients computed without DDP
     ref_net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
@@ -49,7 +56,7 @@ def _worker(rank, world, port, q, impl):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("impl", ["flat", "ddp"])
+@pytest.mark.parametrize("impl", ["flat", "flat2", "ddp"])
 def test_ddp_gradient_average_and_gathers(impl):
     world = 2
     port = _free_port()
