@@ -339,9 +339,10 @@ int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int
  *   loss_h = num_h / den_h ; total = sum_h ratio_h * loss_h ; scale_h = ratio_h / den_h (the factor the
  *   backward applies to the un-normalised dlogits) ; dl_sum[c] = sum_p dlogits[p, c] (second-layer bias grads).
  * out: [num_heads + 1] = per-head losses then the total.  (model/peneo_decoder.py:315-336,375-428)
+ * inv_den (optional, [num_heads]) = 1 / den_h: the factor for a gradient arriving on a per-head loss itself.
  * ------------------------------------------------------------------------------------------ */
 int peneo_loss_finish(const float* partials, int64_t n_partials, const float* ratio, int num_heads, int total_classes,
-                      float* out, float* scale, float* dl_sum, peneo_stream_t stream);
+                      float* out, float* scale, float* dl_sum, float* inv_den, peneo_stream_t stream);
 /* stand-alone weighted CE on materialised logits [rows, C] (used by the unfused parity path) */
 int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* class_weight, int64_t rows, int C,
                       float* num, float* den, float* dlogits, peneo_stream_t stream);
@@ -357,11 +358,14 @@ int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* cla
  * parameters at lr x peneo_downstream_speedup_ratio, no decay on biases / LayerNorm) in ONE launch.
  * Arithmetic of torch.optim.AdamW (decoupled decay, bias-corrected moments).  The table and the two chunk maps
  * (chunk c covers elements [chunk_index[c] * peneo_adamw_chunk_elems(), ...) of tensor chunk_tensor[c]) live in
- * device memory and are built once.  `step` counts from 1.
+ * device memory and are built once.  `step` counts from 1; a tensor whose own count differs (state resumed from a
+ * checkpoint with per-parameter steps, a parameter that joined later) carries the difference in `step_offset`:
+ * its bias corrections use step + step_offset (which must be >= 1).
  * ------------------------------------------------------------------------------------------ */
 typedef struct peneo_adamw_tensor {
   float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
   int64_t numel; float lr; float weight_decay;
+  int32_t step_offset; int32_t reserved;
 } peneo_adamw_tensor;
 int peneo_adamw_chunk_elems(void);
 int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,

@@ -166,8 +166,13 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* x, int64_t ldx
 constexpr int ADAMW_CHUNK = 4096;
 __global__ __launch_bounds__(256) void adamw_kernel(const peneo_adamw_tensor* tab, const int32_t* chunk_tensor,
                                                     const int32_t* chunk_index, float beta1, float beta2, float eps,
-                                                    float bc1, float rsqrt_bc2) {
+                                                    float bc1, float rsqrt_bc2, int step) {
   const peneo_adamw_tensor t = tab[chunk_tensor[blockIdx.x]];
+  if (t.step_offset != 0) {   // this tensor's own step count (block-uniform branch; resumed / late-joining parameters only)
+    const double s = (double)(step + t.step_offset);
+    bc1 = (float)(1.0 - pow((double)beta1, s));
+    rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, s)));
+  }
   const int64_t base = (int64_t)chunk_index[blockIdx.x] * ADAMW_CHUNK;
   const int64_t end = min(t.numel, base + ADAMW_CHUNK);
   const float step_size = t.lr / bc1, decay = 1.0f - t.lr * t.weight_decay;
@@ -213,7 +218,7 @@ extern "C" int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32
   PENEO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "peneo_adamw_step: bad hyper-parameters");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, chunk_tensor_dev, chunk_index_dev,
-                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)));
+                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), step);
   return check_launch("peneo_adamw_step");
 }
 

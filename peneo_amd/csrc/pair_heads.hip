@@ -792,7 +792,8 @@ __global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzPa
 
 // partials [n][32] (num[8] | den[8] | dl_sum[16]) -> per-head losses, total, backward scales, dl_sum
 __global__ __launch_bounds__(1024) void loss_finish_kernel(const float* partials, int64_t n, const float* ratio, int nh,
-                                                           int total_classes, float* out, float* scale, float* dl_sum) {
+                                                           int total_classes, float* out, float* scale, float* dl_sum,
+                                                           float* inv_den) {
   __shared__ float red[32][33];
   const int col = threadIdx.x & 31, row = threadIdx.x >> 5;   // 32 x 32
   float s = 0.f;
@@ -812,6 +813,7 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(const float* partials
       out[h] = l;
       tot += ratio[h] * l;
       if (scale) scale[h] = ratio[h] / red[0][8 + h];
+      if (inv_den) inv_den[h] = 1.0f / red[0][8 + h];
     }
     out[nh] = tot;
   }
@@ -1437,11 +1439,11 @@ extern "C" int64_t peneo_pair_loss_partials(int B, int N) {
 }
 
 extern "C" int peneo_loss_finish(const float* partials, int64_t n_partials, const float* ratio, int num_heads, int total_classes,
-                                 float* out, float* scale, float* dl_sum, peneo_stream_t stream) {
+                                 float* out, float* scale, float* dl_sum, float* inv_den, peneo_stream_t stream) {
   PENEO_REQUIRE(partials && n_partials > 0 && ratio && out && num_heads > 0 && num_heads <= PENEO_MAX_HEADS &&
                 total_classes >= 0 && total_classes <= NCP, "peneo_loss_finish: bad arguments");
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, n_partials, ratio, num_heads,
-                     total_classes, out, scale, dl_sum);
+                     total_classes, out, scale, dl_sum, inv_den);
   return check_launch("peneo_loss_finish");
 }
 

@@ -42,7 +42,7 @@ class GemmProblem(C.Structure):
 
 class AdamwTensor(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("numel", _i64), ("lr", _f),
-                ("weight_decay", _f)]
+                ("weight_decay", _f), ("step_offset", _i), ("reserved", _i)]
 
 
 class EmbedTables(C.Structure):
@@ -111,7 +111,7 @@ SIGNATURES = {
     "peneo_pair_dz": (_i, [_i, _vp, _i64, C.POINTER(PairDzArgs), _vp, _vp]),
     "peneo_pair_dz_fused": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(PairDzArgs), _vp, _vp, _vp, _vp, _vp]),
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
-    "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "peneo_adamw_chunk_elems": (_i, []),
     "peneo_adamw_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),

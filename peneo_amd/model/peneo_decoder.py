@@ -202,7 +202,7 @@ class _DecoderStage(torch.autograd.Function):
             ratio = dec.loss_ratio_tensor(dev)
             losses, scale, dls = ops.loss_finish(partials, ratio, sum(HEAD_CLASSES))
             outs = [losses[5]] + [losses[i] for i in range(5)]
-            saved.update(scale=scale, dlog=dlog, dls=dls)
+            saved.update(scale=scale[0], inv_den=scale[1], dlog=dlog, dls=dls)
         else:
             outs = [None] * 6
         saved.update(ab=ab, B=B, N=N, D=D, seq=seq)
@@ -210,13 +210,14 @@ class _DecoderStage(torch.autograd.Function):
         ctx.has_loss = tags is not None
         if logits is None:
             logits = [None] * 5
-        for lg in logits:
-            if lg is not None:
-                ctx.mark_non_differentiable(lg)
+        # ONE call: each call replaces ctx.non_differentiable.  The logits carry no gradient (the CE is fused into the
+        # kernel that produces them), so a loss built on them outside the model raises instead of training on zeros.
+        ctx.mark_non_differentiable(*[lg for lg in logits if lg is not None])
+        ctx.set_materialize_grads(False)             # unused loss outputs arrive as None in backward, not as zero tensors
         return tuple(outs) + tuple(logits)
 
     @staticmethod
-    def backward(ctx, d_loss, *unused):
+    def backward(ctx, d_loss, d_le=None, d_elh=None, d_elt=None, d_lgh=None, d_lgt=None, *unused):
         dec, sv, params = ctx.dec, ctx.saved, ctx.params
         if not ctx.has_loss:
             raise PeneoHipError("backward through the PEneo decoder needs the five *_shaking_tag label maps")
@@ -230,8 +231,15 @@ class _DecoderStage(torch.autograd.Function):
         ab, seeds = sv["ab"], sv["seeds"]
         dt, dev = ab.dtype, ab.device
         nh = len(HEAD_NAMES)
-        # dlogits are un-normalised: scale_h = ratio_h / den_h, times the incoming d(loss)
-        scale = sv["scale"] * d_loss.to(torch.float32)
+        # dlogits are un-normalised: scale_h = ratio_h / den_h, times the incoming d(loss); the five per-head losses are
+        # ordinary differentiable outputs as in the reference (peneo_decoder.py:375-428): their own incoming gradients
+        # enter head by head as d(head loss) / den_h = d_head * scale_h / ratio_h
+        scale = sv["scale"] * (d_loss.to(torch.float32) if d_loss is not None else 0.0)
+        d_heads = [d_le, d_elh, d_elt, d_lgh, d_lgt]
+        if any(d is not None for d in d_heads):
+            extra = torch.stack([d.to(torch.float32).reshape(()) if d is not None else torch.zeros((), device=dev)
+                                 for d in d_heads])
+            scale = scale + extra * sv["inv_den"]
         w1s, b1s = [hd[0] for hd in heads], [hd[1] for hd in heads]
         w2s, b2s = [hd[2] for hd in heads], [hd[3] for hd in heads]
         W1cat = wc.cat_rows("dec.w1cat", w1s, dt)                      # [nh*D, D]

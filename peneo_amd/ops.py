@@ -566,13 +566,13 @@ def pair_dz_finish(workspace: torch.Tensor, nh: int, D: int, classes: Sequence[i
 
 
 def loss_finish(partials: torch.Tensor, ratio: torch.Tensor, total_classes: int):
-    """-> (out [nh + 1] per-head losses then total, scale [nh] = ratio_h / den_h, dl_sum [total_classes])."""
+    """-> (out [nh + 1] per-head losses then total, scale [2, nh] = (ratio_h / den_h, 1 / den_h), dl_sum [total_classes])."""
     nh = ratio.numel()
     out = torch.empty(nh + 1, dtype=torch.float32, device=partials.device)
-    scale = torch.empty(nh, dtype=torch.float32, device=partials.device)
+    scale = torch.empty((2, nh), dtype=torch.float32, device=partials.device)
     dls = torch.empty(total_classes, dtype=torch.float32, device=partials.device)
-    check(lib().peneo_loss_finish(ptr(partials), partials.shape[0], ptr(ratio), nh, total_classes, ptr(out), ptr(scale),
-                                  ptr(dls), stream()), "peneo_loss_finish")
+    check(lib().peneo_loss_finish(ptr(partials), partials.shape[0], ptr(ratio), nh, total_classes, ptr(out), ptr(scale[0]),
+                                  ptr(dls), ptr(scale[1]), stream()), "peneo_loss_finish")
     return out, scale, dls
 
 

@@ -43,32 +43,70 @@ def peneo_param_groups(model: nn.Module, lr: float, weight_decay: float, speedup
 
 class FusedAdamW(torch.optim.Optimizer):
     """AdamW over all groups in one kernel launch per step (fp32 master parameters, contiguous fp32 gradients).
-    Learning rates may be changed between steps through ``param_groups`` (schedulers work unchanged)."""
+    Learning rates may be changed between steps through ``param_groups`` (schedulers work unchanged).
+
+    State layout is torch.optim.AdamW's (``state[p] = {"step", "exp_avg", "exp_avg_sq"}``), so ``state_dict()`` /
+    ``load_state_dict()`` round-trip and a reference ``optimizer.pt`` resumes with its own step counts: the kernel takes
+    one global step plus a per-tensor offset (0 unless a checkpoint holds differing counts or a parameter joined late).
+    ``state[p]["step"]`` is written back lazily (in ``state_dict()`` and before the device tables are rebuilt), not by
+    241 host tensor updates per step."""
 
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = None
         self._step = 0
+        self._entries = []
+        self._offsets = []
+
+    # ---- step bookkeeping -------------------------------------------------------------------------------------------
+    def _flush_steps(self) -> None:
+        """Write the step counts of the tracked tensors into ``self.state`` (torch's format: a CPU float tensor)."""
+        for (p, st, _), off in zip(self._entries, self._offsets):
+            st["step"] = torch.tensor(float(self._step + off))
+
+    def state_dict(self):
+        self._flush_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        # self.state was replaced: the cached per-parameter dicts and the device table (moment pointers) are stale
+        self._tables, self._entries, self._offsets, self._step = None, [], [], 0
+
+    def __setstate__(self, state) -> None:
+        super().__setstate__(state)
+        self._tables, self._entries, self._offsets = None, [], []
+        self._step = getattr(self, "_step", 0)
+
+    def _wanted(self):
+        return [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"] if p.grad is not None]
 
     def _build(self):
+        self._flush_steps()                          # a rebuild (new parameters with gradients) keeps everyone's count
         chunk = lib().peneo_adamw_chunk_elems()
-        entries, chunk_t, chunk_i, owners = [], [], [], []
-        for gi, group in enumerate(self.param_groups):
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise hip.PeneoHipError("FusedAdamW needs contiguous fp32 parameters on the GPU")
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                t = len(entries)
-                entries.append((p, st, gi))
-                for c in range((p.numel() + chunk - 1) // chunk):
-                    chunk_t.append(t)
-                    chunk_i.append(c)
+        entries, chunk_t, chunk_i, steps = [], [], [], []
+        for p, gi in self._wanted():
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise hip.PeneoHipError("FusedAdamW needs contiguous fp32 parameters on the GPU")
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            for k in ("exp_avg", "exp_avg_sq"):      # e.g. moments loaded from a checkpoint in another dtype / layout
+                if st[k].dtype != torch.float32 or not st[k].is_contiguous() or st[k].device != p.device:
+                    st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+            steps.append(int(float(st.get("step", 0))))
+            t = len(entries)
+            entries.append((p, st, gi))
+            for c in range((p.numel() + chunk - 1) // chunk):
+                chunk_t.append(t)
+                chunk_i.append(c)
+        if not entries:
+            raise hip.PeneoHipError("FusedAdamW.step(): no parameter has a gradient")
         dev = entries[0][0].device
+        # global step = the most common count (all equal in practice), the others ride on per-tensor offsets
+        self._step = max(set(steps), key=steps.count)
+        self._offsets = [s - self._step for s in steps]
         self._entries = entries
         self._chunk_t = torch.tensor(chunk_t, dtype=torch.int32, device=dev)
         self._chunk_i = torch.tensor(chunk_i, dtype=torch.int32, device=dev)
@@ -85,10 +123,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise hip.PeneoHipError("FusedAdamW: every tracked parameter needs a contiguous fp32 .grad each step")
             group = self.param_groups[gi]
             e = self._host[k]
-            vals = (p.data_ptr(), g.data_ptr(), float(group["lr"]), float(group["weight_decay"]))
+            vals = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    float(group["lr"]), float(group["weight_decay"]), self._offsets[k])
             if self._grads[k] != vals:
-                e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                e.numel, e.lr, e.weight_decay = p.numel(), vals[2], vals[3]
+                e.param, e.grad, e.exp_avg, e.exp_avg_sq = vals[:4]
+                e.numel, e.lr, e.weight_decay, e.step_offset = p.numel(), vals[4], vals[5], vals[6]
                 self._grads[k] = vals
                 dirty = True
         if dirty:   # pointer / lr table changed (new .grad tensors, scheduler step): one small H2D copy
@@ -98,6 +137,10 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        if self._tables is not None:                 # the set of parameters with gradients changed: rebuild the tables
+            want = self._wanted()
+            if len(want) != len(self._entries) or any(a is not b[0] for (a, _), b in zip(want, self._entries)):
+                self._tables = None
         if self._tables is None:
             self._build()
         self._refresh()

@@ -64,13 +64,16 @@ class FlatGradDataParallel(torch.nn.Module):
         self.require_sync = True
         self._armed = False
         self.sync_calls = 0                          # all-reduces issued so far (tests)
-        # Optional overlap (PENEO_DP_CHUNKS=2, off by default: it cannot be measured on one GPU).  Gradients arrive in
-        # roughly reverse parameter order, so the upper half of the flat buffer (by bytes) is complete long before the
-        # embedding tables: it is packed and all-reduced asynchronously as soon as the parameter just below the split has
-        # its gradient, while the backward of the lower half is still running.
+        # Optional overlap (PENEO_DP_CHUNKS=2, off by default: it cannot be measured on one GPU).  The upper half of the flat
+        # buffer (by bytes; mostly the decoder and the upper encoder layers) is packed and all-reduced asynchronously while
+        # the backward of the rest is still running.  Gradient arrival order is NOT parameter order (the embedding-stage
+        # parameters registered after encoder.layer.* get theirs last; the order inside one stage is undefined), so the
+        # early collective starts only when EVERY upper-half parameter has reported its gradient this step (counted
+        # post-accumulate hooks); parameters that report late, or never, are handled by the fall-back in sync_gradients.
         self._split = None
         self._early = None
         self.early_calls = 0
+        self._upper_ids = set()
         chunks = int(os.environ.get("PENEO_DP_CHUNKS", "1"))
         if chunks >= 2 and len(self.params) >= 2:
             half, acc, split = total // 2, 0, len(self.params) - 1
@@ -81,10 +84,12 @@ class FlatGradDataParallel(torch.nn.Module):
                     break
             self._split = max(1, split)
             self._split_off = offs[self._split]
-            self.params[self._split - 1].register_post_accumulate_grad_hook(self._upper_half_ready)
+            for p in self.params[self._split:]:
+                p.register_post_accumulate_grad_hook(self._upper_grad_ready)
         with torch.no_grad():                       # every rank starts from rank 0's parameters and buffers
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0)
+        _invalidate_working_weights()
 
     def no_sync(self):
         import contextlib
@@ -121,8 +126,13 @@ class FlatGradDataParallel(torch.nn.Module):
         if have:
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
 
-    def _upper_half_ready(self, _param) -> None:
-        if self._armed and self.require_sync and self._early is None:
+    def _upper_grad_ready(self, param) -> None:
+        if not (self._armed and self.require_sync) or self._early is not None:
+            return
+        if id(param) in self._upper_ids:             # a second accumulation into the same parameter: counted once
+            return
+        self._upper_ids.add(id(param))
+        if len(self._upper_ids) == len(self.params) - self._split:
             self._pack(self._split, len(self.params))
             self._early = dist.all_reduce(self.flat[self._split_off:], async_op=True)
             self.early_calls += 1
@@ -131,6 +141,7 @@ class FlatGradDataParallel(torch.nn.Module):
         """Average the gradients over the ranks (runs by itself at the end of backward())."""
         self._armed = False
         self.sync_calls += 1
+        self._upper_ids.clear()
         have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
         if self._split is not None:
             if self._early is None:                  # the hook did not fire on this rank: same two collectives, same order
@@ -152,6 +163,16 @@ class FlatGradDataParallel(torch.nn.Module):
                 p.grad = v.to(torch.float32)
 
 
+def _invalidate_working_weights() -> None:
+    """The broadcast wrote the parameters through ``.data``: neither ``_version`` nor the parameter epoch moved, so
+    working-precision copies cached by an earlier forward would be stale on ranks != 0."""
+    try:
+        from .model.engine import bump_param_epoch
+    except Exception:                                # plain torch modules (CPU tests) have no weight caches
+        return
+    bump_param_epoch()
+
+
 def wrap_data_parallel(model: torch.nn.Module, device_ids=None, bucket_cap_mb: int = 128, compress: str = "bf16",
                        impl: Optional[str] = None):
     """Data-parallel wrapper.  impl = "flat" (default, PENEO_DP_IMPL): FlatGradDataParallel above.  impl = "ddp": torch's
@@ -166,6 +187,7 @@ def wrap_data_parallel(model: torch.nn.Module, device_ids=None, bucket_cap_mb: i
     if compress == "bf16" and dist.get_backend() == "nccl":
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
+    _invalidate_working_weights()                    # DDP's constructor broadcast rank 0's parameters in place
     return ddp
 
 

@@ -562,7 +562,7 @@ def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
         assert abs(float(den[h]) - float(wsum)) / float(wsum) < 1e-5
         assert rel_err(dlog[h], lr.grad) < 1e-4
     assert rel_err(dls, torch.cat([d.sum((0, 1)) for d in dlog])) < 1e-3
-    assert abs(float(out[5]) - float((num / den).sum())) < 1e-4 and rel_err(scale, 1.0 / den) < 1e-5
+    assert abs(float(out[5]) - float((num / den).sum())) < 1e-4 and rel_err(scale[0], 1.0 / den) < 1e-5 and rel_err(scale[1], 1.0 / den) < 1e-5
     # loss-only call (no logits written) agrees
     _, part2, _ = ops.pair_heads_fwd(ab, wp, torch.cat(b1), torch.cat(b2), classes, want_logits=False,
                                      tags=tags, class_weights=cw)

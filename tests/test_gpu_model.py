@@ -293,9 +293,12 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_flat_grad_data_parallel_over_rccl_world_of_one():
+@pytest.mark.parametrize("chunks", ["1", "2"])
+def test_flat_grad_data_parallel_over_rccl_world_of_one(chunks):
     """The data-parallel wrapper on the real backend (RCCL) with a single rank: gradients pass through the bf16 wire buffer
-    and the all-reduce unchanged up to bf16 rounding, on two consecutive steps."""
+    and the all-reduce unchanged up to bf16 rounding, on two consecutive steps.  chunks = 2: the early all-reduce of the
+    upper half must not lose the gradients that arrive last (rel-pos tables, patch embedding, the embedding LayerNorms are
+    registered after encoder.layer.* but get their gradients from the last backward stage)."""
     import os, subprocess, sys
     code = """
 import os, sys, torch
@@ -320,12 +323,16 @@ def grads(net):
 ref = grads(m)
 net = wrap_data_parallel(m, device_ids=[0])
 assert isinstance(net, FlatGradDataParallel) and net.flat.dtype == torch.bfloat16
+if os.environ.get("PENEO_DP_CHUNKS") == "2":
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert net._split is not None and any("rel_pos" in n or "patch_embed" in n for n in names[net._split:])
 for step in range(2):
     got = grads(net)
     assert set(got) == set(ref)
     for n in ref:
         err = float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12))
         assert err < 1e-2, (step, n, err)
+        assert float(ref[n].abs().max()) == 0 or float(got[n].abs().max()) > 0, n
 assert net.sync_calls == 2, net.sync_calls        # armed from the PEneoOutput fields, once per backward
 with net.no_sync():
     got = grads(net)
@@ -334,5 +341,107 @@ assert all(float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e
 dist.destroy_process_group()
 print("ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PENEO_DP_CHUNKS=chunks), capture_output=True,
+                       text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_fused_adamw_resumes_from_state_dict_and_from_torch_adamw():
+    """state_dict() carries torch.optim.AdamW's layout (per-parameter `step`, exp_avg, exp_avg_sq): 3 steps + save + load
+    into a fresh optimizer + 3 steps == 6 uninterrupted steps of torch.optim.AdamW; a torch AdamW checkpoint (the
+    reference's optimizer.pt) resumes too; load_state_dict() after a step() re-points the device table at the loaded moments."""
+    from peneo_amd.optim import FusedAdamW
+
+    def make():
+        torch.manual_seed(3)
+        return [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in [(70, 33), (70,), (5001, 70), (3,)]]
+
+    gen = torch.Generator().manual_seed(4)
+    grads = [[torch.randn(s, generator=gen).cuda() for s in [(70, 33), (70,), (5001, 70), (3,)]] for _ in range(6)]
+
+    def run(opt, ps, steps):
+        for k in steps:
+            for p, g in zip(ps, grads[k]):
+                p.grad = g.clone()
+            opt.step()
+
+    kw = dict(lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
+    pr = make(); ref = torch.optim.AdamW(pr, **kw); run(ref, pr, range(6))
+    # (a) fused -> state_dict -> fresh fused
+    pa = make(); oa = FusedAdamW(pa, **kw); run(oa, pa, range(3))
+    sd = oa.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values()) and len(sd["state"]) == 4
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ob = FusedAdamW(pb, **kw); ob.load_state_dict(sd); run(ob, pb, range(3, 6))
+    for a, r in zip(pb, pr):
+        assert maxdiff(a, r) <= 2e-6 * float(r.abs().max()) + 1e-7
+    assert all(float(st["step"]) == 6.0 for st in ob.state_dict()["state"].values())
+    # (b) torch AdamW checkpoint -> fused
+    import copy
+    pt = make(); ot = torch.optim.AdamW(pt, **kw); run(ot, pt, range(3))
+    ckpt = copy.deepcopy(ot.state_dict())            # load_state_dict() aliases same-dtype tensors: keep a pristine copy
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pt]
+    oc = FusedAdamW(pc, **kw); oc.load_state_dict(copy.deepcopy(ckpt)); run(oc, pc, range(3, 6))
+    for a, r in zip(pc, pr):
+        assert maxdiff(a, r) <= 2e-6 * float(r.abs().max()) + 1e-7
+    # (c) load_state_dict AFTER the first step of the same object: the loaded moments are the ones that get updated
+    pd = make(); od = FusedAdamW(pd, **kw); run(od, pd, [5])           # some unrelated step first
+    with torch.no_grad():
+        for p, src in zip(pd, pt):
+            p.copy_(src)
+    od.load_state_dict(copy.deepcopy(ckpt)); run(od, pd, range(3, 6))
+    for a, r in zip(pd, pr):
+        assert maxdiff(a, r) <= 2e-6 * float(r.abs().max()) + 1e-7
+    assert maxdiff(od.state_dict()["state"][0]["exp_avg"], ref.state_dict()["state"][0]["exp_avg"]) < 1e-6
+    # (d) a parameter that gets its first gradient later starts its own bias correction at step 1
+    pe = make(); oe = FusedAdamW(pe, **kw)
+    pf = make(); of = torch.optim.AdamW(pf, **kw)
+    for k in range(4):
+        for j, (p, q, g) in enumerate(zip(pe, pf, grads[k])):
+            if j == 3 and k < 2:
+                p.grad = q.grad = None
+            else:
+                p.grad, q.grad = g.clone(), g.clone()
+        oe.step(); of.step()
+    for a, r in zip(pe, pf):
+        assert maxdiff(a, r) <= 2e-6 * float(r.abs().max()) + 1e-7
+
+
+def test_per_head_losses_are_differentiable_and_logits_are_not():
+    """The five *_loss fields are ordinary differentiable outputs in the reference (peneo_decoder.py:375-428): backward from
+    one of them, or from a re-weighted sum, must give the matching gradients; the logit maps carry no grad_fn."""
+    fx = load_golden("lmv3_tiny")
+    m = build_model(fx["config"], fx["state_dict"]).eval()
+    b = to_cuda(fx["batch"])
+    out = m(**b)
+    for h in HEADS:
+        assert not out[h + "_shaking_outputs"].requires_grad, h
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+
+    def grads_of(loss):
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    g_total = grads_of(out["loss"])                                   # ratios are all 1 in the fixture
+    out = m(**b)
+    g_sum = grads_of(sum(out[h + "_loss"] for h in HEADS))
+    for n in g_total:
+        assert maxdiff(g_sum[n], g_total[n]) <= 2e-4 * float(g_total[n].abs().max()) + 1e-7, n
+    out = m(**b)
+    g_le = grads_of(out["line_extraction_loss"])
+    out = m(**b)
+    g_rest = grads_of(sum(out[h + "_loss"] for h in HEADS[1:]))
+    w = "peneo_decoder.line_extraction_fc.0.weight"
+    assert float(g_le[w].abs().max()) > 0 and float(g_rest[w].abs().max()) == 0
+    for n in g_total:
+        tot = g_le[n] + g_rest[n]
+        assert maxdiff(tot, g_total[n]) <= 2e-4 * float(g_total[n].abs().max()) + 1e-7, n
+    out = m(**b)
+    g_mix = grads_of(0.5 * out["loss"] + 2.0 * out["ent_linking_t2t_loss"])
+    out = m(**b)
+    g_elt = grads_of(out["ent_linking_t2t_loss"])
+    for n in g_total:
+        want = 0.5 * g_total[n] + 2.0 * g_elt[n]
+        assert maxdiff(g_mix[n], want) <= 2e-4 * float(want.abs().max()) + 1e-7, n

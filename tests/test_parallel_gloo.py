@@ -14,7 +14,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, impl):
+class _LateFirst(torch.nn.Module):
+    """Parameter order != gradient order, like the real model: `embed` is registered LAST (it lands in the upper half of the
+    flat buffer) but used FIRST, so its gradient is the last one the backward produces."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
+        self.embed = torch.nn.Linear(8, 16)
+
+    def forward(self, x):
+        return self.body(torch.tanh(self.embed(x)))
+
+
+def _make_net(kind):
+    if kind == "late_first":
+        return _LateFirst()
+    return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
+
+
+def _worker(rank, world, port, q, impl, kind="seq"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from peneo_amd.parallel import (all_gather_counts, init_distributed, max_over_ranks, shard_documents,
@@ -22,7 +41,7 @@ def _worker(rank, world, port, q, impl):
     r, lr, w = init_distributed("gloo")
     assert (r, w) == (rank, world)
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
+    net = _make_net(kind)
     if impl == "flat2":                              # the upper half of the gradients goes on the wire during the backward
         os.environ["PENEO_DP_CHUNKS"] = "2"
         impl = "flat"
@@ -38,10 +57,17 @@ def _worker(rank, world, port, q, impl):
         loss = ddp(x).pow(2).mean()
         loss.backward()
     if os.environ.get("PENEO_DP_CHUNKS") == "2":
-        assert ddp.early_calls == 2 and ddp.sync_calls == 2
+        assert ddp.sync_calls == 2
+        if kind == "seq":                            # every upper-half gradient is there before the backward ends
+            assert ddp.early_calls == 2
+        names = [n for n, _ in net.named_parameters()]
+        if kind == "late_first":                     # the late gradient sits in the upper half: this is the case under test
+            assert any(n.startswith("embed") for n in names[ddp._split:])
+    for n, p in net.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) > 0, n
     g = torch.cat([p.grad.flatten() for p in net.parameters()])
     # reference: average of the two ranks' local gradients computed without DDP
-    ref_net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.SiLU(), torch.nn.Linear(16, 3))
+    ref_net = _make_net(kind)
     ref_net.load_state_dict(net.state_dict())
     acc = None
     for rr in range(world):
@@ -56,13 +82,14 @@ def _worker(rank, world, port, q, impl):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("impl", ["flat", "flat2", "ddp"])
-def test_ddp_gradient_average_and_gathers(impl):
+@pytest.mark.parametrize("impl,kind", [("flat", "seq"), ("flat2", "seq"), ("flat2", "late_first"), ("flat", "late_first"),
+                                       ("ddp", "seq")])
+def test_ddp_gradient_average_and_gathers(impl, kind):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, impl)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, impl, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
