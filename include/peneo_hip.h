@@ -343,6 +343,23 @@ int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int
  * ------------------------------------------------------------------------------------------ */
 int peneo_loss_finish(const float* partials, int64_t n_partials, const float* ratio, int num_heads, int total_classes,
                       float* out, float* scale, float* dl_sum, float* inv_den, peneo_stream_t stream);
+/* K13, OHEM branch ("next" row f.3): CrossEntropyLossOHEM.forward with num_hard_positive / num_hard_negative != -1
+ * (model/custom_loss.py:204-288) as executed by the reference, over the n = B*P flattened pairs of one head:
+ * per-pair weighted CE, positives (tag != 0) and negatives sorted by descending loss (stable: equal losses keep the
+ * flattened order), k = min(count, num_hard); k <= 0 or k == count keeps every element of the class, otherwise the kept
+ * elements are sorted[idx[:k]] (the reference indexes the sorted array with unsorted positions; reproduced).
+ * out8 = [loss, sum of kept losses, k_pos + k_neg, n_pos, n_neg, k_pos, k_neg, 0]; dlogits (optional, [n, C], the
+ * un-normalised w_y (softmax - onehot) written by peneo_pair_heads_fwd) is zeroed on the dropped pairs in place and
+ * dl_sum[C] receives its column sums.  Everything stays on the device (no host read-back of the counts).
+ * Workspace: peneo_ohem_workspace_bytes(n) bytes, 256-byte aligned. */
+size_t peneo_ohem_workspace_bytes(int64_t n);
+int peneo_ohem_ce(const float* logits, const int64_t* tags, const float* class_weight, int64_t n, int C,
+                  int num_hard_positive, int num_hard_negative, float* dlogits, float* out8, float* dl_sum,
+                  void* workspace, size_t workspace_bytes, peneo_stream_t stream);
+/* per-head out8 rows [num_heads, 8] -> out[num_heads + 1] (losses, then sum_h ratio_h loss_h), scale_h = ratio_h / den_h,
+ * inv_den_h = 1 / den_h: the OHEM counterpart of peneo_loss_finish */
+int peneo_ohem_finish(const float* out8, const float* ratio, int num_heads, float* out, float* scale, float* inv_den,
+                      peneo_stream_t stream);
 /* stand-alone weighted CE on materialised logits [rows, C] (used by the unfused parity path) */
 int peneo_weighted_ce(const float* logits, const int64_t* tags, const float* class_weight, int64_t rows, int C,
                       float* num, float* den, float* dlogits, peneo_stream_t stream);

@@ -29,6 +29,7 @@ Reference citations (relative to the upstream repo root):
 * HandshakingKernel ................ model/peneo_decoder.py:118-177
 * PEneoDecoder ..................... model/peneo_decoder.py:201-443
 * CrossEntropyLossOHEM fast path ... model/custom_loss.py:189-202
+* CrossEntropyLossOHEM OHEM branch . model/custom_loss.py:204-288 (``ohem_ce``)
 * spots decoding ................... model/peneo_decoder.py:76-115
 """
 from __future__ import annotations
@@ -381,6 +382,33 @@ def weighted_ce(logits: Tensor, target: Tensor, weight: Optional[Tensor]) -> Ten
     return F.cross_entropy(logits.float().view(-1, logits.shape[-1]), target.view(-1), weight=weight)
 
 
+def ohem_ce(logits: Tensor, target: Tensor, weight: Optional[Tensor], num_hard_positive: int, num_hard_negative: int) -> Tensor:
+    """CrossEntropyLossOHEM.forward with OHEM active, reduction "mean", random=False (custom_loss.py:204-288), stated with
+    explicit ranks instead of the reference's tensor indexing:
+
+    * per-element weighted CE; positives = target != 0, negatives = target == 0, each kept in flattened order (:236-238);
+    * each class is sorted by descending loss; k = min(count, num_hard) (:259-262, :269-272);
+    * k <= 0 -> the class keeps all its elements; k < count -> the reference evaluates ``sorted[idx[:k]]`` (:265-267,
+      :275-277), i.e. for each of the k hardest elements, with position j inside its class list, the j-th largest loss of
+      the class is what enters the sum (the sorted array is indexed with positions of the unsorted one);
+    * loss = (kept positives + kept negatives) / (k_pos + k_neg) with the k's as computed, even when <= 0 (:279-283).
+    """
+    ce = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), target.view(-1), weight=weight, reduction="none")
+    tgt = target.view(-1)
+    total, ks = 0.0, []
+    for cls_mask, num_hard in ((tgt != 0, num_hard_positive), (tgt == 0, num_hard_negative)):
+        vals = ce[cls_mask]                                   # flattened order
+        n = vals.shape[0]
+        k = min(n, num_hard)
+        ks.append(k)
+        if 0 < k < n:
+            order = torch.argsort(vals, descending=True, stable=True)     # order[r] = list position of the r-th largest
+            by_rank = vals[order]                                          # by_rank[r] = r-th largest loss
+            vals = by_rank[order[:k]]                                      # ranks taken from list positions: as executed
+        total = total + vals.sum()
+    return total / (ks[0] + ks[1])
+
+
 def decoder_forward(sd, pcfg, seq: Tensor, tags: Optional[Sequence[Tensor]] = None, training=False,
                     as_executed=False, capture: Optional[dict] = None, p="peneo_decoder.") -> Dict[str, Tensor]:
     """PEneoDecoder.forward (peneo_decoder.py:338-443)."""
@@ -407,7 +435,11 @@ def decoder_forward(sd, pcfg, seq: Tensor, tags: Optional[Sequence[Tensor]] = No
     total = 0.0
     for name, tag, ratio in zip(HEAD_NAMES, tags, ratios):
         w = le_w if name == "line_extraction" else link_w
-        l = weighted_ce(out[name + "_shaking_outputs"], tag, w)
+        hp, hn = pcfg.get("peneo_ohem_num_positive", -1), pcfg.get("peneo_ohem_num_negative", -1)
+        if hp == -1 and hn == -1:
+            l = weighted_ce(out[name + "_shaking_outputs"], tag, w)
+        else:
+            l = ohem_ce(out[name + "_shaking_outputs"], tag, w, hp, hn)
         out[name + "_loss"] = l
         total = total + ratio * l
     out["loss"] = total

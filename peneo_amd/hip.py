@@ -113,6 +113,9 @@ SIGNATURES = {
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
     "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "peneo_ohem_workspace_bytes": (_sz, [_i64]),
+    "peneo_ohem_ce": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "peneo_ohem_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "peneo_adamw_chunk_elems": (_i, []),
     "peneo_adamw_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
     "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

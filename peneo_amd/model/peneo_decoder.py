@@ -139,9 +139,13 @@ class _ClassWeightedCE(nn.Module):
     def __init__(self, weight: torch.Tensor, num_hard_positive: int, num_hard_negative: int):
         super().__init__()
         self.register_buffer("weight", weight)
-        if num_hard_positive != -1 or num_hard_negative != -1:
-            raise NotImplementedError("OHEM (peneo_ohem_num_* != -1) is a 'next' row (SURVEY §8f.3); the shipped "
-                                      "default -1/-1 (plain class-weighted CE) is implemented")
+        # -1 / -1: plain class-weighted mean (custom_loss.py:189-202, fused into the pair-heads kernel); anything else runs
+        # the OHEM branch (:204-288) through peneo_ohem_ce on the logit maps
+        self.num_hard_positive, self.num_hard_negative = int(num_hard_positive), int(num_hard_negative)
+
+    @property
+    def ohem(self) -> bool:
+        return self.num_hard_positive != -1 or self.num_hard_negative != -1
 
 
 def _row_chunks(n: int, max_pairs: int) -> List[Tuple[int, int]]:
@@ -198,7 +202,23 @@ class _DecoderStage(torch.autograd.Function):
                                                     tags=tags, class_weights=cws,
                                                     want_dlogits=need_grad and tags is not None)
         outs = []
-        if tags is not None:
+        if tags is not None and dec.le_loss.ohem:
+            # OHEM: the kept pairs of each head are chosen from its finished logit map; the un-normalised dlogits of the
+            # dropped pairs are zeroed in place, so the backward below runs unchanged with scale_h = ratio_h / (k_pos + k_neg)
+            ratio = dec.loss_ratio_tensor(dev)
+            out8 = torch.empty((len(HEAD_NAMES), 8), dtype=torch.float32, device=dev)
+            dls = torch.zeros(sum(HEAD_CLASSES), dtype=torch.float32, device=dev)
+            ws, off = None, 0
+            for h, c in enumerate(HEAD_CLASSES):
+                lossmod = dec.le_loss if h == 0 else dec.link_loss
+                _, ws = ops.ohem_ce(logits[h], tags[h], cws[h], lossmod.num_hard_positive, lossmod.num_hard_negative,
+                                    dlogits=dlog[h] if dlog is not None else None, out8=out8[h], dl_sum=dls[off:off + c],
+                                    workspace=ws)
+                off += c
+            losses, scale = ops.ohem_finish(out8, ratio)
+            outs = [losses[5]] + [losses[i] for i in range(5)]
+            saved.update(scale=scale[0], inv_den=scale[1], dlog=dlog, dls=dls)
+        elif tags is not None:
             ratio = dec.loss_ratio_tensor(dev)
             losses, scale, dls = ops.loss_finish(partials, ratio, sum(HEAD_CLASSES))
             outs = [losses[5]] + [losses[i] for i in range(5)]

@@ -576,6 +576,38 @@ def loss_finish(partials: torch.Tensor, ratio: torch.Tensor, total_classes: int)
     return out, scale, dls
 
 
+def ohem_ce(logits: torch.Tensor, tags: torch.Tensor, cw: Optional[torch.Tensor], num_hard_positive: int, num_hard_negative: int,
+            dlogits: Optional[torch.Tensor] = None, out8: Optional[torch.Tensor] = None, dl_sum: Optional[torch.Tensor] = None,
+            workspace: Optional[torch.Tensor] = None):
+    """OHEM cross entropy of one head over its flattened pairs (reference custom_loss.py:204-288, as executed).
+    -> out8 = [loss, kept sum, k_pos + k_neg, n_pos, n_neg, k_pos, k_neg, 0] (device); `dlogits` is masked in place."""
+    _c(logits)
+    C_ = logits.shape[-1]
+    n = logits.numel() // C_
+    assert logits.dtype == torch.float32 and tags.dtype == torch.int64 and tags.numel() == n
+    need = lib().peneo_ohem_workspace_bytes(n)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=logits.device)
+    if out8 is None:
+        out8 = torch.empty(8, dtype=torch.float32, device=logits.device)
+    if dlogits is not None:
+        assert dlogits.dtype == torch.float32 and dlogits.numel() == logits.numel()
+        _c(dlogits)
+    check(lib().peneo_ohem_ce(ptr(logits), ptr(_c(tags)), ptr(cw), n, C_, int(num_hard_positive), int(num_hard_negative),
+                              ptr(dlogits), ptr(out8), ptr(dl_sum), ptr(workspace), workspace.numel(), stream()), "peneo_ohem_ce")
+    return out8, workspace
+
+
+def ohem_finish(out8: torch.Tensor, ratio: torch.Tensor):
+    """[nh, 8] per-head OHEM results -> (out [nh + 1], scale [2, nh]) like ``loss_finish``."""
+    nh = ratio.numel()
+    out = torch.empty(nh + 1, dtype=torch.float32, device=out8.device)
+    scale = torch.empty((2, nh), dtype=torch.float32, device=out8.device)
+    check(lib().peneo_ohem_finish(ptr(_c(out8)), ptr(ratio), nh, ptr(out), ptr(scale[0]), ptr(scale[1]), stream()),
+          "peneo_ohem_finish")
+    return out, scale
+
+
 def weighted_ce(logits: torch.Tensor, tags: torch.Tensor, cw: Optional[torch.Tensor], want_dlogits: bool = False):
     _c(logits)
     C_ = logits.shape[-1]

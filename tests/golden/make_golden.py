@@ -143,15 +143,57 @@ def make_base(ref, seed: int = 7):
           f"nonzero={[fx['argmax'][h]['count_nonzero'] for h in HEADS]} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def make_ohem(ref, seed: int = 11):
+    """OHEM branch of the reference's CrossEntropyLossOHEM (model/custom_loss.py:204-288): stand-alone cases (loss and the
+    gradient with respect to the logits) and the tiny LayoutLMv3 model with OHEM switched on (losses + parameter gradients;
+    weights and batch are those of lmv3_tiny.pt)."""
+    from model.custom_loss import CrossEntropyLossOHEM
+    g = torch.Generator().manual_seed(seed)
+    cases = []
+    # (n, C, positive fraction, num_hard_positive, num_hard_negative)
+    for n, C, frac, hp, hn in [(300, 3, 0.10, 5, 40), (300, 2, 0.10, 100, 1000), (1000, 3, 0.02, 8, 8), (64, 3, 0.5, -1, 10),
+                               (64, 3, 0.5, 10, -1), (500, 3, 0.0, 4, 100), (2000, 3, 0.05, 30, 300), (257, 2, 0.2, 51, 1),
+                               (128, 3, 0.1, 0, 20), (4096, 3, 0.01, 16, 512)]:
+        logits = torch.randn(n, C, generator=g) * 2.0
+        target = (torch.rand(n, generator=g) < frac).long() * torch.randint(1, C, (n,), generator=g)
+        w = torch.tensor([1.0, 10.0, 10.0][:C])
+        lg = logits.clone().requires_grad_(True)
+        crit = CrossEntropyLossOHEM(num_hard_positive=hp, num_hard_negative=hn, weight=w)
+        loss = crit(lg, target)
+        grad = None
+        if torch.isfinite(loss):
+            loss.backward()
+            grad = lg.grad.clone()
+        cases.append(dict(logits=logits, target=target, weight=w, num_hard_positive=hp, num_hard_negative=hn,
+                          loss=loss.detach().clone(), grad=grad))
+        print(f"[ohem] n={n} C={C} hp={hp} hn={hn} n_pos={int((target != 0).sum())} loss={float(loss):.6f}")
+    tiny = torch.load(os.path.join(HERE, "lmv3_tiny.pt"), weights_only=False)
+    pcfg = dict(tiny["config"], peneo_ohem_num_positive=3, peneo_ohem_num_negative=60)
+    model = build_reference_model(ref, pcfg, 1)
+    model.load_state_dict(tiny["state_dict"])
+    res = run_reference(model, tiny["batch"])
+    fx = {"cases": cases, "model": {"config": pcfg, "base_fixture": "lmv3_tiny",
+                                    "losses": {k: v for k, v in res["outputs"].items() if k.endswith("loss")},
+                                    "grads": res["grads"]}}
+    path = os.path.join(HERE, "ohem.pt")
+    torch.save(fx, path)
+    print(f"[ohem] model loss={float(res['outputs']['loss']):.6f} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base", action="store_true")
+    ap.add_argument("--only-ohem", action="store_true", help="regenerate tests/golden/ohem.pt only")
     args = ap.parse_args()
     ref = import_reference()
     torch.set_num_threads(8)
+    if args.only_ohem:
+        make_ohem(ref)
+        return
     make_tiny(ref, "lmv3_tiny", peneo_config("layoutlmv3-base", layoutlmv3_config("tiny")), 40, 8, True, True, 1)
     make_tiny(ref, "lmv3_tiny_s24", peneo_config("layoutlmv3-base", layoutlmv3_config("tiny")), 24, 5, True, True, 2)
     make_tiny(ref, "lilt_tiny", peneo_config("lilt-roberta-en-base", lilt_config("tiny")), 33, 6, False, False, 3)
+    make_ohem(ref)
     if args.base:
         make_base(ref)
 

@@ -80,3 +80,30 @@ def test_bucket_function_small_cases():
     b = O.relative_position_bucket(rp, 32, 128)
     assert b.tolist()[6] == 0 and b.tolist()[5] == 1 and b.tolist()[7] == 17
     assert b.max() == 31 and b[0] == 15 and b[-1] == 31
+
+
+def test_ohem_cases_match_reference():
+    """CrossEntropyLossOHEM with OHEM active (custom_loss.py:204-288), run by the real reference: loss and d loss / d logits."""
+    fx = load_golden("ohem")
+    assert len(fx["cases"]) >= 10
+    for c in fx["cases"]:
+        lg = c["logits"].clone().requires_grad_(True)
+        loss = O.ohem_ce(lg, c["target"], c["weight"], c["num_hard_positive"], c["num_hard_negative"])
+        key = (c["num_hard_positive"], c["num_hard_negative"], c["logits"].shape)
+        assert abs(float(loss) - float(c["loss"])) <= 1e-5 * abs(float(c["loss"])) + 1e-6, key
+        if c["grad"] is not None:
+            loss.backward()
+            assert (lg.grad - c["grad"]).abs().max() <= 1e-5 * c["grad"].abs().max() + 1e-8, key
+
+
+def test_ohem_model_matches_reference():
+    fx = load_golden("ohem")["model"]
+    base = load_golden(fx["base_fixture"])
+    sd = _req_grad(base["state_dict"])
+    out = O.peneo_forward(sd, fx["config"], base["batch"])
+    for k, v in fx["losses"].items():
+        assert abs(float(out[k]) - float(v)) < 1e-5 * max(1.0, abs(float(v))), k
+    assert abs(float(out["loss"]) - float(base["outputs"]["loss"])) > 1e-3      # OHEM really changed the loss
+    out["loss"].backward()
+    for n, g in fx["grads"].items():
+        assert (sd[n].grad - g).abs().max() <= 2e-4 * g.abs().max() + 1e-7, n
