@@ -138,3 +138,44 @@ def side_stream(device, role: str) -> "torch.cuda.Stream":
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
 
+
+
+# ---- deferred joins of side-stream work ------------------------------------------------------------------------------
+# A backward stage that put its weight-gradient kernels on a side stream used to end with main.wait_stream(side): the main
+# stream (= the activation-gradient critical path) then idles until the last weight gradient of the layer is done (~50 us
+# per encoder layer, the QKV wgrad can only start once the attention backward has produced dqkv).  When the gradients are
+# freshly assigned (p.grad is None: autograd's AccumulateGrad only stores the tensor, no kernel reads it) the join can wait:
+# the stage leaves an event here, the NEXT stage's end (one layer of slack) or the end-of-backward callback waits for it on
+# the main stream.  Anything that reads gradients on the main stream before the backward has ended (the data-parallel
+# wrapper's early pack) calls join_pending() first.
+_PENDING: list = []
+_CALLBACK_ARMED = [False]
+
+
+def _end_of_backward_join() -> None:
+    _CALLBACK_ARMED[0] = False
+    join_pending()
+
+
+def defer_join(side: "torch.cuda.Stream", keep=()) -> None:
+    """Record `side`'s progress; waits for the events left by EARLIER stages (they are long complete) on the current stream.
+    `keep`: tensors the side stream is still reading; they were allocated on the main stream, so they must stay referenced
+    until the join (the caching allocator would hand their memory to the next main-stream allocation otherwise)."""
+    older = list(_PENDING)
+    _PENDING.clear()
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _PENDING.append((ev, tuple(keep)))
+    main = torch.cuda.current_stream()
+    for e, _ in older:
+        main.wait_event(e)
+    if not _CALLBACK_ARMED[0]:
+        _CALLBACK_ARMED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
+
+
+def join_pending() -> None:
+    """Make the current stream wait for every deferred side-stream event."""
+    main = torch.cuda.current_stream()
+    while _PENDING:
+        main.wait_event(_PENDING.pop()[0])

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import ops
 from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
 from .configuration_peneo import LayoutLMv3Config
-from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
+from .engine import DropoutSeeds, WeightCache, defer_join, join_pending, zeros_like_param, zeros_like_params
 from .engine import side_stream as engine_side_stream
 from .relpos import bucket_lut, visual_xy
 
@@ -281,6 +281,7 @@ class _EmbedStage(torch.autograd.Function):
                                     1.0 / math.sqrt(d))
                 st.g_bias = None
             st = st_parent
+        join_pending()     # weight-gradient work the layer stages left on the side stream
         grads = tuple(g[id(p)] if p.requires_grad else None for p in ctx.params)
         return (None, None, None, None, None, None) + grads
 
@@ -429,7 +430,11 @@ class _LayerStage(torch.autograd.Function):
         _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
         if side is not None:
-            main.wait_stream(side)
+            if model.defer_wgrad_join and all(p.grad is None for p in ctx.params):
+                # joined one stage later (engine.py): the critical path does not wait for dW_qkv
+                defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x))
+            else:
+                main.wait_stream(side)    # gradients are accumulated into existing .grad tensors on main right after this
         grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, db1,
                  dwi, dbi, dwo2, dbo2, dg2, db2)
         grads = tuple(gr if p.requires_grad else None for gr, p in zip(grads, ctx.params))
@@ -471,6 +476,7 @@ class LayoutLMv3Model(nn.Module):
         self.weight_cache = WeightCache()
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
+        self.defer_wgrad_join = os.environ.get("PENEO_DEFER_JOIN", "1") != "0"
         # one grouped launch (peneo_gemm_group) for three of a layer's four wgrads: 2x faster alone (97 vs 190 us for all four),
         # but in the step the long full-K workgroups crowd the critical path: enc. backward 7.9 vs 7.6 ms -> off by default
         self.wgrad_group = os.environ.get("PENEO_WGRAD_GROUP", "0") != "0"

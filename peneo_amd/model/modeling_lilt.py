@@ -16,6 +16,7 @@ matrices; here both streams share one mask.
 from __future__ import annotations
 
 import math
+import os
 from typing import List
 
 import torch
@@ -25,6 +26,7 @@ from .. import ops
 from ..hip import ACT_GELU, PeneoHipError
 from .configuration_peneo import LiltConfig
 from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
+from .engine import defer_join, join_pending
 from .engine import side_stream as engine_side_stream
 
 
@@ -214,6 +216,7 @@ class _LiltEmbedStage(torch.autograd.Function):
         d_sp = ops.gemm(d_l0, wc.cast("boxlin", lin_w, dt), b_kmajor=False)
         ops.embed_bwd(d_sp, B, S, H, bbox=bbox, g_x=g[id(xw)], g_y=g[id(yw)], g_h=g[id(hw)], g_w=g[id(ww)], clip_hw=False,
                       pad_id=cfg.pad_token_id)
+        join_pending()     # weight-gradient work the layer stages left on the side stream
         grads = tuple(g[id(p)] if p.requires_grad else None for p in ctx.params)
         return (None, None, None, None) + grads
 
@@ -275,7 +278,10 @@ class _LiltLayerStage(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = model.side_stream(dev)
 
+        kept = []        # closures of the side-stream work: they hold the operand tensors until the (deferred) join
+
         def on_side(fn):
+            kept.append(fn)
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(side):
@@ -301,7 +307,10 @@ class _LiltLayerStage(torch.autograd.Function):
         dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_x_res)
         d_l = ops.gemm(dlqkv, Wlqkv, b_kmajor=False, residual=d_l_res)
-        main.wait_stream(side)
+        if os.environ.get("PENEO_DEFER_JOIN", "1") != "0" and all(p.grad is None for p in ctx.params):
+            defer_join(side, keep=kept)   # joined one stage later: the critical path does not wait for the QKV wgrads (engine.py)
+        else:
+            main.wait_stream(side)
         grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:],
                  dwlqkv[:Hl], dblqkv[:Hl], dwlqkv[Hl:2 * Hl], dblqkv[Hl:2 * Hl], dwlqkv[2 * Hl:], dblqkv[2 * Hl:]) + gt + gl
         grads = tuple(gr if p.requires_grad else None for gr, p in zip(grads, ctx.params))

@@ -119,6 +119,7 @@ class FlatGradDataParallel(torch.nn.Module):
         return grad
 
     def _pack(self, lo: int, hi: int) -> None:
+        _join_side_streams()                        # gradients may still be in flight on the model's side streams
         have = [(p, v) for p, v in zip(self.params[lo:hi], self.views[lo:hi]) if p.grad is not None]
         for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
@@ -161,6 +162,15 @@ class FlatGradDataParallel(torch.nn.Module):
         for p, v in zip(self.params, self.views):
             if p.grad is None:                       # unused on this rank, used elsewhere
                 p.grad = v.to(torch.float32)
+
+
+def _join_side_streams() -> None:
+    try:
+        from .model.engine import join_pending
+    except Exception:
+        return
+    if torch.cuda.is_available():
+        join_pending()
 
 
 def _invalidate_working_weights() -> None:
