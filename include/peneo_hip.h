@@ -334,6 +334,29 @@ int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int
                         void* x_out /* optional [npairs, D]: what peneo_pair_x_fwd would write */,
                         void* pre_out /* given together with x_out */, peneo_stream_t stream);
 
+/* Decoder backward through the pair space in ONE kernel (bf16; D / 16 in {2, 4, 8, 24}): for all pairs (i, j), i <= j, of
+ * all B documents it rebuilds x = SiLU(a_i + b_j) in registers, computes z = x W1cat^T + b1 and dz (as peneo_pair_dz_fused),
+ * du = dz W1cat on the matrix cores with the accumulator kept in registers over all hidden units, and
+ *   d_ab[b, i, :D] = sum_j du * SiLU'(a_i + b_j),  d_ab[b, j, D:] = sum_i du * SiLU'(a_i + b_j)   (fp32, overwritten; per-block
+ *   partial rows + one reduction launch, no atomics),
+ * plus the dW2 / db1 column sums into `workspace` (layout of peneo_pair_dz, first 256 rows).  It leaves dz [B * rows, nh*D]
+ * and x [B * rows, D] (bf16) for the one remaining GEMM dW1cat = dz^T x.  rows = peneo_pair_bwd_rows(N): the pairs are
+ * walked in blocks of 8 rows i x 16 columns j of the triangle (blocks on the diagonal / the last row of blocks carry
+ * pairs outside it: their dz rows are zero, their x rows finite), both buffers in that block order.
+ * args->dlogits[h] is the whole [B, P, classes[h]] map, args->scale the device vector of peneo_loss_finish.
+ * Replaces, per document, peneo_pair_x_fwd + peneo_pair_dz_fused + the du GEMM (grad_src epilogue) + peneo_pair_x_bwd:
+ * the autograd graph through model/peneo_decoder.py:149-177 and :231-292 except the first-layer weight gradient.
+ * `w_packed`: peneo_pair_bwd_pack (per 32-unit slab the B-operand fragments of both products). */
+int peneo_pair_bwd_supported(int dtype, int D);
+int64_t peneo_pair_bwd_rows(int N);
+size_t peneo_pair_bwd_packed_bytes(int num_heads, int D);
+int peneo_pair_bwd_pack(const float* const* w1 /* host array of num_heads device pointers to [D, D] fp32 */, int num_heads, int D,
+                        void* packed, peneo_stream_t stream);
+size_t peneo_pair_bwd_partial_bytes(int B, int N, int D);   /* `partials`: per-block partial rows of d_a / d_b (scratch) */
+int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int D, const void* w_packed, const float* b1,
+                         const peneo_pair_dz_args* args, void* dz, void* x, float* d_ab, float* workspace,
+                         float* partials, peneo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K13 — loss finish: reduces the per-workgroup partial rows of peneo_pair_heads_fwd:
  *   loss_h = num_h / den_h ; total = sum_h ratio_h * loss_h ; scale_h = ratio_h / den_h (the factor the

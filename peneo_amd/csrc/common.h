@@ -215,6 +215,26 @@ __device__ __forceinline__ void lds_dma_1k(const char* gsrc_lane, uint32_t lds_b
                : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_base_uniform), "n"(OFF) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// UPW consecutive 1 KiB pieces (this wave's share of a weight slab).  Hidden in asm, the DMA is ours to order: counted
+// s_waitcnt vmcnt + s_barrier before the slab is read (cdna guide §5.7).
+template <int U, int UPW>
+__device__ __forceinline__ void lds_dma_units(const char* gsrc_lane, uint32_t lds_base_uniform) {
+  if constexpr (U < UPW) {
+    lds_dma_1k<(U % 4) * 1024>(gsrc_lane + (U / 4) * 4096, lds_base_uniform + (U / 4) * 4096);
+    lds_dma_units<U + 1, UPW>(gsrc_lane, lds_base_uniform);
+  }
+}
+
+// fragment `frag_index` of a buffer in MFMA fragment order (64 lanes x 8 elements per fragment)
+template <typename T> struct FragBytes { static constexpr int v = 8 * (int)sizeof(T); };  // per lane per fragment
+template <typename T>
+__device__ __forceinline__ Frag<T> load_frag_linear(const char* base, int frag_index, int lane) {
+  Frag<T> f;
+  const char* p = base + ((int64_t)frag_index * 64 + lane) * FragBytes<T>::v;
+  if constexpr (sizeof(T) == 2) f.v = *reinterpret_cast<const uint4*>(p);
+  else { f.v[0] = *reinterpret_cast<const uint4*>(p); f.v[1] = *reinterpret_cast<const uint4*>(p + 16); }
+  return f;
+}
 
 // ---------------------------------------------------------------- packed upper-triangular pair index
 // p(i, j) = i*n - i(i-1)/2 + (j - i),  0 <= i <= j < n   (reference: model/peneo_decoder.py:129-147)

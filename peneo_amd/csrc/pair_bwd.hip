@@ -1,0 +1,1083 @@
+// Decoder backward through the pair space in ONE kernel (bf16): for every token pair (i, j), i <= j, of every document
+//
+//   x   = SiLU(a_i + b_j)                                   rebuilt in registers (MFMA operand fragments)
+//   z   = x W1cat^T + b1                                    matrix cores, accumulator = z[pair, hidden]
+//   dz  = (sum_c scale_h dlogits_h[p, c] W2_h[c, :]) * SiLU'(z)        -> written once ([rows, nh*D] bf16, for dW1 = dz^T x)
+//   du  = dz W1cat                                          matrix cores again, accumulated over all hidden slabs in registers
+//   d_a[i] += sum_j du * SiLU'(a_i + b_j),  d_b[j] += sum_i du * SiLU'(a_i + b_j)
+//   dW2 / db1 column sums                                   (as peneo_pair_dz_fused)
+//
+// i.e. the autograd graph through model/peneo_decoder.py:149-177 (HandshakingKernel) and :231-292 (the five classifier
+// heads) except the weight gradient of the first layers, which stays a GEMM over the dz / x this kernel leaves behind.
+// Against the kernel chain it replaces (peneo_pair_x_fwd, peneo_pair_dz_fused, the du GEMM with its SiLU' epilogue,
+// peneo_pair_x_bwd) dz is read back from HBM once instead of twice, and neither a_i + b_j nor du ever go through memory.
+//
+// Work unit: one workgroup (4 waves, one per SIMD: the kernel lives on ~450 registers per lane, mostly the 32 x D du
+// accumulator of each wave) owns a block of 8 rows i x 16 columns j of the pair triangle, wave w the rows 2w, 2w+1.  With
+// pairs blocked in 2-D the sums over j (d_a) stay inside a wave and the sums over i (d_b) need 8x fewer atomics than a
+// row-major walk of the triangle.  dz and x are written in this block order ("rows" below); the dW1 GEMM only needs both
+// in the SAME order.  Pairs of a block outside the triangle (i > j, or beyond N) carry dlogits = 0: their dz rows are 0.
+//
+// Weights: per 32-column slab of hidden units 2*KS fragments of 1 KiB (KS = D / 16), packed by peneo_pair_bwd_pack:
+//   fragment ks < KS          : W1cat[slab*32 + (lane&31)][16 ks + 8 (lane>>5) + e]          B operand of z   (k = decoder dim)
+//   fragment KS + 2 dt + kk   : W1cat[slab*32 + 16 kk + 8 (lane>>5) + e][32 dt + (lane&31)]  B operand of du  (k = hidden unit)
+// streamed L2 -> LDS by LDS-DMA, each half through its own two-slot ring (the du half of slab s is loaded one iteration
+// after the z half, it is needed one phase later).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace peneo {
+
+constexpr int PB_WAVES = 4;
+constexpr int PB_TI = 8, PB_TJ = 16;               // rows i / columns j of the pair triangle per workgroup
+constexpr int PB_ROWS = PB_TI * PB_TJ;              // 128 pairs per workgroup, 32 per wave
+constexpr int PB_SLOTS = 256;                       // rows of the dW2 / db1 workspace the atomics are spread over
+
+__host__ __device__ inline int pb_row_tiles(int N) { return (N + PB_TI - 1) / PB_TI; }
+__host__ __device__ inline int pb_col_tiles(int N) { return (N + PB_TJ - 1) / PB_TJ; }
+// blocks of row-tile ti: tj = first(ti) .. pb_col_tiles - 1, first(ti) = 8 ti / 16
+__host__ __device__ inline int pb_tiles_before(int ti, int N) {
+  const int m = ti >> 1;
+  return ti * pb_col_tiles(N) - (m * (m - 1) + ((ti & 1) ? m : 0));
+}
+__host__ __device__ inline int pb_num_tiles(int N) { return pb_tiles_before(pb_row_tiles(N), N); }
+
+struct PackBwdSrc { const float* w1[PENEO_MAX_HEADS]; int num_heads; int D; };
+
+__global__ void pack_bwd_weights_kernel(PackBwdSrc s, bf16_t* out) {
+  const int D = s.D, KS = D / 16;
+  const int nslab = s.num_heads * D / 32;
+  const int64_t stride = (int64_t)2 * KS * 512;     // elements per slab
+  const int64_t total = (int64_t)nslab * stride;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int slab = (int)(q / stride);
+    const int64_t i = q % stride;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), f = (int)(i >> 9);
+    int row, col;                                   // element of W1cat [nh*D, D]
+    if (f < KS) { row = slab * 32 + (lane & 31); col = 16 * f + 8 * (lane >> 5) + e; }
+    else { const int g = f - KS, dt = g >> 1, kk = g & 1; row = slab * 32 + 16 * kk + 8 * (lane >> 5) + e; col = 32 * dt + (lane & 31); }
+    const int h = row / D;
+    out[q] = f32_to_bf16(s.w1[h][(int64_t)(row - h * D) * D + col]);
+  }
+}
+
+struct PairBwdParams {
+  const bf16_t* ab; int B, N, D; int64_t P;
+  const void* wp; const float* b1;
+  peneo_pair_dz_args a;          // dlogits[h]: [B, P, classes[h]] of the whole batch
+  bf16_t* dz; bf16_t* x;         // [B][ntiles * 128][nh*D] / [.. ][D]
+  float* part_a; float* part_b;  // per-block partial sums [B][ntiles][8][D] / [B][ntiles][16][D] fp32
+  float* ws;                     // [PB_SLOTS][4 * nh*D]
+  int ntiles;
+};
+
+// hand-issued fragment reads (the compiler would wait for every ds_read right in front of its MFMA: with one wave per SIMD
+// nothing else covers that latency).  The reader owns lgkmcnt: pb_lgkm0 waits and ties the fragment registers to the wait.
+typedef __attribute__((ext_vector_type(4))) unsigned int pb_u32x4;
+__device__ __forceinline__ void lds_dma_piece(const char* gsrc_lane, uint32_t lds_base_uniform) { lds_dma_1k<0>(gsrc_lane, lds_base_uniform); }
+template <int OFF> __device__ __forceinline__ void pb_dsr(pb_u32x4& d, uint32_t a) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+}
+__device__ __forceinline__ void pb_mma(const pb_u32x4& a, const pb_u32x4& b, f32x16_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void pb_mma(const Frag<bf16_t>& a, const pb_u32x4& b, f32x16_t& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+// fragments per chunk: a slab's KS fragments are dealt to 8 chunks, fragment f goes to chunk f * 8 / KS
+template <int KS> constexpr int pb_chunk_count(int j) { int n = 0; for (int f = 0; f < KS; ++f) n += (f * 8 / KS == j) ? 1 : 0; return n; }
+template <int KS> constexpr int pb_chunk_first(int j) { for (int f = 0; f < KS; ++f) if (f * 8 / KS == j) return f; return KS; }
+constexpr int PB_MAXC = 3;   // fragments per chunk (KS = 24)
+
+#ifndef PB_DBG
+#define PB_DBG 0      // race hunting (tools/): 1 __syncthreads instead of the raw barrier, 2 second barrier per iteration, 4 all DMA by waves 0-3
+#endif
+#ifndef PB_OPT
+#define PB_OPT 1      // 1: tile store behind the chunk's wait, 2: LDS-DMA pieces spread over the chunks (measured slower; and racy)
+#endif
+#ifndef PB_ABLATE
+#define PB_ABLATE 0   // timing experiments (tools/): 1 no dz stores, 2 no du MFMAs, 4 no z MFMAs, 8 no epilogue, 16 no du-half DMA, 32 no DMA (ws kernel)
+#endif
+
+template <int KS, bool PIPE>
+__global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBwdParams p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF_BYTES = KS * 1024;              // z fragments of a slab (= du fragments of a slab)
+  constexpr int PW = KS / PB_WAVES >= 1 ? KS / PB_WAVES : 1;   // 1 KiB DMA pieces per wave per half slab
+  constexpr int DMA_WAVES = KS >= PB_WAVES ? PB_WAVES : KS;    // tiny D: fewer waves carry the stream
+  static_assert(KS % 2 == 0 && (KS >= PB_WAVES ? KS % PB_WAVES == 0 : true), "unsupported decoder width");
+  constexpr int NDT = KS / 2;                        // 32-column tiles of the decoder dim
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
+  char* sA = smem;                                                          // [2][HALF_BYTES] z operands
+  char* sB = smem + 2 * HALF_BYTES;                                         // [2][HALF_BYTES] du operands
+  float4* sCol = reinterpret_cast<float4*>(smem + 4 * HALF_BYTES);          // [ncol]: W2 rows 0..2 of the column, b1
+  float4* sG = sCol + ncol;                                                 // [PB_WAVES][32]
+  float4* sPart = sG + PB_WAVES * 32;                                       // [2][PB_WAVES][32]
+  char* sT = reinterpret_cast<char*>(sPart + 2 * PB_WAVES * 32);            // [PB_WAVES][32 rows][64 B] dz tiles (bf16, swizzled)
+
+  // ---- which block of the triangle ----
+  int ti = 0;
+  {
+    const int nti = pb_row_tiles(N);
+    while (ti + 1 < nti && pb_tiles_before(ti + 1, N) <= (int)blockIdx.x) ++ti;
+  }
+  const int tj = (ti >> 1) + ((int)blockIdx.x - pb_tiles_before(ti, N));
+  const int b = blockIdx.y;
+  const int i0 = ti * PB_TI + 2 * wave, j0 = tj * PB_TJ;
+  const int pi = i0 + (r32 >> 4), pj = j0 + (r32 & 15);
+  const bool pair_ok = pi < N && pj < N && pi <= pj;
+  const int ci = min(pi, N - 1), cj = min(pj, N - 1);
+  const int64_t mypair = pair_row_start(ci, N) + (cj - ci);                 // only used when pair_ok
+  const int64_t rows_per_doc = (int64_t)p.ntiles * PB_ROWS;
+  const int64_t row = (int64_t)b * rows_per_doc + (int64_t)blockIdx.x * PB_ROWS + wave * 32 + r32;
+  const int nslab = ncol / 32, spb = D / 32;
+
+  for (int n = tid; n < ncol; n += PB_WAVES * 64) {
+    const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
+    sCol[n] = make_float4(p.a.w2[h][k], Cn > 1 ? p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? p.a.w2[h][(int64_t)2 * D + k] : 0.f,
+                          p.b1[n]);
+  }
+
+  // ---- x = SiLU(a_i + b_j) as operand fragments (row = pair, k = decoder dim); also what the dW1 GEMM reads ----
+  const T* abd = p.ab + (int64_t)b * N * 2 * D;
+  const T* arow = abd + (int64_t)ci * 2 * D;
+  const T* brow = abd + (int64_t)cj * 2 * D + D;
+  T* x_row = p.x + row * D + 8 * half;
+  Frag<T> xf[KS];
+  {
+    constexpr int G = KS % 4 == 0 ? 4 : 2;
+    uint4 ra[2][G], rb[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
+      rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
+    }
+#pragma unroll
+    for (int g = 0; g < KS / G; ++g) {
+      if (g + 1 < KS / G) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (G * (g + 1) + i) + 8 * half);
+          rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (G * (g + 1) + i) + 8 * half);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        float a[8], bb[8];
+        unpack16<T>(ra[g & 1][i], a);
+        unpack16<T>(rb[g & 1][i], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+        xf[G * g + i] = pack_frag8<T>(a);
+        asm volatile("" : "+v"(xf[G * g + i].v.x), "+v"(xf[G * g + i].v.y), "+v"(xf[G * g + i].v.z), "+v"(xf[G * g + i].v.w) :: "memory");
+        *reinterpret_cast<uint4*>(x_row + 16 * (G * g + i)) = xf[G * g + i].v;
+      }
+    }
+  }
+  __syncthreads();                                          // sCol visible
+
+  // ---- weight stream ----
+  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (PW * 1024) + lane * 16;
+  const uint32_t adst = lds_addr(sA) + wave * (PW * 1024), bdst = lds_addr(sB) + wave * (PW * 1024);
+  auto dma_z = [&](int s) {    // z fragments of slab s -> sA[s & 1]
+    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (2 * HALF_BYTES), __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES));
+  };
+  auto dma_u = [&](int s) {    // du fragments of slab s -> sB[s & 1]
+    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (2 * HALF_BYTES) + HALF_BYTES, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES));
+  };
+
+  float* slot = p.ws + (int64_t)(blockIdx.x % PB_SLOTS) * 4 * ncol;
+  auto flush = [&](int s) {    // the wave that owns slab s adds the four waves' column sums of that slab to the workspace
+    if (wave == (s & (PB_WAVES - 1)) && lane < 32) {
+      const float4* src = sPart + (s & 1) * (PB_WAVES * 32) + lane;
+      float4 t = src[0];
+#pragma unroll
+      for (int w = 1; w < PB_WAVES; ++w) { const float4 u = src[w * 32]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      float* dst = slot + s * 32 + lane;
+      atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
+    }
+  };
+  auto stage_g = [&](int h) {  // scale_h * dlogits_h of the wave's 32 pairs -> LDS, two adjacent pairs interleaved
+    const int Cn = p.a.classes[h];
+    if (lane < 32) {
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+      if (pair_ok) {
+        const float sc = p.a.scale[h];
+        const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
+        gx = dl[0] * sc;
+        if (Cn > 1) gy = dl[1] * sc;
+        if (Cn > 2) gz = dl[2] * sc;
+      }
+      float* gp = reinterpret_cast<float*>(sG + wave * 32) + (lane >> 1) * 8 + (lane & 1);
+      gp[0] = gx; gp[2] = gy; gp[4] = gz;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 one2 = f2{1.f, 1.f}, nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
+  const float4* myG = sG + wave * 32;
+  char* myT = sT + wave * 2048;
+  const bool odd = (lane & 1) != 0;
+  // dz tile in LDS: row r (pair) = 64 bytes = four 16-byte chunks, chunk q stored at q ^ ((r >> 2) & 3)
+  const uint32_t t_read = lds_addr(myT) + r32 * 64;
+  const int t_swz = (r32 >> 2) & 3;
+  T* dz_row = p.dz + row * ncol + 8 * half;                 // + slab * 32 + 16 kk
+
+  f32x16_t du[NDT];
+#pragma unroll
+  for (int t = 0; t < NDT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
+  f32x16_t zp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zp[r] = 0.f;
+
+  // phase Z(s): z of slab s on the matrix cores;  phase E(s): z -> dz, column sums, dz -> LDS tile;
+  // phase U(s): dz tile -> A fragments -> HBM, du += dz W1 (slab s)
+  auto phase_ze = [&](auto mma_c, auto epi_c, int s) {
+    constexpr bool MMA = decltype(mma_c)::value, EPI = decltype(epi_c)::value;
+    const char* wb = sA + (s & 1) * HALF_BYTES;
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    const int es = MMA ? s - 1 : s;                          // slab whose z sits in zp
+    float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI) cw = sCol[es * 32 + r32];
+    const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
+    f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (MMA) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          if (ks * 8 / KS == j) {
+            Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
+            if constexpr (PB_ABLATE & 4) z[ks & 15] += __uint_as_float(wf.v.x);
+            else mma_step(xf[ks], wf, z);                    // rows = pairs, columns = hidden units
+          }
+      }
+      if constexpr (EPI) {
+        const int r0 = 2 * j, rowc = (r0 & 3) + 8 * (r0 >> 2);   // accumulator registers 2j, 2j+1: pair rows rowc + 4*half + {0, 1}
+        const int row0 = rowc + 4 * half;
+        const float4 g01 = myG[row0];
+        const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
+        const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
+        const f2 zz = f2{zp[r0], zp[r0 + 1]} + b1;
+        const f2 t = zz * nl2e;
+        const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+        const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f2 y = zz * sg;
+        const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
+        const f2 dzv = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
+        s0 = __builtin_elementwise_fma(g0, y, s0);
+        s1 = __builtin_elementwise_fma(g1, y, s1);
+        s2 = __builtin_elementwise_fma(g2, y, s2);
+        sb = sb + dzv;
+        // even lanes keep columns (c, c+1) of pair row row0, odd lanes columns (c-1, c) of row0 + 1
+        const float give = odd ? dzv.x : dzv.y;
+        const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
+        const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
+        const int trow = row0 + (lane & 1);
+        const int boff = (r32 & ~1) * 2;                     // byte offset of the column pair inside the 64-byte row
+        const int f = ((rowc >> 2) + half) & 3;              // (trow >> 2) & 3 (rowc & 3 is 0 or 2: no carry from 4*half + odd)
+        *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
+      }
+    }
+    if constexpr (EPI) {
+      float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
+      part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
+      part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
+      if (lane < 32) sPart[(es & 1) * (PB_WAVES * 32) + wave * 32 + lane] = part;
+    }
+    if constexpr (MMA) zp = z;
+  };
+  auto phase_u = [&](int s) {
+    // the tile was written by this wave only: order its writes before its reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    Frag<T> a0, a1;
+    a0.v = *reinterpret_cast<const uint4*>(myT + r32 * 64 + (((0 + half) ^ t_swz) << 4));
+    a1.v = *reinterpret_cast<const uint4*>(myT + r32 * 64 + (((2 + half) ^ t_swz) << 4));
+    if constexpr (!(PB_ABLATE & 1)) {
+      *reinterpret_cast<uint4*>(dz_row + s * 32) = a0.v;
+      *reinterpret_cast<uint4*>(dz_row + s * 32 + 16) = a1.v;
+    }
+    if constexpr (!(PB_ABLATE & 2)) {
+      const char* ub = sB + (s & 1) * HALF_BYTES;
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) {
+        Frag<T> w0 = load_frag_linear<T>(ub, 2 * t, lane), w1 = load_frag_linear<T>(ub, 2 * t + 1, lane);
+        mma_step(a0, w0, du[t]);
+        mma_step(a1, w1, du[t]);
+      }
+    } else {
+      du[0][0] += __uint_as_float(a0.v.x) + __uint_as_float(a1.v.y);
+    }
+    // the next E phase overwrites the tile: its reads above must have completed (they have: the MFMAs consumed them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  (void)t_read;
+
+  if constexpr (!PIPE) {
+    dma_z(0);
+    for (int s = 0; s < nslab; ++s) {
+      // z fragments of slab s (issued one iteration ago) have landed; every wave is done with the slots the next DMAs overwrite
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nslab) dma_z(s + 1);
+      dma_u(s);
+      if (s > 0) flush(s - 1);
+      if (s % spb == 0) stage_g(s / spb);
+      phase_ze(yes{}, no{}, s);
+      phase_ze(no{}, yes{}, s);
+      // du fragments of slab s: issued just above, needed now -> wait for them (all waves' pieces)
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      phase_u(s);
+    }
+  } else {
+    // Three slabs in flight per iteration s (one wave per SIMD: the overlap has to be built into the instruction stream):
+    //   Z(s+1)  first-layer MFMAs of slab s+1                       (fragments: sA[(s+1) & 1])
+    //   E(s)    z of slab s -> dz (VALU), column sums, dz -> LDS tile
+    //   U(s-1)  du += dz(s-1) W1(s-1)                               (fragments: sB[(s-1) & 1]; A operand read from the tile
+    //                                                                 at the top of the iteration, before E(s) rewrites it)
+    // in 8 chunks: [MFMAs of chunk j] [issue the fragment reads of chunk j+1] [dz arithmetic of rows 2j, 2j+1] [wait].
+    // DMA: z fragments of slab s+2 and du fragments of slab s are issued at the top of iteration s; both have a whole
+    // iteration to land.
+    const uint32_t fbase = lds_addr(sA) + lane * 16;                 // sB = sA + 2 * HALF_BYTES
+    // the 2 * PW pieces a wave contributes per iteration (z fragments of slab s+2, du fragments of slab s), dealt to the
+    // 8 chunks: piece q goes to chunk q * 8 / (2 PW)
+    auto dma_chunk = [&](auto jc, int s) {
+      constexpr int J = decltype(jc)::value;
+      if (wave < DMA_WAVES) {
+#pragma unroll
+        for (int q = 0; q < 2 * PW; ++q) {
+          if (q * 8 / (2 * PW) != J) continue;
+          if (q < PW) {
+            if (s >= 0 && s + 2 < nslab)
+              lds_dma_piece(wsrc + (int64_t)(s + 2) * (2 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES + q * 1024));
+          } else {
+            if (s >= 0 && s < nslab)
+              lds_dma_piece(wsrc + (int64_t)s * (2 * HALF_BYTES) + HALF_BYTES + (q - PW) * 1024, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES + (q - PW) * 1024));
+          }
+        }
+      }
+    };
+    auto iteration = [&](auto z_c, auto e_c, auto u_c, int s) {
+      constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value, DOU = decltype(u_c)::value;
+      const uint32_t za = fbase + ((s + 1) & 1) * HALF_BYTES;
+      const uint32_t ua = fbase + (2 + ((s - 1) & 1)) * HALF_BYTES;
+      pb_u32x4 a0 = pb_u32x4{0u, 0u, 0u, 0u}, a1 = a0;
+      if constexpr (DOU) {
+        const uint32_t ta = lds_addr(myT) + r32 * 64;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(ta + (((0 + half) ^ t_swz) << 4)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(ta + (((2 + half) ^ t_swz) << 4)));
+      }
+      // ONE register set for the fragments: the reads of chunk j+1 are issued behind the MFMAs of chunk j, which have read
+      // their operands long before the LDS data returns
+      pb_u32x4 fz[PB_MAXC], fu[PB_MAXC];
+#pragma unroll
+      for (int i = 0; i < PB_MAXC; ++i) { fz[i] = pb_u32x4{0u, 0u, 0u, 0u}; fu[i] = fz[i]; }
+      auto issue = [&](auto jc, pb_u32x4 (&dz_)[PB_MAXC], pb_u32x4 (&du_)[PB_MAXC]) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+        static_assert(C <= PB_MAXC, "chunk too large");
+        if constexpr (DOZ) {
+          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(dz_[0], za);
+          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(dz_[1], za);
+          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(dz_[2], za);
+        }
+        if constexpr (DOU) {
+          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(du_[0], ua);
+          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(du_[1], ua);
+          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(du_[2], ua);
+        }
+      };
+      auto landed = [&](pb_u32x4 (&dz_)[PB_MAXC], pb_u32x4 (&du_)[PB_MAXC]) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dz_[0]), "+v"(dz_[1]), "+v"(dz_[2]), "+v"(du_[0]), "+v"(du_[1]), "+v"(du_[2]), "+v"(a0), "+v"(a1) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      issue(std::integral_constant<int, 0>{}, fz, fu);
+      landed(fz, fu);
+      if constexpr (DOU && !(PB_ABLATE & 1)) {
+        *reinterpret_cast<pb_u32x4*>(dz_row + (s - 1) * 32) = a0;
+        *reinterpret_cast<pb_u32x4*>(dz_row + (s - 1) * 32 + 16) = a1;
+      }
+      f32x16_t z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      asm volatile("" : "+a"(z));      // opaque zero (see the wave-specialised kernel): no destination / operand overlap
+      float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (DOE) cw = sCol[s * 32 + r32];
+      const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
+      f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
+      auto chunk = [&](auto jc, pb_u32x4 (&cz)[PB_MAXC], pb_u32x4 (&cu)[PB_MAXC], pb_u32x4 (&xz)[PB_MAXC], pb_u32x4 (&xu)[PB_MAXC]) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+        uint32_t packed_out = 0;
+        // (a) the MFMAs of this chunk: their fragments landed at the end of the previous chunk
+        if constexpr (DOZ && !(PB_ABLATE & 4)) {
+          if constexpr (C > 0) pb_mma(xf[F0 + 0], cz[0], z);
+          if constexpr (C > 1) pb_mma(xf[F0 + 1], cz[1], z);
+          if constexpr (C > 2) pb_mma(xf[F0 + 2], cz[2], z);
+        }
+        if constexpr (DOU && !(PB_ABLATE & 2)) {
+          // fragment f = 2 t + kk: tile t of the decoder dim, k half kk <-> a0 / a1
+          if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, cu[0], du[(F0 + 0) >> 1]);
+          if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, cu[1], du[(F0 + 1) >> 1]);
+          if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, cu[2], du[(F0 + 2) >> 1]);
+        }
+        // (b) this chunk's share of the weight stream (an LDS-DMA piece costs 60-180 cycles of issue: in the shadow of the
+        //     MFMAs, not in a block behind the barrier), then the fragment reads of the next chunk
+        if constexpr (PB_OPT & 2) dma_chunk(std::integral_constant<int, J>{}, s);
+        if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{}, xz, xu);
+        // (c) dz arithmetic of accumulator registers 2J, 2J+1 in the shadow of the MFMAs
+        if constexpr (DOE) {
+          constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
+          const int row0 = rowc + 4 * half;
+          const float4 g01 = myG[row0];
+          const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
+          const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
+          const f2 zz = f2{zp[r0], zp[r0 + 1]} + b1;
+          const f2 t = zz * nl2e;
+          const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+          const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+          const f2 y = zz * sg;
+          const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
+          const f2 dzv = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
+          s0 = __builtin_elementwise_fma(g0, y, s0);
+          s1 = __builtin_elementwise_fma(g1, y, s1);
+          s2 = __builtin_elementwise_fma(g2, y, s2);
+          sb = sb + dzv;
+          const float give = odd ? dzv.x : dzv.y;
+          const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
+          const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
+          packed_out = packed;
+          if constexpr (!(PB_OPT & 1)) {
+            const int trow = rowc + 4 * half + (lane & 1);
+            const int boff = (r32 & ~1) * 2;
+            const int f = ((rowc >> 2) + half) & 3;
+            *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed_out;
+          }
+        }
+        // (d) everything this chunk put on the LDS queue so far is done (the next chunk's fragments among it); the tile
+        // store goes out BEHIND the wait: its round trip is covered by the next chunk instead of being waited for here
+        if constexpr (J + 1 < 8) landed(xz, xu);
+        if constexpr (DOE && (PB_OPT & 1)) {
+          constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
+          const int trow = rowc + 4 * half + (lane & 1);
+          const int boff = (r32 & ~1) * 2;
+          const int f = ((rowc >> 2) + half) & 3;
+          *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed_out;
+        }
+      };
+      chunk(std::integral_constant<int, 0>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 1>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 2>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 3>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 4>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 5>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 6>{}, fz, fu, fz, fu);
+      chunk(std::integral_constant<int, 7>{}, fz, fu, fz, fu);
+      if constexpr (DOE) {
+        float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
+        part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
+        part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
+        if (lane < 32) sPart[(s & 1) * (PB_WAVES * 32) + wave * 32 + lane] = part;
+      }
+      if constexpr (DOZ) zp = z;
+    };
+    auto top = [&](int s) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // column sums are flushed by another wave
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(PB_OPT & 2)) {
+        if (s >= 0 && s + 2 < nslab) dma_z(s + 2);
+        if (s >= 0 && s < nslab) dma_u(s);
+      }
+      if (s >= 1) flush(s - 1);                               // column sums of E(s-1), written before this barrier
+      if (s >= 0 && s < nslab && s % spb == 0) stage_g(s / spb);
+    };
+    // prologue / steady state / epilogue as separate code (nslab >= 2 is checked by the launcher): inside one loop the five
+    // flavours of the iteration made the register allocator spill
+    dma_z(0);
+    dma_z(1);
+    top(-1); iteration(yes{}, no{}, no{}, -1);
+    top(0); iteration(yes{}, yes{}, no{}, 0);
+    // the du accumulators stay in the accumulator half of the register file across the loop (without the pin the
+    // allocator parked them in arch VGPRs at the back edge: 192 v_accvgpr moves per iteration)
+    auto pin_du = [&]() {
+#pragma unroll
+      for (int t = 0; t < NDT; ++t) asm volatile("" : "+a"(du[t]));
+    };
+    pin_du();
+    for (int s = 1; s + 1 < nslab; ++s) { top(s); iteration(yes{}, yes{}, yes{}, s); pin_du(); }
+    top(nslab - 1);
+    if (nslab > 1) iteration(no{}, yes{}, yes{}, nslab - 1);
+    top(nslab); iteration(no{}, no{}, yes{}, nslab);
+  }
+  __syncthreads();
+  if constexpr (!PIPE) flush(nslab - 1);
+
+  // ---- du * SiLU'(a_i + b_j), summed over j into d_a[i] and over i into d_b[j] ----
+  // accumulator register r of lane (c, half) of tile t: pair row rho = (r&3) + 8 (r>>2) + 4 half, decoder column 32 t + c;
+  // i = i0 + (r >> 3), j = j0 + 8 ((r >> 2) & 1) + 4 half + (r & 3).  The sums over j stay inside the wave (its two rows i);
+  // the sums over i meet in LDS (the weight rings are dead by now: 4 waves x [D/32][16][32] fp32 fill them exactly).  Both
+  // leave as plain per-block partial rows; pair_bwd_reduce_kernel adds the blocks of a row / column (no atomics: 108
+  // same-address-prone atomic instructions per lane cost a quarter of the kernel).
+  if constexpr (!(PB_ABLATE & 8)) {
+    float* red = reinterpret_cast<float*>(smem);                      // [PB_WAVES][NDT][16][32]
+    const int ia = min(i0, N - 1), ib = min(i0 + 1, N - 1);
+    float* pa = p.part_a + (((int64_t)b * p.ntiles + blockIdx.x) * PB_TI + 2 * wave + half) * D;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+      const int d = 32 * t + r32;
+      const float a_lo = bf16_to_f32(abd[(int64_t)ia * 2 * D + d]), a_hi = bf16_to_f32(abd[(int64_t)ib * 2 * D + d]);
+      float bj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = min(j0 + 8 * (q >> 2) + 4 * half + (q & 3), N - 1);
+        bj[q] = bf16_to_f32(abd[(int64_t)j * 2 * D + D + d]);
+      }
+      float sa0 = 0.f, sa1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v0 = du[t][q] * silu_grad_f(a_lo + bj[q]);          // i = i0     , registers 0..7
+        const float v1 = du[t][8 + q] * silu_grad_f(a_hi + bj[q]);      // i = i0 + 1 , registers 8..15
+        sa0 += v0; sa1 += v1;
+        red[((wave * NDT + t) * 16 + 8 * (q >> 2) + 4 * half + (q & 3)) * 32 + r32] = v0 + v1;
+      }
+      sa0 += __shfl_xor(sa0, 32);
+      sa1 += __shfl_xor(sa1, 32);
+      pa[d] = half ? sa1 : sa0;
+    }
+    __syncthreads();
+    float* pb = p.part_b + ((int64_t)b * p.ntiles + blockIdx.x) * PB_TJ * D;
+    for (int e = tid; e < NDT * 16 * 32; e += PB_WAVES * 64) {
+      const int c = e & 31, jl = (e >> 5) & 15, t = e >> 9;
+      float v = red[e];
+#pragma unroll
+      for (int w = 1; w < PB_WAVES; ++w) v += red[w * NDT * 512 + e];
+      pb[(int64_t)jl * D + 32 * t + c] = v;
+    }
+  }
+}
+
+// d_ab[b, i, :D] = sum over the blocks of row-tile i / 8 of part_a ; d_ab[b, j, D:] = sum over the blocks of column-tile j / 16 of part_b
+__global__ __launch_bounds__(256) void pair_bwd_reduce_kernel(const float* part_a, const float* part_b, int N, int D, int ntiles,
+                                                              float* d_ab) {
+  const int n = blockIdx.x, b = blockIdx.y;
+  const int ncolt = pb_col_tiles(N);
+  const float* pa = part_a + (int64_t)b * ntiles * PB_TI * D;
+  const float* pb = part_b + (int64_t)b * ntiles * PB_TJ * D;
+  float* out = d_ab + ((int64_t)b * N + n) * 2 * D;
+  const int ti = n / PB_TI, first = pb_tiles_before(ti, N), cnt = ncolt - (ti >> 1);
+  const int tj = n / PB_TJ, ti_max = min(pb_row_tiles(N) - 1, 2 * tj + 1);
+  for (int d = threadIdx.x; d < 2 * D; d += blockDim.x) {
+    float v = 0.f;
+    if (d < D) {
+      for (int k = 0; k < cnt; ++k) v += pa[((int64_t)(first + k) * PB_TI + (n % PB_TI)) * D + d];
+    } else {
+      for (int t = 0; t <= ti_max; ++t) {
+        const int tile = pb_tiles_before(t, N) + (tj - (t >> 1));
+        v += pb[((int64_t)tile * PB_TJ + (n % PB_TJ)) * D + (d - D)];
+      }
+    }
+    out[d] = v;
+  }
+}
+
+// ================================================================================================
+// Wave-specialised form (default): 8 waves per workgroup, two per SIMD.  Waves 0-3 ("producers", pair group w) own
+// x, z and the dz arithmetic; waves 4-7 ("consumers", pair group w - 4) own the du accumulator.  A producer hands the dz
+// tile of a slab to its consumer through a double-buffered LDS tile; the ONE workgroup barrier per slab that already
+// orders the weight ring orders that hand-off too.  With two waves on every SIMD the hardware overlaps the producer's
+// VALU-bound dz arithmetic with the consumer's MFMAs, and both roles fit 256 registers.
+//   iteration s = -1 .. nslab:   producer: Z(s+1) interleaved with E(s) -> tile[s & 1]     consumer: U(s-1) <- tile[(s-1) & 1]
+//   weight ring: z fragments of slab s+2 -> sA[s & 1], du fragments of slab s -> sB[s & 1], issued at the top of
+//   iteration s by all 8 waves (KS/4 pieces each), landed by the top of iteration s+1.
+// Two rules this kernel obeys because two waves share each SIMD's matrix pipe (both found the hard way: sporadic wrong
+// 16-byte pieces of dz that vanished as soon as the partner wave issued no MFMAs):
+//   * nothing reads an MFMA accumulator shortly after the chain that wrote it: z is double buffered (Z(s+1) writes one
+//     accumulator while E(s) reads the other, a whole barrier later), du is only read after the loop.  The wait states the
+//     compiler inserts between an MFMA and a reader assume the MFMA started when it was issued; with a partner wave's
+//     MFMAs queued in front of it, it did not.
+//   * operand fragments are re-loaded only after the NEXT chunk's MFMAs have been issued behind the ones that read them.
+// ================================================================================================
+constexpr int PW_WAVES = 8;
+
+template <int KS>
+__global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdParams p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF_BYTES = KS * 1024;
+  constexpr int NDT = KS / 2;
+  constexpr int NPIECE = 2 * KS;                             // 1 KiB pieces per iteration (both halves)
+  constexpr int PPW = (NPIECE + PW_WAVES - 1) / PW_WAVES;    // pieces per wave
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 4;
+  const int grp = wave & 3;                                  // pair group: rows 2 grp, 2 grp + 1 of the block
+  const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
+  char* sA = smem;                                                          // [2][HALF_BYTES] z operands
+  float4* sCol = reinterpret_cast<float4*>(smem + 4 * HALF_BYTES);          // [ncol]   (sB = sA + 2 * HALF_BYTES)
+  float4* sG = sCol + ncol;                                                 // [4][32]
+  float4* sPart = sG + 4 * 32;                                              // [2][4][32]
+  char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
+
+  int ti = 0;
+  {
+    const int nti = pb_row_tiles(N);
+    while (ti + 1 < nti && pb_tiles_before(ti + 1, N) <= (int)blockIdx.x) ++ti;
+  }
+  const int tj = (ti >> 1) + ((int)blockIdx.x - pb_tiles_before(ti, N));
+  const int b = blockIdx.y;
+  const int i0 = ti * PB_TI + 2 * grp, j0 = tj * PB_TJ;
+  const int pi = i0 + (r32 >> 4), pj = j0 + (r32 & 15);
+  const bool pair_ok = pi < N && pj < N && pi <= pj;
+  const int ci = min(pi, N - 1), cj = min(pj, N - 1);
+  const int64_t mypair = pair_row_start(ci, N) + (cj - ci);
+  const int64_t rows_per_doc = (int64_t)p.ntiles * PB_ROWS;
+  const int64_t row = (int64_t)b * rows_per_doc + (int64_t)blockIdx.x * PB_ROWS + grp * 32 + r32;
+  const int nslab = ncol / 32, spb = D / 32;
+  const T* abd = p.ab + (int64_t)b * N * 2 * D;
+
+  for (int n = tid; n < ncol; n += PW_WAVES * 64) {
+    const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
+    sCol[n] = make_float4(p.a.w2[h][k], Cn > 1 ? p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? p.a.w2[h][(int64_t)2 * D + k] : 0.f,
+                          p.b1[n]);
+  }
+
+  // weight stream: piece q of an iteration (q < KS: z fragments, else du fragments); wave w carries pieces w, w + 8, ...
+  const char* wbase = reinterpret_cast<const char*>(p.wp) + lane * 16;
+  const uint32_t ring = lds_addr(sA);
+  auto dma_z = [&](int slab, int q) {
+    if (!(PB_ABLATE & 32))
+      lds_dma_1k<0>(wbase + (int64_t)slab * (2 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(ring + (slab & 1) * HALF_BYTES + q * 1024));
+  };
+  auto dma_u = [&](int slab, int q) {   // q in [KS, 2 KS)
+    if (!(PB_ABLATE & 48))
+      lds_dma_1k<0>(wbase + (int64_t)slab * (2 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(ring + (2 + (slab & 1)) * HALF_BYTES + (q - KS) * 1024));
+  };
+  auto dma_iter = [&](int s) {
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int q = wave + k * PW_WAVES;
+      if (q < KS) { if (s >= 0 && s + 2 < nslab) dma_z(s + 2, q); }
+      else if (q < NPIECE) { if (s >= 0 && s < nslab) dma_u(s, q); }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < PPW; ++k) {        // z fragments of slabs 0 and 1 before the loop
+    const int q = wave + k * PW_WAVES;
+    if (q < KS) { dma_z(0, q); if (nslab > 1) dma_z(1, q); }
+  }
+
+#if !(PB_DBG & 65536)
+  // Scalar pairs, and this file is built with -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_mul / v_pk_fma / v_pk_add_f32) in
+  // this kernel.  With the partner wave's MFMAs running on the same SIMD the packed forms returned wrong low halves in lanes
+  // 48-63 (sporadic wrong 16-byte pieces of dz, gone with the partner's MFMAs removed, gone with scalar arithmetic; the
+  // one-wave-per-SIMD kernel above, where nothing shares the SIMD, is unaffected).
+  struct f2 {
+    float x, y;
+    __device__ f2 operator+(const f2& o) const { return f2{x + o.x, y + o.y}; }
+    __device__ f2 operator-(const f2& o) const { return f2{x - o.x, y - o.y}; }
+    __device__ f2 operator*(const f2& o) const { return f2{x * o.x, y * o.y}; }
+  };
+  auto fma2 = [](const f2& a, const f2& b, const f2& c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; };
+#else
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  auto fma2 = [](const f2& a, const f2& b, const f2& c) { return __builtin_elementwise_fma(a, b, c); };
+#endif
+  const uint32_t fbase = ring + lane * 16;
+  const int t_swz = (r32 >> 2) & 3;
+  // top of an iteration, both roles: everything this wave put in flight has completed (LDS-DMA pieces: vmcnt; tile /
+  // column-sum stores that OTHER waves read: lgkmcnt), then the workgroup meets
+  auto top = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (producer) {
+    // ---------------------------------------------------------------- producer: x, z, dz
+    const T* arow = abd + (int64_t)ci * 2 * D;
+    const T* brow = abd + (int64_t)cj * 2 * D + D;
+    T* x_row = p.x + row * D + 8 * half;
+    Frag<T> xf[KS];
+    {
+      constexpr int G = KS % 4 == 0 ? 4 : 2;
+      uint4 ra[2][G], rb[2][G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
+        rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
+      }
+#pragma unroll
+      for (int g = 0; g < KS / G; ++g) {
+        if (g + 1 < KS / G) {
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (G * (g + 1) + i) + 8 * half);
+            rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (G * (g + 1) + i) + 8 * half);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          float a[8], bb[8];
+          unpack16<T>(ra[g & 1][i], a);
+          unpack16<T>(rb[g & 1][i], bb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+          xf[G * g + i] = pack_frag8<T>(a);
+          asm volatile("" : "+v"(xf[G * g + i].v.x), "+v"(xf[G * g + i].v.y), "+v"(xf[G * g + i].v.z), "+v"(xf[G * g + i].v.w) :: "memory");
+          *reinterpret_cast<uint4*>(x_row + 16 * (G * g + i)) = xf[G * g + i].v;
+        }
+      }
+    }
+    float* slot = p.ws + (int64_t)(blockIdx.x % PB_SLOTS) * 4 * ncol;
+    auto flush = [&](int s) {
+      if (wave == (s & 3) && lane < 32) {
+        const float4* src = sPart + (s & 1) * (4 * 32) + lane;
+        float4 t = src[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 u = src[w * 32]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        float* dst = slot + s * 32 + lane;
+        atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
+      }
+    };
+    auto stage_g = [&](int h) {
+      const int Cn = p.a.classes[h];
+      if (lane < 32) {
+        float gx = 0.f, gy = 0.f, gz = 0.f, sc = 0.f;
+        if (pair_ok) {
+          sc = p.a.scale[h];
+          const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
+          gx = dl[0];
+          if (Cn > 1) gy = dl[1];
+          if (Cn > 2) gz = dl[2];
+        }
+        // explicit wait: the compiler's counted vmcnt does not know about the LDS-DMA pieces in flight around these loads
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(sc) :: "memory");
+        gx *= sc; gy *= sc; gz *= sc;
+        float* gp = reinterpret_cast<float*>(sG + grp * 32) + (lane >> 1) * 8 + (lane & 1);
+        gp[0] = gx; gp[2] = gy; gp[4] = gz;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    const f2 one2 = f2{1.f, 1.f}, nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
+    const float4* myG = sG + grp * 32;
+    const bool odd = (lane & 1) != 0;
+
+    // one producer iteration: Z(s+1) accumulates into zw (fragments hand-issued one chunk ahead, two register sets, each
+    // re-loaded only BEHIND the following chunk's MFMAs); E(s) reads zr (written during the previous iteration)
+    auto iteration = [&](auto z_c, auto e_c, int s, f32x16_t& zr, f32x16_t& zw) {
+      constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value;
+      const uint32_t za = fbase + ((s + 1) & 1) * HALF_BYTES;
+      char* myT = sT + ((s & 1) * 4 + grp) * 2048;
+      pb_u32x4 fa[PB_MAXC], fb[PB_MAXC];
+#pragma unroll
+      for (int i = 0; i < PB_MAXC; ++i) { fa[i] = pb_u32x4{0u, 0u, 0u, 0u}; fb[i] = fa[i]; }
+      if constexpr (DOZ) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zw[r] = 0.f;
+        asm volatile("" : "+v"(zw));   // opaque zero: a literal 0 as srcC lets the compiler overlap the chain's destination with its B operand
+      }
+      float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (DOE) cw = sCol[s * 32 + r32];
+      const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
+      f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
+      auto issue = [&](auto jc, pb_u32x4 (&d_)[PB_MAXC]) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+        static_assert(C <= PB_MAXC, "chunk too large");
+        if constexpr (DOZ) {
+          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(d_[0], za);
+          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(d_[1], za);
+          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], za);
+        }
+      };
+      auto landed = [&](pb_u32x4 (&d_)[PB_MAXC]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto chunk = [&](auto jc, pb_u32x4 (&cur)[PB_MAXC], pb_u32x4 (&nxt)[PB_MAXC]) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+        if constexpr (DOZ && !(PB_ABLATE & 4)) {
+          if constexpr (C > 0) pb_mma(xf[F0 + 0], cur[0], zw);
+          if constexpr (C > 1) pb_mma(xf[F0 + 1], cur[1], zw);
+          if constexpr (C > 2) pb_mma(xf[F0 + 2], cur[2], zw);
+        }
+        if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{}, nxt);
+        if constexpr (DOE) {
+          constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
+          const int row0 = rowc + 4 * half;
+          const float4 g01 = myG[row0];
+          const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
+          const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
+          const f2 zz = f2{zr[r0], zr[r0 + 1]} + b1;
+          const f2 t = zz * nl2e;
+          const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+          const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+          const f2 y = zz * sg;
+          const f2 dy = fma2(g2, w2, fma2(g1, w1, g0 * w0));
+          const f2 dzv = dy * (sg * fma2(zz, one2 - sg, one2));
+          s0 = fma2(g0, y, s0);
+          s1 = fma2(g1, y, s1);
+          s2 = fma2(g2, y, s2);
+          sb = sb + dzv;
+          const float give = odd ? dzv.x : dzv.y;
+          const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
+          const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
+          const int trow = row0 + (lane & 1);
+          const int boff = (r32 & ~1) * 2;
+          const int f = ((rowc >> 2) + half) & 3;
+          *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
+        }
+        if constexpr (J + 1 < 8) landed(nxt);
+      };
+      issue(std::integral_constant<int, 0>{}, fa);
+      landed(fa);
+      chunk(std::integral_constant<int, 0>{}, fa, fb);
+      chunk(std::integral_constant<int, 1>{}, fb, fa);
+      chunk(std::integral_constant<int, 2>{}, fa, fb);
+      chunk(std::integral_constant<int, 3>{}, fb, fa);
+      chunk(std::integral_constant<int, 4>{}, fa, fb);
+      chunk(std::integral_constant<int, 5>{}, fb, fa);
+      chunk(std::integral_constant<int, 6>{}, fa, fb);
+      chunk(std::integral_constant<int, 7>{}, fb, fa);
+      if constexpr (DOE) {
+        float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
+        part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
+        part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
+        if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = part;
+      }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    f32x16_t z0, z1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { z0[r] = 0.f; z1[r] = 0.f; }
+    __syncthreads();                                          // sCol visible (matches the consumers' barrier)
+    // slab s lives in z0 when s is even, in z1 when odd; nslab >= 2 (launcher)
+    top(); dma_iter(-1); iteration(yes{}, no{}, -1, z1, z0);
+    int s = 0;
+    for (; s + 2 < nslab; s += 2) {
+      top(); dma_iter(s); if (s >= 1) flush(s - 1); if (s % spb == 0) stage_g(s / spb);
+      iteration(yes{}, yes{}, s, z0, z1);
+      top(); dma_iter(s + 1); flush(s); if ((s + 1) % spb == 0) stage_g((s + 1) / spb);
+      iteration(yes{}, yes{}, s + 1, z1, z0);
+    }
+    for (; s < nslab; ++s) {                                  // the last one or two slabs: no Z(s+1) for the very last
+      top(); dma_iter(s); if (s >= 1) flush(s - 1); if (s % spb == 0) stage_g(s / spb);
+      if (s + 1 < nslab) { if (s & 1) iteration(yes{}, yes{}, s, z1, z0); else iteration(yes{}, yes{}, s, z0, z1); }
+      else { if (s & 1) iteration(no{}, yes{}, s, z1, z0); else iteration(no{}, yes{}, s, z0, z1); }
+    }
+    top(); dma_iter(nslab); flush(nslab - 1);                 // iteration nslab: the consumers' U(nslab - 1)
+    __syncthreads();     // the consumers' reduction buffer (the rings) is free
+    __syncthreads();     // ... and filled
+  } else {
+    // ---------------------------------------------------------------- consumer: du, d_a / d_b
+    f32x16_t du[NDT];
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
+    T* dz_row = p.dz + row * ncol + 8 * half;
+    __syncthreads();                                          // matches the producers' barrier
+    for (int s = -1; s <= nslab; ++s) {
+      top();
+      dma_iter(s);
+      if (s >= 1) {
+        const int u = s - 1;
+        const uint32_t ta = lds_addr(sT + ((u & 1) * 4 + grp) * 2048) + r32 * 64;
+        const uint32_t ua = fbase + (2 + (u & 1)) * HALF_BYTES;
+        pb_u32x4 a0, a1;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(ta + (((0 + half) ^ t_swz) << 4)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(ta + (((2 + half) ^ t_swz) << 4)));
+        pb_u32x4 fa[PB_MAXC], fb[PB_MAXC];
+#pragma unroll
+        for (int i = 0; i < PB_MAXC; ++i) { fa[i] = pb_u32x4{0u, 0u, 0u, 0u}; fb[i] = fa[i]; }
+        auto uissue = [&](auto jc, pb_u32x4 (&d_)[PB_MAXC]) {
+          constexpr int J = decltype(jc)::value;
+          constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(d_[0], ua);
+          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(d_[1], ua);
+          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], ua);
+        };
+        auto ulanded = [&](pb_u32x4 (&d_)[PB_MAXC]) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]), "+v"(a0), "+v"(a1) :: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto uchunk = [&](auto jc, pb_u32x4 (&cur)[PB_MAXC], pb_u32x4 (&nxt)[PB_MAXC]) {
+          constexpr int J = decltype(jc)::value;
+          constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+          if constexpr (!(PB_ABLATE & 2)) {
+            if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, cur[0], du[(F0 + 0) >> 1]);
+            if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, cur[1], du[(F0 + 1) >> 1]);
+            if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, cur[2], du[(F0 + 2) >> 1]);
+          }
+          if constexpr (J + 1 < 8) { uissue(std::integral_constant<int, J + 1>{}, nxt); ulanded(nxt); }
+        };
+        uissue(std::integral_constant<int, 0>{}, fa);
+        ulanded(fa);
+        if constexpr (!(PB_ABLATE & 1)) {
+          *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
+          *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
+        }
+        uchunk(std::integral_constant<int, 0>{}, fa, fb);
+        uchunk(std::integral_constant<int, 1>{}, fb, fa);
+        uchunk(std::integral_constant<int, 2>{}, fa, fb);
+        uchunk(std::integral_constant<int, 3>{}, fb, fa);
+        uchunk(std::integral_constant<int, 4>{}, fa, fb);
+        uchunk(std::integral_constant<int, 5>{}, fb, fa);
+        uchunk(std::integral_constant<int, 6>{}, fa, fb);
+        uchunk(std::integral_constant<int, 7>{}, fb, fa);
+      }
+    }
+    __syncthreads();     // every wave is done with the rings
+    // ---- du * SiLU'(a_i + b_j): sums over j stay in the wave, sums over i meet in LDS (see the single-wave kernel) ----
+    float* red = reinterpret_cast<float*>(smem);                      // [4][NDT][16][32]
+    const int ia = min(i0, N - 1), ib = min(i0 + 1, N - 1);
+    float* pa = p.part_a + (((int64_t)b * p.ntiles + blockIdx.x) * PB_TI + 2 * grp + half) * D;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+      const int d = 32 * t + r32;
+      const float a_lo = bf16_to_f32(abd[(int64_t)ia * 2 * D + d]), a_hi = bf16_to_f32(abd[(int64_t)ib * 2 * D + d]);
+      float bj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = min(j0 + 8 * (q >> 2) + 4 * half + (q & 3), N - 1);
+        bj[q] = bf16_to_f32(abd[(int64_t)j * 2 * D + D + d]);
+      }
+      float sa0 = 0.f, sa1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v0 = du[t][q] * silu_grad_f(a_lo + bj[q]);
+        const float v1 = du[t][8 + q] * silu_grad_f(a_hi + bj[q]);
+        sa0 += v0; sa1 += v1;
+        red[((grp * NDT + t) * 16 + 8 * (q >> 2) + 4 * half + (q & 3)) * 32 + r32] = v0 + v1;
+      }
+      sa0 += __shfl_xor(sa0, 32);
+      sa1 += __shfl_xor(sa1, 32);
+      pa[d] = half ? sa1 : sa0;
+    }
+    __syncthreads();
+    float* pb = p.part_b + ((int64_t)b * p.ntiles + blockIdx.x) * PB_TJ * D;
+    for (int e = tid - 256; e < NDT * 16 * 32; e += 256) {
+      const int c = e & 31, jl = (e >> 5) & 15, t = e >> 9;
+      float v = red[e];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += red[w * NDT * 512 + e];
+      pb[(int64_t)jl * D + 32 * t + c] = v;
+    }
+  }
+}
+
+template <int KS>
+static int launch_pair_bwd_ws(const PairBwdParams& p, hipStream_t st) {
+  const int ncol = p.a.num_heads * p.D;
+  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 16 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048;
+  if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
+  if (sh > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_ws_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_error("peneo_pair_bwd_fused: cannot raise dynamic LDS to %zu bytes", sh);
+    return PENEO_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((pair_bwd_ws_kernel<KS>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PW_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_bwd_fused");
+}
+
+template <int KS, bool PIPE>
+static int launch_pair_bwd_v(const PairBwdParams& p, hipStream_t st) {
+  const int ncol = p.a.num_heads * p.D;
+  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 16 + (size_t)PB_WAVES * 32 * 16 * 3 + (size_t)PB_WAVES * 2048;
+  if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
+  if (sh > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_fused_kernel<KS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_error("peneo_pair_bwd_fused: cannot raise dynamic LDS to %zu bytes", sh);
+    return PENEO_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((pair_bwd_fused_kernel<KS, PIPE>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PB_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_bwd_fused");
+}
+template <int KS>
+static int launch_pair_bwd(const PairBwdParams& p, hipStream_t st) {
+  // PENEO_PB_MODE: "ws" (default) = wave-specialised kernel, "1w" = one wave per SIMD (PENEO_PB_PIPE = 0 / 1: its two schedules)
+  static const bool ws = [] { const char* e = getenv("PENEO_PB_MODE"); return !(e && e[0] == '1'); }();
+  if (ws) return launch_pair_bwd_ws<KS>(p, st);
+  static const bool pipe = [] { const char* e = getenv("PENEO_PB_PIPE"); return e ? atoi(e) != 0 : true; }();
+  return pipe ? launch_pair_bwd_v<KS, true>(p, st) : launch_pair_bwd_v<KS, false>(p, st);
+}
+
+}  // namespace peneo
+using namespace peneo;
+
+extern "C" int peneo_pair_bwd_supported(int dtype, int D) {
+  const int ks = D / 16;
+  return dtype == PENEO_BF16 && D % 32 == 0 && (ks == 2 || ks == 4 || ks == 8 || ks == 24);
+}
+
+extern "C" int64_t peneo_pair_bwd_rows(int N) { return N > 0 ? (int64_t)pb_num_tiles(N) * PB_ROWS : 0; }
+
+extern "C" size_t peneo_pair_bwd_packed_bytes(int num_heads, int D) { return (size_t)(num_heads * D / 32) * 2 * (D / 16) * 1024; }
+
+extern "C" int peneo_pair_bwd_pack(const float* const* w1, int num_heads, int D, void* packed, peneo_stream_t stream) {
+  PENEO_REQUIRE(w1 && packed && num_heads > 0 && num_heads <= PENEO_MAX_HEADS && D % 32 == 0, "peneo_pair_bwd_pack: bad arguments");
+  PackBwdSrc s;
+  s.num_heads = num_heads; s.D = D;
+  for (int h = 0; h < num_heads; ++h) { PENEO_REQUIRE(w1[h], "peneo_pair_bwd_pack: null weight"); s.w1[h] = w1[h]; }
+  hipLaunchKernelGGL(pack_bwd_weights_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, s, reinterpret_cast<bf16_t*>(packed));
+  return check_launch("peneo_pair_bwd_pack");
+}
+
+extern "C" size_t peneo_pair_bwd_partial_bytes(int B, int N, int D) {
+  return (size_t)B * pb_num_tiles(N) * (PB_TI + PB_TJ) * D * sizeof(float);
+}
+
+extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int D, const void* w_packed, const float* b1,
+                                    const peneo_pair_dz_args* args, void* dz, void* x, float* d_ab, float* workspace,
+                                    float* partials, peneo_stream_t stream) {
+  PENEO_REQUIRE(peneo_pair_bwd_supported(dtype, D), "peneo_pair_bwd_fused: bf16 and D/16 in {2, 4, 8, 24} only (got D=%d)", D);
+  PENEO_REQUIRE(ab && w_packed && b1 && args && dz && x && d_ab && workspace && partials && B > 0 && N > 0, "peneo_pair_bwd_fused: bad arguments");
+  PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D == D && args->scale, "peneo_pair_bwd_fused: bad head description");
+  PENEO_REQUIRE(args->num_heads * D >= 64, "peneo_pair_bwd_fused: needs at least two 32-unit slabs of hidden units");
+  PENEO_REQUIRE(((reinterpret_cast<uintptr_t>(ab) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(x)) & 15) == 0,
+                "peneo_pair_bwd_fused: pointers must be 16-byte aligned");
+  for (int h = 0; h < args->num_heads; ++h)
+    PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3, "peneo_pair_bwd_fused: head %d", h);
+  PairBwdParams p;
+  p.ab = reinterpret_cast<const bf16_t*>(ab); p.B = B; p.N = N; p.D = D; p.P = (int64_t)N * (N + 1) / 2;
+  p.wp = w_packed; p.b1 = b1; p.a = *args;
+  p.dz = reinterpret_cast<bf16_t*>(dz); p.x = reinterpret_cast<bf16_t*>(x); p.ws = workspace;
+  p.ntiles = pb_num_tiles(N);
+  p.part_a = partials; p.part_b = partials + (size_t)B * p.ntiles * PB_TI * D;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = PENEO_ERR_INVALID;
+  switch (D / 16) {
+    case 2: rc = launch_pair_bwd<2>(p, st); break;
+    case 4: rc = launch_pair_bwd<4>(p, st); break;
+    case 8: rc = launch_pair_bwd<8>(p, st); break;
+    case 24: rc = launch_pair_bwd<24>(p, st); break;
+  }
+  if (rc != PENEO_OK) return rc;
+  hipLaunchKernelGGL(pair_bwd_reduce_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, st, p.part_a, p.part_b, N, D, p.ntiles, d_ab);
+  return check_launch("peneo_pair_bwd_fused (reduce)");
+}

@@ -105,16 +105,6 @@ __device__ __forceinline__ void dls_add(float (&dls)[NCP], int idx, float g) {
   for (int c = 0; c < NCP; ++c) dls[c] += (c == idx) ? g : 0.f;
 }
 
-template <typename T> struct FragBytes { static constexpr int v = 8 * (int)sizeof(T); };  // per lane per fragment
-
-template <typename T>
-__device__ __forceinline__ Frag<T> load_frag_linear(const char* base, int frag_index, int lane) {
-  Frag<T> f;
-  const char* p = base + ((int64_t)frag_index * 64 + lane) * FragBytes<T>::v;
-  if constexpr (sizeof(T) == 2) f.v = *reinterpret_cast<const uint4*>(p);
-  else { f.v[0] = *reinterpret_cast<const uint4*>(p); f.v[1] = *reinterpret_cast<const uint4*>(p + 16); }
-  return f;
-}
 
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the count must be an immediate
 __device__ __forceinline__ void wait_vmcnt(int n) {
@@ -360,17 +350,6 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_pipe_kernel(P
   pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
 }
 
-// One 1 KiB LDS-DMA piece (global_load_lds_dwordx4: 64 lanes x 16 B; LDS destination = M0 base + offset + lane*16),
-// issued from inline asm on purpose: hipcc drains the whole vm counter (s_waitcnt vmcnt(0)) in front of every ds_read
-// while an LDS-DMA *it knows about* is in flight, which would serialise the weight stream with the MFMAs.  Hidden in
-// asm, the DMA is ours to order: counted s_waitcnt vmcnt + s_barrier before the slab is read (cdna guide §5.7).
-template <int U, int UPW>
-__device__ __forceinline__ void lds_dma_units(const char* gsrc_lane, uint32_t lds_base_uniform) {
-  if constexpr (U < UPW) {
-    lds_dma_1k<(U % 4) * 1024>(gsrc_lane + (U / 4) * 4096, lds_base_uniform + (U / 4) * 4096);
-    lds_dma_units<U + 1, UPW>(gsrc_lane, lds_base_uniform);
-  }
-}
 
 // Generic kernel (bf16 and fp32).  Per workgroup: 8 waves x 32 pairs.  Weight slabs (32 hidden rows: KS first-layer
 // fragments + 2 second-layer fragments, padded to UPW KiB per wave) stream L2 -> LDS through a ring of NSTAGE buffers,

@@ -113,6 +113,12 @@ SIGNATURES = {
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
     "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "peneo_pair_bwd_supported": (_i, [_i, _i]),
+    "peneo_pair_bwd_rows": (_i64, [_i]),
+    "peneo_pair_bwd_packed_bytes": (_sz, [_i, _i]),
+    "peneo_pair_bwd_pack": (_i, [_vp, _i, _i, _vp, _vp]),
+    "peneo_pair_bwd_partial_bytes": (_sz, [_i, _i, _i]),
+    "peneo_pair_bwd_fused": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "peneo_ohem_workspace_bytes": (_sz, [_i64]),
     "peneo_ohem_ce": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "peneo_ohem_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

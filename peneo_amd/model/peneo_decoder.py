@@ -266,9 +266,26 @@ class _DecoderStage(torch.autograd.Function):
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         dW1cat = torch.zeros((nh * D, D), dtype=torch.float32, device=dev)
         dz_ws = ops.pair_dz_workspace(nh, D, dev, slots=256)   # rows both dz producers used here spread their atomics over
-        d_ab = torch.zeros((B, N, 2 * D), dtype=torch.float32, device=dev)
         P = N * (N + 1) // 2
-        chunks = _row_chunks(N, dec.bwd_chunk_pairs)
+        w2d = [w.detach().contiguous() for w in w2s]
+        use_fused_bwd = dec.fused_bwd and ops.pair_bwd_supported(dt, D)
+        # the fused kernel overwrites d_ab; the chunked path accumulates into it
+        d_ab = (torch.empty if use_fused_bwd else torch.zeros)((B, N, 2 * D), dtype=torch.float32, device=dev)
+        if use_fused_bwd:
+            # ONE kernel for the whole batch: x, z, dz, du = dz W1 and the sums into d_a / d_b never leave the chip except
+            # dz and x themselves (block order), which the one remaining GEMM dW1 = dz^T x reads back once
+            wp2 = wc.get(("dec.pack2", dt), w1s, lambda: ops.pair_bwd_pack([w.detach() for w in w1s]))
+            rows = ops.pair_bwd_rows(N)
+            dzbuf = torch.empty((B * rows, nh * D), dtype=dt, device=dev)
+            xbuf1 = torch.empty((B * rows, D), dtype=dt, device=dev)
+            dza = ops.pair_dz_args(D, HEAD_CLASSES, sv["dlog"], w2d, scale)
+            ops.pair_bwd_fused(ab, wp2, b1cat, dza, dzbuf, xbuf1, d_ab, dz_ws)
+            ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
+            chunks = []
+        else:
+            chunks = _row_chunks(N, dec.bwd_chunk_pairs)
+        if not chunks:
+            return _DecoderStage._finish_backward(ctx, dec, sv, params, scale, dW1cat, dz_ws, d_ab, heads, w1s, b1s, w2s, b2s)
         maxp = max((i1 * N - i1 * (i1 - 1) // 2) - (i0 * N - i0 * (i0 - 1) // 2) for i0, i1 in chunks)
         # Two-stage pipeline over the pair chunks on two HIP streams: stage 1 (x, z GEMM whose epilogue turns z into dz:
         # VALU-bound) runs one chunk ahead of stage 2 (dW1 and dx GEMMs + the scatter into d_ab: MFMA-bound), so the two
@@ -277,7 +294,6 @@ class _DecoderStage(torch.autograd.Function):
         prebuf = [torch.empty((maxp, D), dtype=dt, device=dev) for _ in range(2)]   # a_i + b_j: SiLU' source of the dx GEMM
         zbuf = [torch.empty((maxp, nh * D), dtype=dt, device=dev) for _ in range(2)]
         dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
-        w2d = [w.detach().contiguous() for w in w2s]
         fused_dz = (dec.fused_dz and not dec.three_streams and dt == torch.bfloat16 and D % 32 == 0
                     and D // 16 in (2, 4, 6, 8, 12, 16, 24, 32))
         if fused_dz:
@@ -353,6 +369,21 @@ class _DecoderStage(torch.autograd.Function):
         main.wait_stream(side)
         if third is not None:
             main.wait_stream(third)
+        return _DecoderStage._finish_backward(ctx, dec, sv, params, scale, dW1cat, dz_ws, d_ab, heads, w1s, b1s, w2s, b2s)
+
+    @staticmethod
+    def _finish_backward(ctx, dec, sv, params, scale, dW1cat, dz_ws, d_ab, heads, w1s, b1s, w2s, b2s):
+        """Second half of the backward: parameter gradients of the heads from the accumulated sums, then back through the
+        [a | b] projection and the shrink MLP."""
+        wc = dec.weight_cache
+        B, N, D = sv["B"], sv["N"], sv["D"]
+        ab, seeds = sv["ab"], sv["seeds"]
+        dt, dev = ab.dtype, ab.device
+        nh = len(HEAD_NAMES)
+        it = iter(params)
+        if dec.decoder_shrink:
+            w0, b0, w3, b3 = next(it), next(it), next(it), next(it)
+        wc_w, wc_b = next(it), next(it)
         dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
         db2cat = sv["dls"]
         # back through the [a | b] projection and the shrink MLP
@@ -440,6 +471,7 @@ class PEneoDecoder(nn.Module):
         self.bwd_chunk_pairs = int(os.environ.get("PENEO_BWD_CHUNK_PAIRS", 1 << 18))
         self.three_streams = os.environ.get("PENEO_DEC_STREAMS", "2") == "3"   # measured: no gain over two
         self.fused_dz = os.environ.get("PENEO_DZ_FUSED", "1") != "0"            # bf16: dz without x / z in memory
+        self.fused_bwd = os.environ.get("PENEO_BWD_FUSED", "1") != "0"          # bf16: the whole pair-space backward in one kernel
         self._ratio = {}
 
     def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:

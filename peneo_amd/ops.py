@@ -556,6 +556,38 @@ def pair_dz_fused(ab_doc: torch.Tensor, i0: int, i1: int, wp: torch.Tensor, b1: 
               "peneo_pair_dz_fused")
 
 
+def pair_bwd_supported(dtype: torch.dtype, D: int) -> bool:
+    return dtype == torch.bfloat16 and bool(lib().peneo_pair_bwd_supported(BF16, D))
+
+
+def pair_bwd_rows(N: int) -> int:
+    """Rows per document of the dz / x buffers of ``pair_bwd_fused`` (pairs in 8 x 16 blocks of the triangle)."""
+    return int(lib().peneo_pair_bwd_rows(N))
+
+
+def pair_bwd_pack(w1: Sequence[torch.Tensor]) -> torch.Tensor:
+    """First-layer weights of all heads ([D, D] fp32 each) -> bf16 fragment stream of ``pair_bwd_fused``."""
+    nh, D = len(w1), w1[0].shape[0]
+    out = torch.empty(lib().peneo_pair_bwd_packed_bytes(nh, D), dtype=torch.uint8, device=w1[0].device)
+    check(lib().peneo_pair_bwd_pack(_ptr_list([_c(w) for w in w1]), nh, D, ptr(out), stream()), "peneo_pair_bwd_pack")
+    return out
+
+
+def pair_bwd_fused(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, args: "hip.PairDzArgs", dz: torch.Tensor,
+                   x: torch.Tensor, d_ab: torch.Tensor, workspace: torch.Tensor) -> None:
+    """Whole-batch decoder backward through the pair space (see include/peneo_hip.h): ab [B, N, 2D] bf16 ->
+    dz [B * rows, nh*D], x [B * rows, D] (bf16, block order), d_ab [B, N, 2D] fp32 (overwritten), dW2 / db1 sums in `workspace`."""
+    B, N, D2 = ab.shape
+    assert d_ab.dtype == torch.float32 and d_ab.shape == ab.shape and dz.dtype == x.dtype == torch.bfloat16
+    rows = pair_bwd_rows(N)
+    assert dz.shape[0] == B * rows and x.shape == (B * rows, D2 // 2)
+    partials = torch.empty(lib().peneo_pair_bwd_partial_bytes(B, N, D2 // 2) // 4, dtype=torch.float32, device=ab.device)
+    with kernel_timer("pair_bwd_fused"):
+        check(lib().peneo_pair_bwd_fused(dtype_code(ab.dtype), ptr(_c(ab)), B, N, D2 // 2, ptr(wp), ptr(b1), C.byref(args),
+                                         ptr(_c(dz)), ptr(_c(x)), ptr(_c(d_ab)), ptr(workspace), ptr(partials), stream()),
+              "peneo_pair_bwd_fused")
+
+
 def pair_dz_finish(workspace: torch.Tensor, nh: int, D: int, classes: Sequence[int]):
     """-> (dw2 list of [C_h, D] fp32, db1 [nh * D] fp32) from the accumulated workspace."""
     vec = colsum(workspace)                     # [4 * nh * D]

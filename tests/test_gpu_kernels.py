@@ -851,3 +851,55 @@ def test_ohem_ce_matches_reference_cases_and_oracle(ops):
     assert int((kept_g != kept_r).sum()) <= 0.02 * (64 + 20000), int((kept_g != kept_r).sum())
     both = kept_g & kept_r
     assert (got[both] - lr.grad[both]).abs().max() <= 2e-5 * lr.grad.abs().max()
+
+
+@pytest.mark.parametrize("B,N,D", [(2, 45, 128), (1, 70, 384), (3, 23, 32), (1, 130, 64), (2, 16, 384), (1, 9, 128)])
+def test_pair_bwd_fused_matches_autograd(ops, B, N, D):
+    """peneo_pair_bwd_fused: dz / x in block order, d_ab (= d_a | d_b), dW2 / db1 sums and (through the one GEMM it leaves)
+    dW1, against fp32 autograd through x = SiLU(a_i + b_j) -> z = x W1^T + b1 -> SiLU -> W2 with given dlogits."""
+    dtype, classes = torch.bfloat16, [2, 3, 3, 3, 3]
+    nh = len(classes)
+    g = torch.Generator().manual_seed(B * 100000 + N * 1000 + D)
+    ab = torch.randn(B, N, 2 * D, generator=g).to(DEV).to(dtype)
+    P = N * (N + 1) // 2
+    w1 = [(torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV) for _ in classes]
+    w2 = [torch.randn(c, D, generator=g).to(DEV) for c in classes]
+    b1cat = (0.1 * torch.randn(nh * D, generator=g)).to(DEV)
+    dl = [torch.randn(B, P, c, generator=g).to(DEV) for c in classes]
+    scale = torch.rand(nh, generator=g).to(DEV) + 0.5
+    assert ops.pair_bwd_supported(dtype, D)
+    rows = ops.pair_bwd_rows(N)
+    assert rows % 128 == 0 and rows >= P
+    wp2 = ops.pair_bwd_pack(w1)
+    args = ops.pair_dz_args(D, classes, dl, w2, scale)
+    dz = torch.full((B * rows + 2, nh * D), 7.0, device=DEV, dtype=dtype)
+    x = torch.full((B * rows + 2, D), 7.0, device=DEV, dtype=dtype)
+    d_ab = torch.full((B, N, 2 * D), 5.0, device=DEV)            # overwritten, not accumulated
+    ws = ops.pair_dz_workspace(nh, D, DEV, slots=256)
+    ops.pair_bwd_fused(ab, wp2, b1cat, args, dz[:B * rows], x[:B * rows], d_ab, ws)
+    torch.cuda.synchronize()
+    assert bool((dz[B * rows:] == 7.0).all()) and bool((x[B * rows:] == 7.0).all())
+    dW1 = ops.gemm(dz[:B * rows], x[:B * rows], a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    dw2, db1 = ops.pair_dz_finish(ws, nh, D, classes)
+    # fp32 autograd of the same block (bf16-rounded operands where the kernel rounds: ab, x, W1)
+    abr = ab.float().clone().requires_grad_(True)
+    ii, jj = torch.triu_indices(N, N, device=DEV)
+    xr = F.silu(abr[:, ii, :D] + abr[:, jj, D:])                               # [B, P, D]
+    xq = xr + (xr.detach().to(dtype).float() - xr.detach())                     # straight-through bf16 rounding of x
+    w1r = [w.to(dtype).float().clone().requires_grad_(True) for w in w1]
+    w2r = [w.clone().requires_grad_(True) for w in w2]
+    b1r = b1cat.clone().requires_grad_(True)
+    tot = 0
+    for h in range(nh):
+        z = xq @ w1r[h].t() + b1r[h * D:(h + 1) * D]
+        tot = tot + ((F.silu(z) @ w2r[h].t()) * dl[h] * scale[h]).sum()
+    tot.backward()
+    t = 3e-2
+    assert rel_err(d_ab, abr.grad) < t, rel_err(d_ab, abr.grad)
+    assert rel_err(db1, b1r.grad) < t
+    for h in range(nh):
+        assert rel_err(dw2[h], w2r[h].grad) < t, h
+        assert rel_err(dW1[h * D:(h + 1) * D], w1r[h].grad) < t, h
+    # rows outside the triangle are exactly zero in dz and finite in x; the valid ones carry every pair exactly once
+    nz = (dz[:B * rows].float().abs().sum(-1) > 0).view(B, rows).sum(-1)
+    assert int(nz.max()) <= P and bool(torch.isfinite(x[:B * rows].float()).all())
