@@ -93,7 +93,7 @@ template <int KS> constexpr int pb_chunk_first(int j) { for (int f = 0; f < KS; 
 constexpr int PB_MAXC = 3;   // fragments per chunk (KS = 24)
 
 #ifndef PB_DBG
-#define PB_DBG 0      // race hunting (tools/): 1 __syncthreads instead of the raw barrier, 2 second barrier per iteration, 4 all DMA by waves 0-3
+#define PB_DBG 0      // tools/ab_pb_dbg.sh: 65536 = packed-fp32 dz arithmetic in the wave-specialised kernel (reproduces the corruption)
 #endif
 #ifndef PB_OPT
 #define PB_OPT 1      // 1: tile store behind the chunk's wait, 2: LDS-DMA pieces spread over the chunks (measured slower; and racy)

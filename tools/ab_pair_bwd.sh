@@ -3,7 +3,7 @@ LIST="${LIST:-1 16 32 33}"
 cd $GRAFT_REPO_ROOT/peneo_amd/csrc
 for n in $LIST; do
   mkdir -p /tmp/pb$n
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DPB_ABLATE=$n -c pair_bwd.hip -o /tmp/pb$n/pair_bwd.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DPB_ABLATE=$n -c pair_bwd.hip -o /tmp/pb$n/pair_bwd.o &
 done
 wait
 cd $GRAFT_REPO_ROOT
