@@ -838,7 +838,8 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
           const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
           const f2 y = zz * sg;
           const f2 dy = fma2(g2, w2, fma2(g1, w1, g0 * w0));
-          const f2 dzv = dy * (sg * fma2(zz, one2 - sg, one2));
+          // SiLU'(z) = sg (1 + z (1 - sg)) = sg + y (1 - sg) = (sg + y) - y sg
+          const f2 dzv = dy * fma2(f2{-y.x, -y.y}, sg, sg + y);
           s0 = fma2(g0, y, s0);
           s1 = fma2(g1, y, s1);
           s2 = fma2(g2, y, s2);

@@ -21,7 +21,7 @@ from transformers.modeling_outputs import ModelOutput
 
 from .. import ops
 from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
-from .engine import DropoutSeeds, WeightCache
+from .engine import DropoutSeeds, WeightCache, defer_join
 
 HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
@@ -280,7 +280,19 @@ class _DecoderStage(torch.autograd.Function):
             xbuf1 = torch.empty((B * rows, D), dtype=dt, device=dev)
             dza = ops.pair_dz_args(D, HEAD_CLASSES, sv["dlog"], w2d, scale)
             ops.pair_bwd_fused(ab, wp2, b1cat, dza, dzbuf, xbuf1, d_ab, dz_ws)
-            ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
+            # dW1 = dz^T x (2 ms of pure MFMA work, needed by nobody until the optimizer) runs on the side stream beside the
+            # shrink-MLP backward and the first encoder layers, whose short kernels leave CUs idle; joined one stage later
+            if dec.dw1_on_side:
+                main = torch.cuda.current_stream()
+                side = dec.side_stream(dev)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
+                ctx.side_work = (side, (dzbuf, xbuf1, dW1cat, ab))
+            else:
+                ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
             chunks = []
         else:
             chunks = _row_chunks(N, dec.bwd_chunk_pairs)
@@ -415,6 +427,14 @@ class _DecoderStage(torch.autograd.Function):
             grads += [dW1cat[h * D:(h + 1) * D], db1cat[h * D:(h + 1) * D], dw2[h], db2cat[off:off + c] * scale[h]]
             off += c
         grads = tuple(g if p.requires_grad else None for g, p in zip(grads, params))
+        side_work = getattr(ctx, "side_work", None)
+        if side_work is not None:
+            side, keep = side_work
+            ctx.side_work = None
+            if all(p.grad is None for p in params):
+                defer_join(side, keep=keep)
+            else:
+                torch.cuda.current_stream().wait_stream(side)
         return (None, d_seq, None, None, None, None, None) + grads
 
 
@@ -472,6 +492,7 @@ class PEneoDecoder(nn.Module):
         self.three_streams = os.environ.get("PENEO_DEC_STREAMS", "2") == "3"   # measured: no gain over two
         self.fused_dz = os.environ.get("PENEO_DZ_FUSED", "1") != "0"            # bf16: dz without x / z in memory
         self.fused_bwd = os.environ.get("PENEO_BWD_FUSED", "1") != "0"          # bf16: the whole pair-space backward in one kernel
+        self.dw1_on_side = os.environ.get("PENEO_DW1_SIDE", "1") != "0"          # its dW1 GEMM beside the following stages
         self._ratio = {}
 
     def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:

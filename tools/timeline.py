@@ -30,7 +30,7 @@ def main():
     # train steps are the pair_heads launches followed by a pair_dz kernel before the next mark
     train = []
     for a, b in zip(marks, marks[1:] + [len(rows)]):
-        if any("pair_dz" in rows[k][3] for k in range(a, b)):
+        if any(("pair_dz" in rows[k][3] or "pair_bwd" in rows[k][3]) for k in range(a, b)):
             train.append(a)
     if len(train) < back + 1:
         print("not enough train steps in the trace", len(train))
