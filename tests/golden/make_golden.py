@@ -180,20 +180,83 @@ def make_ohem(ref, seed: int = 11):
     print(f"[ohem] model loss={float(res['outputs']['loss']):.6f} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def make_decode(ref, seed: int = 21):
+    """Decoding graph walk (pipeline/decode.py) run by the real reference on small hand-built documents: logits whose
+    argmax is a given set of line / grouping / linking spots plus seeded noise spots, and the matching label maps."""
+    from model.peneo_decoder import HandshakingTaggingScheme
+    from pipeline.decode import decode_peneo, sample_decode_peneo
+    tagger = HandshakingTaggingScheme()
+    g = torch.Generator().manual_seed(seed)
+    docs = []
+    # (n tokens, lines [(h, t)], grouping links [(line a -> line b)], entity links [(key first line, value first line)], flips)
+    layouts = [
+        (24, [(0, 2), (3, 5), (6, 7), (8, 10), (11, 12), (13, 17), (18, 23)], [(0, 1), (3, 4)], [(0, 2), (3, 5), (6, 5)]),
+        (31, [(0, 0), (1, 4), (5, 9), (10, 11), (12, 20), (21, 22), (23, 30)], [(1, 2), (2, 3), (5, 6)], [(1, 4), (5, 0), (4, 5)]),
+        (12, [(0, 3), (4, 7), (8, 11)], [], [(0, 1), (2, 1)]),
+    ]
+    for n, lines, groups, links in layouts:
+        P = n * (n + 1) // 2
+        le, lg_h, lg_t, el_h, el_t = [], [], [], [], []
+        for h, t in lines:
+            le.append((h, t, 1))
+        nxt = dict(groups)
+
+        def last_line(a):
+            hops = 0
+            while a in nxt and hops < 10:
+                a = nxt[a]; hops += 1
+            return a
+        up = lambda i, j: (i, j, 1) if i <= j else (j, i, 2)     # tag 2 = the link runs j -> i (rfund.py:326-358)
+        for a, b in groups:
+            lg_h.append(up(lines[a][0], lines[b][0])); lg_t.append(up(lines[a][1], lines[b][1]))
+        for k, v in links:
+            el_h.append(up(lines[k][0], lines[v][0])); el_t.append(up(lines[last_line(k)][1], lines[last_line(v)][1]))
+        spots = [le, el_h, el_t, lg_h, lg_t]
+        tags = [tagger.spots2shaking_tag4batch([sp], seq_len=n)[0] for sp in spots]
+        logits = []
+        for h, tg in enumerate(tags):
+            C = 2 if h == 0 else 3
+            lgt = torch.randn(P, C, generator=g) * 0.5
+            lgt[:, 0] += 3.0                                    # background wins ...
+            lgt[torch.arange(P), tg] += 4.0 * (tg != 0)          # ... except on the true spots
+            noise = torch.randint(0, P, (4,), generator=g)      # a few wrong detections with mid scores
+            lgt[noise, torch.randint(1, C, (4,), generator=g)] += 3.4
+            logits.append(lgt)
+        text = [chr(97 + (i % 26)) + ("" if i % 5 else " ") for i in range(n)]
+        bbox = torch.stack([torch.tensor([10 * i, 7 * (i % 9), 10 * i + 8, 7 * (i % 9) + 6]) for i in range(n)])
+        pred = sample_decode_peneo(tagger, text, *logits, bbox=bbox, seq_len=n, decode_gt=False)
+        pred_thr = sample_decode_peneo(tagger, text, *logits, seq_len=n, decode_gt=False, score_thresh=0.6)
+        gt = sample_decode_peneo(tagger, text, *tags, bbox=bbox, seq_len=n, decode_gt=True)
+        docs.append(dict(n=n, text=text, bbox=bbox, logits=logits, tags=tags, pred=pred, pred_thr=pred_thr, gt=gt))
+        print(f"[decode] n={n}: pred kv={len(pred[0])} lines={len(pred[1])} | thr kv={len(pred_thr[0])} | gt kv={len(gt[0])} lines={len(gt[1])}")
+    # batch form on the two documents of equal... decode_peneo walks documents one by one: give it lists
+    batch = docs[:2]
+    res = decode_peneo(tagger, [d["text"] for d in batch], *[[d["logits"][h] for d in batch] for h in range(5)],
+                       *[[d["tags"][h] for d in batch] for h in range(5)], [d["bbox"].tolist() for d in batch], ["a.json", "b.json"])
+    path = os.path.join(HERE, "decode.pt")
+    torch.save({"docs": docs, "batch": res}, path)
+    print(f"[decode] -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base", action="store_true")
     ap.add_argument("--only-ohem", action="store_true", help="regenerate tests/golden/ohem.pt only")
+    ap.add_argument("--only-decode", action="store_true", help="regenerate tests/golden/decode.pt only")
     args = ap.parse_args()
     ref = import_reference()
     torch.set_num_threads(8)
     if args.only_ohem:
         make_ohem(ref)
         return
+    if args.only_decode:
+        make_decode(ref)
+        return
     make_tiny(ref, "lmv3_tiny", peneo_config("layoutlmv3-base", layoutlmv3_config("tiny")), 40, 8, True, True, 1)
     make_tiny(ref, "lmv3_tiny_s24", peneo_config("layoutlmv3-base", layoutlmv3_config("tiny")), 24, 5, True, True, 2)
     make_tiny(ref, "lilt_tiny", peneo_config("lilt-roberta-en-base", lilt_config("tiny")), 33, 6, False, False, 3)
     make_ohem(ref)
+    make_decode(ref)
     if args.base:
         make_base(ref)
 

@@ -476,3 +476,24 @@ def test_ohem_model_matches_reference(dtype):
             if cos < 0.6:
                 bad.append((n, cos))
     assert not bad, bad
+
+
+def test_decode_from_device_logits_matches_reference():
+    """SURVEY §8f rank 1 end to end: device logits -> peneo_spots_compact (one launch + one copy per score map) -> host graph
+    walk -> the reference's kv pairs, lines and link dictionaries (tests/golden/decode.pt, produced by pipeline/decode.py)."""
+    from peneo_amd.model import HandshakingTaggingScheme
+    from peneo_amd.pipeline import sample_decode_peneo
+    fx = load_golden("decode")
+    T = HandshakingTaggingScheme()
+    for d in fx["docs"]:
+        for kw, key in ((dict(bbox=d["bbox"]), "pred"), (dict(score_thresh=0.6), "pred_thr")):
+            got = sample_decode_peneo(T, d["text"], *[l.cuda() for l in d["logits"]], seq_len=d["n"], **kw)
+            want = d[key]
+            assert [kv[:2] for kv in got[0]] == [kv[:2] for kv in want[0]]
+            if "bbox" in kw:
+                assert [list(kv[2]) + list(kv[3]) for kv in got[0]] == [list(kv[2]) + list(kv[3]) for kv in want[0]]
+            assert [l[0] if isinstance(l, tuple) else l for l in got[1]] == [l[0] if isinstance(l, tuple) else l for l in want[1]]
+            for a, b in zip(got[2:], want[2:]):
+                assert dict(a) == dict(b)
+        got = sample_decode_peneo(T, d["text"], *[t.cuda() for t in d["tags"]], bbox=d["bbox"], seq_len=d["n"], decode_gt=True)
+        assert [kv[:2] for kv in got[0]] == [kv[:2] for kv in d["gt"][0]] and dict(got[2]) == dict(d["gt"][2])

@@ -132,3 +132,41 @@ def test_synthetic_batch_contract():
     assert torch.equal(b["attention_mask"], (b["input_ids"] != 1).long())
     b2 = synthetic_rfund_batch(3, 64, 9, 500, seed=3, ragged=True)
     assert all(torch.equal(b[k], b2[k]) for k in b)
+
+
+def _same_decode(got, want):
+    """7-tuple of sample_decode_peneo: kv pairs, lines, five link dictionaries."""
+    assert len(got) == len(want) == 7
+    assert [tuple(map(lambda v: tuple(v) if isinstance(v, list) else v, kv)) for kv in got[0]] == \
+           [tuple(map(lambda v: tuple(v) if isinstance(v, list) else v, kv)) for kv in want[0]]
+    norm = lambda ln: (ln[0], tuple(ln[1])) if isinstance(ln, (tuple, list)) else ln
+    assert [norm(l) for l in got[1]] == [norm(l) for l in want[1]]
+    for a, b in zip(got[2:], want[2:]):
+        assert dict(a) == dict(b)
+
+
+def test_decode_graph_walk_matches_reference():
+    """peneo_amd.pipeline.decode (spots -> lines -> kv pairs) on CPU tensors against the fixture produced by the reference's
+    pipeline/decode.py (tests/golden/decode.pt): predictions (one successor per node, best score wins), a score threshold,
+    ground-truth decoding, and the batch form."""
+    from peneo_amd.model import HandshakingTaggingScheme
+    from peneo_amd.pipeline import decode_peneo, parse_matrix_spots, sample_decode_peneo
+    fx = load_golden("decode")
+    T = HandshakingTaggingScheme()
+    for d in fx["docs"]:
+        _same_decode(sample_decode_peneo(T, d["text"], *d["logits"], bbox=d["bbox"], seq_len=d["n"]), d["pred"])
+        _same_decode(sample_decode_peneo(T, d["text"], *d["logits"], seq_len=d["n"], score_thresh=0.6), d["pred_thr"])
+        _same_decode(sample_decode_peneo(T, d["text"], *d["tags"], bbox=d["bbox"], seq_len=d["n"], decode_gt=True), d["gt"])
+        assert len(d["gt"][0]) >= 2                                # the hand-built documents do contain pairs
+    b = fx["docs"][:2]
+    preds, gts, ids = decode_peneo(T, [d["text"] for d in b], *[[d["logits"][h] for d in b] for h in range(5)],
+                                   *[[d["tags"][h] for d in b] for h in range(5)], [d["bbox"].tolist() for d in b],
+                                   ["a.json", "b.json"])
+    assert ids == fx["batch"][2]
+    for got, want in zip(preds, fx["batch"][0]):
+        _same_decode(got, want)
+    for got, want in zip(gts, fx["batch"][1]):
+        _same_decode(got, want)
+    # tie / direction rules of parse_matrix_spots
+    assert parse_matrix_spots([(1, 4, 1, 0.9), (1, 5, 1, 0.95), (2, 5, 1, 0.5)], top_score_only=True) == {1: 5}
+    assert parse_matrix_spots([(1, 4, 2, 0.9), (0, 4, 1, 0.3)], triu_mode=True) == {4: [1], 0: [4]}
