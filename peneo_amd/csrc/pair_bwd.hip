@@ -72,6 +72,7 @@ struct PairBwdParams {
   float* part_a; float* part_b;  // per-block partial sums [B][ntiles][8][D] / [B][ntiles][16][D] fp32
   float* ws;                     // [PB_SLOTS][4 * nh*D]
   int ntiles;
+  unsigned long long* dbg;       // optional (tools/): per wave of the first 256 blocks: cycles in the loop, cycles waiting at the top
 };
 
 // hand-issued fragment reads (the compiler would wait for every ds_read right in front of its MFMA: with one wave per SIMD
@@ -708,10 +709,28 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   const int t_swz = (r32 >> 2) & 3;
   // top of an iteration, both roles: everything this wave put in flight has completed (LDS-DMA pieces: vmcnt; tile /
   // column-sum stores that OTHER waves read: lgkmcnt), then the workgroup meets
+  unsigned long long t_wait = 0, t_vm = 0;
   auto top = [&]() {
+    if (p.dbg) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      t_vm += t1 - t0; t_wait += t2 - t1;
+      return;
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+  };
+  const unsigned long long t_begin = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+  auto report = [&]() {
+    if (p.dbg && blockIdx.y == 0 && blockIdx.x < 256 && lane == 0) {
+      unsigned long long* d = p.dbg + ((int64_t)blockIdx.x * PW_WAVES + wave) * 4;
+      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_vm; d[2] = t_wait; d[3] = 0;
+    }
   };
 
   if (producer) {
@@ -787,7 +806,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
 
     // one producer iteration: Z(s+1) accumulates into zw (fragments hand-issued one chunk ahead, two register sets, each
     // re-loaded only BEHIND the following chunk's MFMAs); E(s) reads zr (written during the previous iteration)
-    auto iteration = [&](auto z_c, auto e_c, int s, f32x16_t& zr, f32x16_t& zw) {
+    auto iteration = [&](auto z_c, auto e_c, int s, f32x16_t& zr, f32x16_t& zw, auto pre) {
       constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value;
       const uint32_t za = fbase + ((s + 1) & 1) * HALF_BYTES;
       char* myT = sT + ((s & 1) * 4 + grp) * 2048;
@@ -854,7 +873,10 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         }
         if constexpr (J + 1 < 8) landed(nxt);
       };
+      // the first chunk's fragments are in LDS since the barrier: their read latency runs under the LDS-DMA issue block,
+      // the column-sum flush and the dlogits staging (`pre`)
       issue(std::integral_constant<int, 0>{}, fa);
+      pre();
       landed(fa);
       chunk(std::integral_constant<int, 0>{}, fa, fb);
       chunk(std::integral_constant<int, 1>{}, fb, fa);
@@ -878,20 +900,26 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
     for (int r = 0; r < 16; ++r) { z0[r] = 0.f; z1[r] = 0.f; }
     __syncthreads();                                          // sCol visible (matches the consumers' barrier)
     // slab s lives in z0 when s is even, in z1 when odd; nslab >= 2 (launcher)
-    top(); dma_iter(-1); iteration(yes{}, no{}, -1, z1, z0);
+    auto pre = [&](int s) {
+      return [&, s]() {
+        dma_iter(s);
+        if (s >= 1) flush(s - 1);
+        if (s >= 0 && s < nslab && s % spb == 0) stage_g(s / spb);
+      };
+    };
+    top(); iteration(yes{}, no{}, -1, z1, z0, pre(-1));
     int s = 0;
     for (; s + 2 < nslab; s += 2) {
-      top(); dma_iter(s); if (s >= 1) flush(s - 1); if (s % spb == 0) stage_g(s / spb);
-      iteration(yes{}, yes{}, s, z0, z1);
-      top(); dma_iter(s + 1); flush(s); if ((s + 1) % spb == 0) stage_g((s + 1) / spb);
-      iteration(yes{}, yes{}, s + 1, z1, z0);
+      top(); iteration(yes{}, yes{}, s, z0, z1, pre(s));
+      top(); iteration(yes{}, yes{}, s + 1, z1, z0, pre(s + 1));
     }
     for (; s < nslab; ++s) {                                  // the last one or two slabs: no Z(s+1) for the very last
-      top(); dma_iter(s); if (s >= 1) flush(s - 1); if (s % spb == 0) stage_g(s / spb);
-      if (s + 1 < nslab) { if (s & 1) iteration(yes{}, yes{}, s, z1, z0); else iteration(yes{}, yes{}, s, z0, z1); }
-      else { if (s & 1) iteration(no{}, yes{}, s, z1, z0); else iteration(no{}, yes{}, s, z0, z1); }
+      top();
+      if (s + 1 < nslab) { if (s & 1) iteration(yes{}, yes{}, s, z1, z0, pre(s)); else iteration(yes{}, yes{}, s, z0, z1, pre(s)); }
+      else { if (s & 1) iteration(no{}, yes{}, s, z1, z0, pre(s)); else iteration(no{}, yes{}, s, z0, z1, pre(s)); }
     }
     top(); dma_iter(nslab); flush(nslab - 1);                 // iteration nslab: the consumers' U(nslab - 1)
+    report();
     __syncthreads();     // the consumers' reduction buffer (the rings) is free
     __syncthreads();     // ... and filled
   } else {
@@ -905,7 +933,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
     __syncthreads();                                          // matches the producers' barrier
     for (int s = -1; s <= nslab; ++s) {
       top();
-      dma_iter(s);
+      if (s < 1) dma_iter(s);
       if (s >= 1) {
         const int u = s - 1;
         const uint32_t ta = lds_addr(sT + ((u & 1) * 4 + grp) * 2048) + r32 * 64;
@@ -938,6 +966,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
           if constexpr (J + 1 < 8) { uissue(std::integral_constant<int, J + 1>{}, nxt); ulanded(nxt); }
         };
         uissue(std::integral_constant<int, 0>{}, fa);
+        dma_iter(s);                 // under the latency of the reads just issued
         ulanded(fa);
         if constexpr (!(PB_ABLATE & 1)) {
           *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
@@ -953,6 +982,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         uchunk(std::integral_constant<int, 7>{}, fb, fa);
       }
     }
+    report();
     __syncthreads();     // every wave is done with the rings
     // ---- du * SiLU'(a_i + b_j): sums over j stay in the wave, sums over i meet in LDS (see the single-wave kernel) ----
     float* red = reinterpret_cast<float*>(smem);                      // [4][NDT][16][32]
@@ -1031,6 +1061,11 @@ static int launch_pair_bwd(const PairBwdParams& p, hipStream_t st) {
 }  // namespace peneo
 using namespace peneo;
 
+static unsigned long long* g_pb_dbg = nullptr;
+/* tools/ only (not in the header): device buffer [256 blocks][8 waves][4] that receives per-wave cycle counts of the
+ * wave-specialised kernel: loop cycles, cycles in s_waitcnt at the top of the iterations, cycles in the barrier */
+extern "C" void peneo_pair_bwd_debug_buffer(unsigned long long* dev) { g_pb_dbg = dev; }
+
 extern "C" int peneo_pair_bwd_supported(int dtype, int D) {
   const int ks = D / 16;
   return dtype == PENEO_BF16 && D % 32 == 0 && (ks == 2 || ks == 4 || ks == 8 || ks == 24);
@@ -1069,6 +1104,7 @@ extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int
   p.wp = w_packed; p.b1 = b1; p.a = *args;
   p.dz = reinterpret_cast<bf16_t*>(dz); p.x = reinterpret_cast<bf16_t*>(x); p.ws = workspace;
   p.ntiles = pb_num_tiles(N);
+  p.dbg = g_pb_dbg;
   p.part_a = partials; p.part_b = partials + (size_t)B * p.ntiles * PB_TI * D;
   hipStream_t st = (hipStream_t)stream;
   int rc = PENEO_ERR_INVALID;
