@@ -780,28 +780,44 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
       }
     };
+    // MFMA operands of the current head, rebuilt every D / 32 slabs from scale_h * dlogits_h of the wave's 32 pairs:
+    //   gA      A operand of dy[pair, hid] = sum_c g[pair, c] W2[c, hid]: row = pair (lanes 0-31 hold (g0, g1, g2, 0 ...), k = class)
+    //   gT[kk]  A operand of the dW2 sums out[c, hid] = sum_pair g[pair, c] y[pair, hid]: row = class, k = pair in the order
+    //           in which a C-layout accumulator register set presents the pairs (pi(kk, half, e) = 16 kk + 8 (e >> 2) + 4 half + (e & 3))
+    pb_u32x4 gA = pb_u32x4{0u, 0u, 0u, 0u}, gT0 = gA, gT1 = gA;
     auto stage_g = [&](int h) {
       const int Cn = p.a.classes[h];
-      if (lane < 32) {
-        float gx = 0.f, gy = 0.f, gz = 0.f, sc = 0.f;
-        if (pair_ok) {
-          sc = p.a.scale[h];
-          const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
-          gx = dl[0];
-          if (Cn > 1) gy = dl[1];
-          if (Cn > 2) gz = dl[2];
-        }
-        // explicit wait: the compiler's counted vmcnt does not know about the LDS-DMA pieces in flight around these loads
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(sc) :: "memory");
-        gx *= sc; gy *= sc; gz *= sc;
-        float* gp = reinterpret_cast<float*>(sG + grp * 32) + (lane >> 1) * 8 + (lane & 1);
-        gp[0] = gx; gp[2] = gy; gp[4] = gz;
+      float gx = 0.f, gy = 0.f, gz = 0.f, sc = 0.f;
+      if (lane < 32 && pair_ok) {
+        sc = p.a.scale[h];
+        const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
+        gx = dl[0];
+        if (Cn > 1) gy = dl[1];
+        if (Cn > 2) gz = dl[2];
       }
+      // explicit wait: the compiler's counted vmcnt does not know about the LDS-DMA pieces in flight around these loads
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(sc) :: "memory");
+      gx *= sc; gy *= sc; gz *= sc;
+      gA = pb_u32x4{pack_bf16x2(gx, gy), pack_bf16x2(gz, 0.f), 0u, 0u};         // lanes >= 32 (k = 8..15) and bad pairs: zeros
+      float* gt = reinterpret_cast<float*>(sG + grp * 32);                        // [3][32] floats: g_c of pair
+      if (lane < 32) { gt[lane] = gx; gt[32 + lane] = gy; gt[64 + lane] = gz; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int c = r32;                                                          // class row of this lane in gT
+      float v[16];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e4 = 0; e4 < 2; ++e4) {
+          const float4 q = c < 3 ? *reinterpret_cast<const float4*>(gt + c * 32 + 16 * kk + 8 * e4 + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[8 * kk + 4 * e4 + 0] = q.x; v[8 * kk + 4 * e4 + 1] = q.y; v[8 * kk + 4 * e4 + 2] = q.z; v[8 * kk + 4 * e4 + 3] = q.w;
+        }
+      gT0 = pb_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      gT1 = pb_u32x4{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     };
-    const f2 one2 = f2{1.f, 1.f}, nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
-    const float4* myG = sG + grp * 32;
+    const f2 nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
     const bool odd = (lane & 1) != 0;
 
     // one producer iteration: Z(s+1) accumulates into zw (fragments hand-issued one chunk ahead, two register sets, each
@@ -820,8 +836,14 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       }
       float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (DOE) cw = sCol[s * 32 + r32];
-      const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
-      f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
+      const f2 b1 = f2{cw.w, cw.w};
+      // dy[pair, hid] = sum_c g[pair, c] W2[c, hid] on the matrix cores: B operand = this lane's column of W2 (k = class:
+      // lanes 0-31 hold (w0, w1, w2, 0 ...), lanes 32-63 the zero half), same accumulator layout as z
+      f32x16_t dy;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dy[r] = 0.f;
+      float sbx = 0.f, sby = 0.f;
+      float yv[16];
       auto issue = [&](auto jc, pb_u32x4 (&d_)[PB_MAXC]) {
         constexpr int J = decltype(jc)::value;
         constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
@@ -848,21 +870,15 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         if constexpr (DOE) {
           constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
           const int row0 = rowc + 4 * half;
-          const float4 g01 = myG[row0];
-          const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
-          const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
           const f2 zz = f2{zr[r0], zr[r0 + 1]} + b1;
           const f2 t = zz * nl2e;
-          const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
+          const f2 den = f2{__builtin_amdgcn_exp2f(t.x) + 1.f, __builtin_amdgcn_exp2f(t.y) + 1.f};
           const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
           const f2 y = zz * sg;
-          const f2 dy = fma2(g2, w2, fma2(g1, w1, g0 * w0));
-          // SiLU'(z) = sg (1 + z (1 - sg)) = sg + y (1 - sg) = (sg + y) - y sg
-          const f2 dzv = dy * fma2(f2{-y.x, -y.y}, sg, sg + y);
-          s0 = fma2(g0, y, s0);
-          s1 = fma2(g1, y, s1);
-          s2 = fma2(g2, y, s2);
-          sb = sb + dzv;
+          yv[r0] = y.x; yv[r0 + 1] = y.y;
+          // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
+          const f2 dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
+          sbx += dzv.x; sby += dzv.y;
           const float give = odd ? dzv.x : dzv.y;
           const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
           const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
@@ -876,7 +892,12 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       // the first chunk's fragments are in LDS since the barrier: their read latency runs under the LDS-DMA issue block,
       // the column-sum flush and the dlogits staging (`pre`)
       issue(std::integral_constant<int, 0>{}, fa);
-      pre();
+      pre();                          // (may stage the next head's dlogits: gA / gT change here)
+      if constexpr (DOE) {
+        const float m = half ? 0.f : 1.f;
+        const pb_u32x4 w2f = pb_u32x4{pack_bf16x2(cw.x * m, cw.y * m), pack_bf16x2(cw.z * m, 0.f), 0u, 0u};
+        pb_mma(gA, w2f, dy);
+      }
       landed(fa);
       chunk(std::integral_constant<int, 0>{}, fa, fb);
       chunk(std::integral_constant<int, 1>{}, fb, fa);
@@ -887,10 +908,18 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       chunk(std::integral_constant<int, 6>{}, fa, fb);
       chunk(std::integral_constant<int, 7>{}, fb, fa);
       if constexpr (DOE) {
-        float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
-        part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
-        part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
-        if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = part;
+        // dW2 sums out[c, hid] = sum_pair g[pair, c] y[pair, hid]: y as the B operand straight from its accumulator-layout
+        // registers (k = pairs in the order gT was built for); rows 0..2 of the result = registers 0..2 of lanes 0-31
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const pb_u32x4 y0 = pb_u32x4{pack_bf16x2(yv[0], yv[1]), pack_bf16x2(yv[2], yv[3]), pack_bf16x2(yv[4], yv[5]), pack_bf16x2(yv[6], yv[7])};
+        const pb_u32x4 y1 = pb_u32x4{pack_bf16x2(yv[8], yv[9]), pack_bf16x2(yv[10], yv[11]), pack_bf16x2(yv[12], yv[13]), pack_bf16x2(yv[14], yv[15])};
+        pb_mma(gT0, y0, acc);
+        pb_mma(gT1, y1, acc);
+        float sbt = sbx + sby;
+        sbt += __shfl_xor(sbt, 32);
+        if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = make_float4(acc[0], acc[1], acc[2], sbt);
       }
     };
     using yes = std::integral_constant<bool, true>;
