@@ -50,7 +50,7 @@ struct PackBwdSrc { const float* w1[PENEO_MAX_HEADS]; int num_heads; int D; };
 __global__ void pack_bwd_weights_kernel(PackBwdSrc s, bf16_t* out) {
   const int D = s.D, KS = D / 16;
   const int nslab = s.num_heads * D / 32;
-  const int64_t stride = (int64_t)2 * KS * 512;     // elements per slab
+  const int64_t stride = (int64_t)3 * KS * 512;     // elements per slab: z fragments | du fragments | z fragments, swizzled
   const int64_t total = (int64_t)nslab * stride;
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
     const int slab = (int)(q / stride);
@@ -58,7 +58,14 @@ __global__ void pack_bwd_weights_kernel(PackBwdSrc s, bf16_t* out) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), f = (int)(i >> 9);
     int row, col;                                   // element of W1cat [nh*D, D]
     if (f < KS) { row = slab * 32 + (lane & 31); col = 16 * f + 8 * (lane >> 5) + e; }
-    else { const int g = f - KS, dt = g >> 1, kk = g & 1; row = slab * 32 + 16 * kk + 8 * (lane >> 5) + e; col = 32 * dt + (lane & 31); }
+    else if (f < 2 * KS) { const int g = f - KS, dt = g >> 1, kk = g & 1; row = slab * 32 + 16 * kk + 8 * (lane >> 5) + e; col = 32 * dt + (lane & 31); }
+    else {
+      // third part (wave-specialised kernel): the z fragments again, 16-byte slot p of fragment ks holding the row
+      // n = (p & 31) ^ (4 h | 8 (ks & 1)), h = p >> 5: the same bytes serve z (one ds_read_b128 per lane, any slot order) and,
+      // read with ds_read_b64_tr_b16, the transposed du operand without bank conflicts
+      const int ks = f - 2 * KS, h = lane >> 5, n = (lane & 31) ^ (4 * h + 8 * (ks & 1));
+      row = slab * 32 + n; col = 16 * ks + 8 * h + e;
+    }
     const int h = row / D;
     out[q] = f32_to_bf16(s.w1[h][(int64_t)(row - h * D) * D + col]);
   }
@@ -187,10 +194,10 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBw
   const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (PW * 1024) + lane * 16;
   const uint32_t adst = lds_addr(sA) + wave * (PW * 1024), bdst = lds_addr(sB) + wave * (PW * 1024);
   auto dma_z = [&](int s) {    // z fragments of slab s -> sA[s & 1]
-    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (2 * HALF_BYTES), __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES));
+    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (3 * HALF_BYTES), __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES));
   };
   auto dma_u = [&](int s) {    // du fragments of slab s -> sB[s & 1]
-    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (2 * HALF_BYTES) + HALF_BYTES, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES));
+    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (3 * HALF_BYTES) + HALF_BYTES, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES));
   };
 
   float* slot = p.ws + (int64_t)(blockIdx.x % PB_SLOTS) * 4 * ncol;
@@ -370,10 +377,10 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBw
           if (q * 8 / (2 * PW) != J) continue;
           if (q < PW) {
             if (s >= 0 && s + 2 < nslab)
-              lds_dma_piece(wsrc + (int64_t)(s + 2) * (2 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES + q * 1024));
+              lds_dma_piece(wsrc + (int64_t)(s + 2) * (3 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES + q * 1024));
           } else {
             if (s >= 0 && s < nslab)
-              lds_dma_piece(wsrc + (int64_t)s * (2 * HALF_BYTES) + HALF_BYTES + (q - PW) * 1024, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES + (q - PW) * 1024));
+              lds_dma_piece(wsrc + (int64_t)s * (3 * HALF_BYTES) + HALF_BYTES + (q - PW) * 1024, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES + (q - PW) * 1024));
           }
         }
       }
@@ -610,8 +617,11 @@ __global__ __launch_bounds__(256) void pair_bwd_reduce_kernel(const float* part_
 // orders the weight ring orders that hand-off too.  With two waves on every SIMD the hardware overlaps the producer's
 // VALU-bound dz arithmetic with the consumer's MFMAs, and both roles fit 256 registers.
 //   iteration s = -1 .. nslab:   producer: Z(s+1) interleaved with E(s) -> tile[s & 1]     consumer: U(s-1) <- tile[(s-1) & 1]
-//   weight ring: z fragments of slab s+2 -> sA[s & 1], du fragments of slab s -> sB[s & 1], issued at the top of
-//   iteration s by all 8 waves (KS/4 pieces each), landed by the top of iteration s+1.
+//   weight ring: ONE copy of a slab's first-layer weights (its z fragments, 16-byte slots XOR-swizzled) serves both products:
+//   the producers read it with ds_read_b128, the consumers read the SAME bytes transposed (ds_read_b64_tr_b16) as the du
+//   operand.  Slab s lives in slot s & 3 of a four-slot ring; slab s+2 is issued at the top of iteration s by all 8 waves
+//   (KS/8 pieces each: an LDS-DMA piece costs its issuer hundreds of cycles once a few are in flight) and has landed by the
+//   top of iteration s+1.
 // Two rules this kernel obeys because two waves share each SIMD's matrix pipe (both found the hard way: sporadic wrong
 // 16-byte pieces of dz that vanished as soon as the partner wave issued no MFMAs):
 //   * nothing reads an MFMA accumulator shortly after the chain that wrote it: z is double buffered (Z(s+1) writes one
@@ -628,15 +638,15 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HALF_BYTES = KS * 1024;
   constexpr int NDT = KS / 2;
-  constexpr int NPIECE = 2 * KS;                             // 1 KiB pieces per iteration (both halves)
+  constexpr int NPIECE = KS;                                 // 1 KiB pieces per iteration: ONE copy of the slab's weights serves z and du
   constexpr int PPW = (NPIECE + PW_WAVES - 1) / PW_WAVES;    // pieces per wave
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave < 4;
   const int grp = wave & 3;                                  // pair group: rows 2 grp, 2 grp + 1 of the block
   const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
-  char* sA = smem;                                                          // [2][HALF_BYTES] z operands
-  float4* sCol = reinterpret_cast<float4*>(smem + 4 * HALF_BYTES);          // [ncol]   (sB = sA + 2 * HALF_BYTES)
+  char* sA = smem;                                                          // [4][HALF_BYTES] weight ring: slab s in slot s & 3
+  float4* sCol = reinterpret_cast<float4*>(smem + 4 * HALF_BYTES);          // [ncol]
   float4* sG = sCol + ncol;                                                 // [4][32]
   float4* sPart = sG + 4 * 32;                                              // [2][4][32]
   char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
@@ -669,18 +679,13 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   const uint32_t ring = lds_addr(sA);
   auto dma_z = [&](int slab, int q) {
     if (!(PB_ABLATE & 32))
-      lds_dma_1k<0>(wbase + (int64_t)slab * (2 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(ring + (slab & 1) * HALF_BYTES + q * 1024));
+      lds_dma_1k<0>(wbase + (int64_t)slab * (3 * HALF_BYTES) + 2 * HALF_BYTES + q * 1024, __builtin_amdgcn_readfirstlane(ring + (slab & 3) * HALF_BYTES + q * 1024));
   };
-  auto dma_u = [&](int slab, int q) {   // q in [KS, 2 KS)
-    if (!(PB_ABLATE & 48))
-      lds_dma_1k<0>(wbase + (int64_t)slab * (2 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(ring + (2 + (slab & 1)) * HALF_BYTES + (q - KS) * 1024));
-  };
-  auto dma_iter = [&](int s) {
+  auto dma_iter = [&](int s) {           // slab s+2 -> slot (s+2) & 3 (last read by U(s-2) during iteration s-1)
 #pragma unroll
     for (int k = 0; k < PPW; ++k) {
       const int q = wave + k * PW_WAVES;
-      if (q < KS) { if (s >= 0 && s + 2 < nslab) dma_z(s + 2, q); }
-      else if (q < NPIECE) { if (s >= 0 && s < nslab) dma_u(s, q); }
+      if (q < NPIECE && s >= 0 && s + 2 < nslab) dma_z(s + 2, q);
     }
   };
 #pragma unroll
@@ -824,7 +829,8 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
     // re-loaded only BEHIND the following chunk's MFMAs); E(s) reads zr (written during the previous iteration)
     auto iteration = [&](auto z_c, auto e_c, int s, f32x16_t& zr, f32x16_t& zw, auto pre) {
       constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value;
-      const uint32_t za = fbase + ((s + 1) & 1) * HALF_BYTES;
+      const uint32_t zs = ring + ((s + 1) & 3) * HALF_BYTES + half * 512;
+      const uint32_t za0 = zs + ((r32 ^ (4 * half)) << 4), za1 = zs + ((r32 ^ (4 * half + 8)) << 4);   // even / odd fragments
       char* myT = sT + ((s & 1) * 4 + grp) * 2048;
       pb_u32x4 fa[PB_MAXC], fb[PB_MAXC];
 #pragma unroll
@@ -849,9 +855,9 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
         static_assert(C <= PB_MAXC, "chunk too large");
         if constexpr (DOZ) {
-          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(d_[0], za);
-          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(d_[1], za);
-          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], za);
+          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(d_[0], ((F0 + 0) & 1) ? za1 : za0);
+          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(d_[1], ((F0 + 1) & 1) ? za1 : za0);
+          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], ((F0 + 2) & 1) ? za1 : za0);
         }
       };
       auto landed = [&](pb_u32x4 (&d_)[PB_MAXC]) {
@@ -966,49 +972,64 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       if (s >= 1) {
         const int u = s - 1;
         const uint32_t ta = lds_addr(sT + ((u & 1) * 4 + grp) * 2048) + r32 * 64;
-        const uint32_t ua = fbase + (2 + (u & 1)) * HALF_BYTES;
+        // du operand = the slab's z fragments read transposed (ds_read_b64_tr_b16: a 16-lane group reads a [4 hid][16 d] block,
+        // each lane 4 consecutive d of one hidden row, and receives 4 consecutive hidden units of one d).  Lane (g = lane >> 4,
+        // r = (lane & 15) >> 2, c = lane & 3): fragment ks' = 2 dt + (g & 1), k half hh = g >> 1, source half h = c >> 1,
+        // hidden row 16 kk + 8 hh + r (+ 4 for the second read), 8 bytes at (c & 1) * 8 of the swizzled slot.
+        const int g_ = lane >> 4, hh_ = g_ >> 1, rr_ = (lane & 15) >> 2, cc_ = lane & 3, h_ = cc_ >> 1;
+        const uint32_t ub = ring + (u & 3) * HALF_BYTES + (g_ & 1) * 1024 + ((h_ * 32 + 8 * (hh_ ^ (g_ & 1)) + rr_) << 4) + (cc_ & 1) * 8;
+        uint32_t ua0 = ub + (h_ ? 64 : 0), ua1 = ub + (h_ ? 0 : 64);
+        typedef __attribute__((ext_vector_type(2))) unsigned int pb_u32x2;
         pb_u32x4 a0, a1;
         asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(ta + (((0 + half) ^ t_swz) << 4)));
         asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(ta + (((2 + half) ^ t_swz) << 4)));
-        pb_u32x4 fa[PB_MAXC], fb[PB_MAXC];
+        pb_u32x2 la[PB_MAXC], ha[PB_MAXC], lb[PB_MAXC], hb[PB_MAXC];
 #pragma unroll
-        for (int i = 0; i < PB_MAXC; ++i) { fa[i] = pb_u32x4{0u, 0u, 0u, 0u}; fb[i] = fa[i]; }
-        auto uissue = [&](auto jc, pb_u32x4 (&d_)[PB_MAXC]) {
+        for (int i = 0; i < PB_MAXC; ++i) { la[i] = pb_u32x2{0u, 0u}; ha[i] = la[i]; lb[i] = la[i]; hb[i] = la[i]; }
+        auto trd = [ua0, ua1](auto off_c, pb_u32x2& lo, pb_u32x2& hi) {
+          constexpr int OFF = decltype(off_c)::value;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ua0), "n"(OFF));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ua1), "n"(OFF));
+        };
+        auto uissue = [&](auto jc, pb_u32x2 (&lo_)[PB_MAXC], pb_u32x2 (&hi_)[PB_MAXC]) {
           constexpr int J = decltype(jc)::value;
           constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
-          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(d_[0], ua);
-          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(d_[1], ua);
-          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], ua);
+          // fragment f = 2 dt + kk -> byte offset dt * 2048 + kk * 256
+          if constexpr (C > 0) trd(std::integral_constant<int, ((F0 + 0) >> 1) * 2048 + ((F0 + 0) & 1) * 256>{}, lo_[0], hi_[0]);
+          if constexpr (C > 1) trd(std::integral_constant<int, ((F0 + 1) >> 1) * 2048 + ((F0 + 1) & 1) * 256>{}, lo_[1], hi_[1]);
+          if constexpr (C > 2) trd(std::integral_constant<int, ((F0 + 2) >> 1) * 2048 + ((F0 + 2) & 1) * 256>{}, lo_[2], hi_[2]);
         };
-        auto ulanded = [&](pb_u32x4 (&d_)[PB_MAXC]) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]), "+v"(a0), "+v"(a1) :: "memory");
+        auto ulanded = [&](pb_u32x2 (&lo_)[PB_MAXC], pb_u32x2 (&hi_)[PB_MAXC]) {
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(lo_[0]), "+v"(lo_[1]), "+v"(lo_[2]), "+v"(hi_[0]), "+v"(hi_[1]), "+v"(hi_[2]), "+v"(a0), "+v"(a1) :: "memory");
           __builtin_amdgcn_sched_barrier(0);
         };
-        auto uchunk = [&](auto jc, pb_u32x4 (&cur)[PB_MAXC], pb_u32x4 (&nxt)[PB_MAXC]) {
+        auto uchunk = [&](auto jc, pb_u32x2 (&clo)[PB_MAXC], pb_u32x2 (&chi)[PB_MAXC], pb_u32x2 (&nlo)[PB_MAXC], pb_u32x2 (&nhi)[PB_MAXC]) {
           constexpr int J = decltype(jc)::value;
           constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
           if constexpr (!(PB_ABLATE & 2)) {
-            if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, cur[0], du[(F0 + 0) >> 1]);
-            if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, cur[1], du[(F0 + 1) >> 1]);
-            if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, cur[2], du[(F0 + 2) >> 1]);
+            // the 4-register operands are put together AFTER the wait (a copy made before it would copy stale registers)
+            if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, pb_u32x4{clo[0].x, clo[0].y, chi[0].x, chi[0].y}, du[(F0 + 0) >> 1]);
+            if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, pb_u32x4{clo[1].x, clo[1].y, chi[1].x, chi[1].y}, du[(F0 + 1) >> 1]);
+            if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, pb_u32x4{clo[2].x, clo[2].y, chi[2].x, chi[2].y}, du[(F0 + 2) >> 1]);
           }
-          if constexpr (J + 1 < 8) { uissue(std::integral_constant<int, J + 1>{}, nxt); ulanded(nxt); }
+          if constexpr (J + 1 < 8) { uissue(std::integral_constant<int, J + 1>{}, nlo, nhi); ulanded(nlo, nhi); }
         };
-        uissue(std::integral_constant<int, 0>{}, fa);
+        uissue(std::integral_constant<int, 0>{}, la, ha);
         dma_iter(s);                 // under the latency of the reads just issued
-        ulanded(fa);
+        ulanded(la, ha);
         if constexpr (!(PB_ABLATE & 1)) {
           *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
           *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
         }
-        uchunk(std::integral_constant<int, 0>{}, fa, fb);
-        uchunk(std::integral_constant<int, 1>{}, fb, fa);
-        uchunk(std::integral_constant<int, 2>{}, fa, fb);
-        uchunk(std::integral_constant<int, 3>{}, fb, fa);
-        uchunk(std::integral_constant<int, 4>{}, fa, fb);
-        uchunk(std::integral_constant<int, 5>{}, fb, fa);
-        uchunk(std::integral_constant<int, 6>{}, fa, fb);
-        uchunk(std::integral_constant<int, 7>{}, fb, fa);
+        uchunk(std::integral_constant<int, 0>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 1>{}, lb, hb, la, ha);
+        uchunk(std::integral_constant<int, 2>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 3>{}, lb, hb, la, ha);
+        uchunk(std::integral_constant<int, 4>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 5>{}, lb, hb, la, ha);
+        uchunk(std::integral_constant<int, 6>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 7>{}, lb, hb, la, ha);
       }
     }
     report();
@@ -1102,7 +1123,7 @@ extern "C" int peneo_pair_bwd_supported(int dtype, int D) {
 
 extern "C" int64_t peneo_pair_bwd_rows(int N) { return N > 0 ? (int64_t)pb_num_tiles(N) * PB_ROWS : 0; }
 
-extern "C" size_t peneo_pair_bwd_packed_bytes(int num_heads, int D) { return (size_t)(num_heads * D / 32) * 2 * (D / 16) * 1024; }
+extern "C" size_t peneo_pair_bwd_packed_bytes(int num_heads, int D) { return (size_t)(num_heads * D / 32) * 3 * (D / 16) * 1024; }
 
 extern "C" int peneo_pair_bwd_pack(const float* const* w1, int num_heads, int D, void* packed, peneo_stream_t stream) {
   PENEO_REQUIRE(w1 && packed && num_heads > 0 && num_heads <= PENEO_MAX_HEADS && D % 32 == 0, "peneo_pair_bwd_pack: bad arguments");
