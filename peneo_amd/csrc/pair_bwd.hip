@@ -681,10 +681,13 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
     if (!(PB_ABLATE & 32))
       lds_dma_1k<0>(wbase + (int64_t)slab * (3 * HALF_BYTES) + 2 * HALF_BYTES + q * 1024, __builtin_amdgcn_readfirstlane(ring + (slab & 3) * HALF_BYTES + q * 1024));
   };
+  // the consumer waves carry the weight stream (the producers' instruction stream is the critical path, tools/pb_cycles.py)
+  constexpr int PPC = (NPIECE + 3) / 4;
   auto dma_iter = [&](int s) {           // slab s+2 -> slot (s+2) & 3 (last read by U(s-2) during iteration s-1)
+    if (wave < 4) return;
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) {
-      const int q = wave + k * PW_WAVES;
+    for (int k = 0; k < PPC; ++k) {
+      const int q = (wave - 4) + k * 4;
       if (q < NPIECE && s >= 0 && s + 2 < nslab) dma_z(s + 2, q);
     }
   };
