@@ -85,7 +85,6 @@ struct PairBwdParams {
 // hand-issued fragment reads (the compiler would wait for every ds_read right in front of its MFMA: with one wave per SIMD
 // nothing else covers that latency).  The reader owns lgkmcnt: pb_lgkm0 waits and ties the fragment registers to the wait.
 typedef __attribute__((ext_vector_type(4))) unsigned int pb_u32x4;
-__device__ __forceinline__ void lds_dma_piece(const char* gsrc_lane, uint32_t lds_base_uniform) { lds_dma_1k<0>(gsrc_lane, lds_base_uniform); }
 template <int OFF> __device__ __forceinline__ void pb_dsr(pb_u32x4& d, uint32_t a) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
 }
@@ -102,9 +101,6 @@ constexpr int PB_MAXC = 3;   // fragments per chunk (KS = 24)
 
 #ifndef PB_DBG
 #define PB_DBG 0      // tools/ab_pb_dbg.sh: 65536 = packed-fp32 dz arithmetic in the wave-specialised kernel (reproduces the corruption)
-#endif
-#ifndef PB_OPT
-#define PB_OPT 1      // 1: tile store behind the chunk's wait, 2: LDS-DMA pieces spread over the chunks (measured slower; and racy)
 #endif
 #ifndef PB_ABLATE
 #define PB_ABLATE 0   // timing experiments (tools/): 1 no dz stores, 2 no du MFMAs, 4 no z MFMAs, 8 no epilogue, 16 no du-half DMA, 32 no DMA (ws kernel)
@@ -367,24 +363,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBw
     // DMA: z fragments of slab s+2 and du fragments of slab s are issued at the top of iteration s; both have a whole
     // iteration to land.
     const uint32_t fbase = lds_addr(sA) + lane * 16;                 // sB = sA + 2 * HALF_BYTES
-    // the 2 * PW pieces a wave contributes per iteration (z fragments of slab s+2, du fragments of slab s), dealt to the
-    // 8 chunks: piece q goes to chunk q * 8 / (2 PW)
-    auto dma_chunk = [&](auto jc, int s) {
-      constexpr int J = decltype(jc)::value;
-      if (wave < DMA_WAVES) {
-#pragma unroll
-        for (int q = 0; q < 2 * PW; ++q) {
-          if (q * 8 / (2 * PW) != J) continue;
-          if (q < PW) {
-            if (s >= 0 && s + 2 < nslab)
-              lds_dma_piece(wsrc + (int64_t)(s + 2) * (3 * HALF_BYTES) + q * 1024, __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES + q * 1024));
-          } else {
-            if (s >= 0 && s < nslab)
-              lds_dma_piece(wsrc + (int64_t)s * (3 * HALF_BYTES) + HALF_BYTES + (q - PW) * 1024, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES + (q - PW) * 1024));
-          }
-        }
-      }
-    };
     auto iteration = [&](auto z_c, auto e_c, auto u_c, int s) {
       constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value, DOU = decltype(u_c)::value;
       const uint32_t za = fbase + ((s + 1) & 1) * HALF_BYTES;
@@ -450,9 +428,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBw
           if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, cu[1], du[(F0 + 1) >> 1]);
           if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, cu[2], du[(F0 + 2) >> 1]);
         }
-        // (b) this chunk's share of the weight stream (an LDS-DMA piece costs 60-180 cycles of issue: in the shadow of the
-        //     MFMAs, not in a block behind the barrier), then the fragment reads of the next chunk
-        if constexpr (PB_OPT & 2) dma_chunk(std::integral_constant<int, J>{}, s);
+        // (b) fragment reads of the next chunk
         if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{}, xz, xu);
         // (c) dz arithmetic of accumulator registers 2J, 2J+1 in the shadow of the MFMAs
         if constexpr (DOE) {
@@ -476,17 +452,11 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBw
           const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
           const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
           packed_out = packed;
-          if constexpr (!(PB_OPT & 1)) {
-            const int trow = rowc + 4 * half + (lane & 1);
-            const int boff = (r32 & ~1) * 2;
-            const int f = ((rowc >> 2) + half) & 3;
-            *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed_out;
-          }
         }
         // (d) everything this chunk put on the LDS queue so far is done (the next chunk's fragments among it); the tile
         // store goes out BEHIND the wait: its round trip is covered by the next chunk instead of being waited for here
         if constexpr (J + 1 < 8) landed(xz, xu);
-        if constexpr (DOE && (PB_OPT & 1)) {
+        if constexpr (DOE) {
           constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
           const int trow = rowc + 4 * half + (lane & 1);
           const int boff = (r32 & ~1) * 2;
@@ -514,10 +484,9 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBw
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // column sums are flushed by another wave
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(PB_OPT & 2)) {
-        if (s >= 0 && s + 2 < nslab) dma_z(s + 2);
-        if (s >= 0 && s < nslab) dma_u(s);
-      }
+      // (spreading these pieces over the chunks of the iteration was slower and gave wrong last slabs: DESIGN.md §12)
+      if (s >= 0 && s + 2 < nslab) dma_z(s + 2);
+      if (s >= 0 && s < nslab) dma_u(s);
       if (s >= 1) flush(s - 1);                               // column sums of E(s-1), written before this barrier
       if (s >= 0 && s < nslab && s % spb == 0) stage_g(s / spb);
     };
