@@ -149,7 +149,9 @@ def side_stream(device, role: str) -> "torch.cuda.Stream":
 # the main stream.  Anything that reads gradients on the main stream before the backward has ended (the data-parallel
 # wrapper's early pack) calls join_pending() first.
 _PENDING: list = []
+_PENDING_HELD: list = []     # joins that only the end of the backward (or join_pending) waits for
 _CALLBACK_ARMED = [False]
+DEFER_ALLOWED = [True]       # False: every stage joins its side stream before it returns (torch DDP reads .grad in hooks)
 
 
 def _end_of_backward_join() -> None:
@@ -157,18 +159,22 @@ def _end_of_backward_join() -> None:
     join_pending()
 
 
-def defer_join(side: "torch.cuda.Stream", keep=()) -> None:
+def defer_join(side: "torch.cuda.Stream", keep=(), hold: bool = False) -> None:
     """Record `side`'s progress; waits for the events left by EARLIER stages (they are long complete) on the current stream.
     `keep`: tensors the side stream is still reading; they were allocated on the main stream, so they must stay referenced
-    until the join (the caching allocator would hand their memory to the next main-stream allocation otherwise)."""
-    older = list(_PENDING)
-    _PENDING.clear()
+    until the join (the caching allocator would hand their memory to the next main-stream allocation otherwise).
+    `hold`: long side work (the decoder's dW1 GEMM) that later stages must NOT wait for: joined by join_pending() only."""
     ev = torch.cuda.Event()
     ev.record(side)
-    _PENDING.append((ev, tuple(keep)))
-    main = torch.cuda.current_stream()
-    for e, _ in older:
-        main.wait_event(e)
+    if hold:
+        _PENDING_HELD.append((ev, tuple(keep)))
+    else:
+        older = list(_PENDING)
+        _PENDING.clear()
+        _PENDING.append((ev, tuple(keep)))
+        main = torch.cuda.current_stream()
+        for e, _ in older:
+            main.wait_event(e)
     if not _CALLBACK_ARMED[0]:
         _CALLBACK_ARMED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
@@ -177,5 +183,6 @@ def defer_join(side: "torch.cuda.Stream", keep=()) -> None:
 def join_pending() -> None:
     """Make the current stream wait for every deferred side-stream event."""
     main = torch.cuda.current_stream()
-    while _PENDING:
-        main.wait_event(_PENDING.pop()[0])
+    for pending in (_PENDING, _PENDING_HELD):
+        while pending:
+            main.wait_event(pending.pop()[0])

@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import ops
 from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
 from .configuration_peneo import LayoutLMv3Config
-from .engine import DropoutSeeds, WeightCache, defer_join, join_pending, zeros_like_param, zeros_like_params
+from .engine import DEFER_ALLOWED, DropoutSeeds, WeightCache, defer_join, join_pending, zeros_like_param, zeros_like_params
 from .engine import side_stream as engine_side_stream
 from .relpos import bucket_lut, visual_xy
 
@@ -430,7 +430,7 @@ class _LayerStage(torch.autograd.Function):
         _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
         if side is not None:
-            if model.defer_wgrad_join and all(p.grad is None for p in ctx.params):
+            if model.defer_wgrad_join and DEFER_ALLOWED[0] and all(p.grad is None for p in ctx.params):
                 # joined one stage later (engine.py): the critical path does not wait for dW_qkv
                 defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x))
             else:

@@ -26,7 +26,7 @@ from .. import ops
 from ..hip import ACT_GELU, PeneoHipError
 from .configuration_peneo import LiltConfig
 from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
-from .engine import defer_join, join_pending
+from .engine import DEFER_ALLOWED, defer_join, join_pending
 from .engine import side_stream as engine_side_stream
 
 
@@ -307,7 +307,7 @@ class _LiltLayerStage(torch.autograd.Function):
         dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_x_res)
         d_l = ops.gemm(dlqkv, Wlqkv, b_kmajor=False, residual=d_l_res)
-        if os.environ.get("PENEO_DEFER_JOIN", "1") != "0" and all(p.grad is None for p in ctx.params):
+        if os.environ.get("PENEO_DEFER_JOIN", "1") != "0" and DEFER_ALLOWED[0] and all(p.grad is None for p in ctx.params):
             defer_join(side, keep=kept)   # joined one stage later: the critical path does not wait for the QKV wgrads (engine.py)
         else:
             main.wait_stream(side)

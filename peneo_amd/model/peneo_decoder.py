@@ -21,7 +21,7 @@ from transformers.modeling_outputs import ModelOutput
 
 from .. import ops
 from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
-from .engine import DropoutSeeds, WeightCache, defer_join
+from .engine import DEFER_ALLOWED, DropoutSeeds, WeightCache, defer_join
 
 HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
@@ -289,8 +289,17 @@ class _DecoderStage(torch.autograd.Function):
                 ev.record(main)
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
-                ctx.side_work = (side, (dzbuf, xbuf1, dW1cat, ab))
+                    # few, long workgroups: the split a GEMM gets when it runs alone fills all 512 resident slots, and the
+                    # main stream's kernels then find no CU to be dispatched to until it ends (measured: the stage after the
+                    # decoder stood still for 1.8 ms).  About one workgroup on every second CU runs ~7 ms beside the whole
+                    # encoder backward instead and is joined when the backward ends (split 11 / 7 / 5 / 4 / 3: 18.56 /
+                    # 18.79 / 18.34 / 18.16 / 18.10 ms per step on one box).
+                    # Only when the join can wait for the end of the backward (fresh .grad tensors, no DDP hooks reading them).
+                    can_hold = dec.dw1_hold and DEFER_ALLOWED[0] and all(p.grad is None for p in params)
+                    split = None if not can_hold else \
+                        dec.dw1_side_split or max(1, dec.dw1_side_wgs // (-(-nh * D // 128) * -(-D // 128)))
+                    ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat, split_k=split)
+                ctx.side_work = (side, (dzbuf, xbuf1, dW1cat, ab), can_hold)
             else:
                 ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
             chunks = []
@@ -429,10 +438,10 @@ class _DecoderStage(torch.autograd.Function):
         grads = tuple(g if p.requires_grad else None for g, p in zip(grads, params))
         side_work = getattr(ctx, "side_work", None)
         if side_work is not None:
-            side, keep = side_work
+            side, keep, can_hold = side_work
             ctx.side_work = None
-            if all(p.grad is None for p in params):
-                defer_join(side, keep=keep)
+            if DEFER_ALLOWED[0] and all(p.grad is None for p in params):
+                defer_join(side, keep=keep, hold=can_hold)
             else:
                 torch.cuda.current_stream().wait_stream(side)
         return (None, d_seq, None, None, None, None, None) + grads
@@ -493,6 +502,9 @@ class PEneoDecoder(nn.Module):
         self.fused_dz = os.environ.get("PENEO_DZ_FUSED", "1") != "0"            # bf16: dz without x / z in memory
         self.fused_bwd = os.environ.get("PENEO_BWD_FUSED", "1") != "0"          # bf16: the whole pair-space backward in one kernel
         self.dw1_on_side = os.environ.get("PENEO_DW1_SIDE", "1") != "0"          # its dW1 GEMM beside the following stages
+        self.dw1_hold = os.environ.get("PENEO_DW1_HOLD", "1") != "0"             # ... joined at the end of the backward only
+        self.dw1_side_split = int(os.environ.get("PENEO_DW1_SPLIT", "0"))        # fixed split-k of that GEMM; 0: from the target
+        self.dw1_side_wgs = int(os.environ.get("PENEO_DW1_WGS", "144"))          # ... of about this many workgroups
         self._ratio = {}
 
     def stacked_combine_weight(self, wc_w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
@@ -527,6 +539,12 @@ class PEneoDecoder(nn.Module):
         tags = [line_extraction_shaking_tag, ent_linking_head_rel_shaking_tag, ent_linking_tail_rel_shaking_tag,
                 line_grouping_head_rel_shaking_tag, line_grouping_tail_rel_shaking_tag]
         P = N * (N + 1) // 2
+        if all(t is None for t in tags) and not self.inference_mode and "line_extraction_matrix_spots" in kwargs:
+            # sparse labels of DataCollatorForPEneo(sparse_tags=True): (b, i, j, tag) rows, scattered on the device
+            assert kwargs.get("shaking_seq_len", N) == N, "spots were collated for another padded length"
+            tags = [ops.spots_to_tags(kwargs[f"{k}_matrix_spots"], N, sequence_output.device, B=B)
+                    for k in ("line_extraction", "ent_linking_head_rel", "ent_linking_tail_rel", "line_grouping_head_rel",
+                              "line_grouping_tail_rel")]
         if all(t is not None for t in tags):
             for t in tags:
                 assert t.shape == (B, P), f"label map shape {tuple(t.shape)} != {(B, P)}"

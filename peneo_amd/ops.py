@@ -667,14 +667,22 @@ def spots_compact(logits: torch.Tensor, N: int, max_spots: int = 4096):
     return spots[:n], scores[:n]
 
 
-def spots_to_tags(batch_spots, N: int, device) -> torch.Tensor:
-    """[[(i, j, tag), ...] per document] -> dense label maps [B, P] int64 built on the device (K13 input side)."""
-    B = len(batch_spots)
-    flat = [(b, int(sp[0]), int(sp[1]), int(sp[2])) for b, spots in enumerate(batch_spots) for sp in spots]
+def spots_to_tags(batch_spots, N: int, device, B: int = None) -> torch.Tensor:
+    """Sparse spots -> dense label maps [B, P] int64 built on the device (K13 input side).  ``batch_spots``: a list with
+    one [(i, j, tag), ...] list per document, or an int32 tensor [n, 4] of (b, i, j, tag) rows (then ``B`` is required;
+    what ``DataCollatorForPEneo(sparse_tags=True)`` ships)."""
+    if torch.is_tensor(batch_spots):
+        assert B is not None and batch_spots.dim() == 2 and batch_spots.shape[1] == 4
+        n = batch_spots.shape[0]
+        sp = batch_spots.to(device=device, dtype=torch.int32).contiguous() if n else None
+    else:
+        B = len(batch_spots)
+        flat = [(b, int(sp[0]), int(sp[1]), int(sp[2])) for b, spots in enumerate(batch_spots) for sp in spots]
+        n = len(flat)
+        sp = torch.tensor(flat, dtype=torch.int32).view(-1, 4).to(device) if flat else None
     tags = torch.empty((B, N * (N + 1) // 2), dtype=torch.int64, device=device)
     status = torch.zeros(1, dtype=torch.int32, device=device)
-    sp = torch.tensor(flat, dtype=torch.int32).view(-1, 4).to(device) if flat else None
-    check(lib().peneo_spots_to_tags(ptr(sp), len(flat), B, N, ptr(tags), ptr(status), stream()), "peneo_spots_to_tags")
-    if flat and int(status) != 0:
+    check(lib().peneo_spots_to_tags(ptr(sp), n, B, N, ptr(tags), ptr(status), stream()), "peneo_spots_to_tags")
+    if n and int(status) != 0:
         raise IndexError("spot outside the [0, N) x [0, N) pair matrix")
     return tags

@@ -192,6 +192,8 @@ def wrap_data_parallel(model: torch.nn.Module, device_ids=None, bucket_cap_mb: i
     if impl == "flat":
         return FlatGradDataParallel(model, compress=compress)
     from torch.nn.parallel import DistributedDataParallel as DDP
+    from .model.engine import DEFER_ALLOWED
+    DEFER_ALLOWED[0] = False    # DDP's hooks read .grad on the main stream as soon as autograd stores it: no deferred joins
     ddp = DDP(model, device_ids=device_ids, broadcast_buffers=False, gradient_as_bucket_view=True,
               bucket_cap_mb=bucket_cap_mb, find_unused_parameters=False)
     if compress == "bf16" and dist.get_backend() == "nccl":

@@ -1,0 +1,260 @@
+"""BASELINE config 1 (RFUND json -> dataset -> collator -> model -> decode -> metric) against the reference's own output on the
+synthetic two-page data set of tests/golden/rfund/ (made by tests/golden/make_rfund_fixture.py by importing the reference).
+
+CPU part: every host stage is compared with what the reference produced from the same files — dataset items (three flag sets,
+one with box jitter under the same ``random.seed``), the collated batch (tensors, label maps, the image tensor), the four
+tokenizer fetchers, the metric functions on the reference's decode results.  GPU part: the tiny PEneo the reference trained on
+the two pages runs through ``prediction_loop`` on the HIP path and must reproduce the reference's spots, key/value pairs and
+metrics (indices bit-exact, losses to 1e-4, logits to 1e-3)."""
+import os
+import random
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "golden", "rfund")
+TAGS = ("line_extraction", "ent_linking_head_rel", "ent_linking_tail_rel", "line_grouping_head_rel", "line_grouping_tail_rel")
+HEADS = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return torch.load(os.path.join(HERE, "golden", "rfund_plumbing.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="module")
+def tok():
+    from transformers import PreTrainedTokenizerFast
+    return PreTrainedTokenizerFast(tokenizer_file=os.path.join(ROOT, "tokenizer", "tokenizer.json"), bos_token="<s>",
+                                   eos_token="</s>", cls_token="<s>", sep_token="</s>", pad_token="<pad>",
+                                   unk_token="<unk>", mask_token="<mask>")
+
+
+def _dataset(tok, split, backbone, **kw):
+    from peneo_amd.data import RFUNDDataset
+    from peneo_amd.model.backbone_mapping import BACKBONE_MAPPING
+    info = BACKBONE_MAPPING[backbone]
+    return RFUNDDataset(data_root=ROOT, split=split, language="en", tokenizer=tok, tokenizer_fetcher=info.tokenizer_fetcher,
+                        max_token_len=info.max_token_len, add_cls_token=info.add_cls_token,
+                        add_sep_token=info.add_sep_token, **kw), info
+
+
+def _same_item(mine: dict, ref: dict):
+    assert list(mine.keys()) == list(ref.keys())
+    for k in ref:
+        if k == "image_path":
+            assert os.path.basename(mine[k]) == os.path.basename(ref[k])
+        elif k.endswith("_spots"):
+            assert [tuple(s) for s in mine[k]] == [tuple(s) for s in ref[k]], k
+        else:
+            assert mine[k] == ref[k], k
+
+
+def test_dataset_items_match_reference(fx, tok):
+    ds, _ = _dataset(tok, "dev", "layoutlmv3-base")
+    assert len(ds) == len(fx["items"]) == 2
+    for k in range(len(ds)):
+        _same_item(ds[k], fx["items"][k])
+    # the long page ran into the token budget (cut-off branch), the short one did not
+    assert len(fx["items"][0]["input_ids"]) >= 500 and len(fx["items"][1]["input_ids"]) < 200
+    # tag-2 (backward) links exist on the short page, so that branch is pinned too
+    assert any(s[2] == 2 for s in fx["items"][1]["ent_linking_head_rel_matrix_spots"])
+    assert any(s[2] == 2 for s in fx["items"][1]["line_grouping_head_rel_matrix_spots"])
+
+
+def test_dataset_box_jitter_matches_reference_under_the_same_seed(fx, tok):
+    random.seed(1234)
+    ds, _ = _dataset(tok, "train", "layoutlmv3-base", apply_box_aug=True)
+    for k in range(len(ds)):
+        _same_item(ds[k], fx["items_boxaug"][k])
+    assert fx["items_boxaug"][1]["orig_bbox"] != fx["items"][1]["orig_bbox"]
+
+
+def test_dataset_items_lilt_roberta_flags(fx, tok):
+    ds, info = _dataset(tok, "test", "lilt-roberta-en-base")
+    assert (info.add_cls_token, info.add_sep_token, info.max_token_len) == (True, False, 511)
+    for k in range(len(ds)):
+        _same_item(ds[k], fx["items_roberta"][k])
+
+
+def _dense(t):
+    if isinstance(t, dict):
+        out = torch.zeros(t["shape"], dtype=torch.int64)
+        out[t["index"][:, 0], t["index"][:, 1]] = t["value"]
+        return out
+    return t
+
+
+def _same_batch(mine: dict, ref: dict, image_tol: float = 0.0):
+    assert set(mine.keys()) == set(ref.keys())
+    for k, want in ref.items():
+        got = mine[k]
+        if k == "image":
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert float((got - want).abs().max()) <= image_tol, float((got - want).abs().max())
+        elif k == "image_path":
+            assert [os.path.basename(p) for p in got] == [os.path.basename(p) for p in want]
+        elif torch.is_tensor(want) or isinstance(want, dict):
+            want = _dense(want)
+            assert got.dtype == want.dtype and got.shape == want.shape, k
+            assert torch.equal(got, want), k
+        else:
+            assert got == want, k
+
+
+def test_collator_batch_matches_reference(fx, tok):
+    from peneo_amd.data import DataCollatorForPEneo, PEneoImageProcessor
+    coll = DataCollatorForPEneo(tokenizer=tok, image_processor=PEneoImageProcessor(), max_length=510, require_image=True,
+                                add_cls_token=True, add_sep_token=True)
+    items = [dict(it, image_path=os.path.join(ROOT, "images", "en", it["fname"])) for it in fx["items"]]
+    batch = coll(items)
+    _same_batch(batch, fx["batch"], image_tol=1e-6)
+    assert batch["input_ids"].shape == (2, 512) and batch["line_extraction_shaking_tag"].shape == (2, 511 * 512 // 2)
+    assert int(batch["attention_mask"][1].sum()) == len(fx["items"][1]["input_ids"])
+
+
+def test_collator_max_length_padding(fx, tok):
+    from peneo_amd.data import DataCollatorForPEneo
+    coll = DataCollatorForPEneo(tokenizer=tok, image_processor=None, padding="max_length", max_length=520,
+                                pad_to_multiple_of=16, require_image=False, add_cls_token=True, add_sep_token=False)
+    batch = coll([dict(it) for it in fx["items_roberta"]])
+    _same_batch(batch, fx["batch_roberta_maxlen"])
+    assert batch["input_ids"].shape[1] == 528
+
+
+def test_collator_sparse_tags_hold_the_same_spots(fx, tok):
+    from peneo_amd.data import DataCollatorForPEneo
+    from peneo_amd.model.peneo_decoder import HandshakingTaggingScheme
+    coll = DataCollatorForPEneo(tokenizer=tok, require_image=False, sparse_tags=True)
+    batch = coll([dict(it) for it in fx["items"]])
+    N = batch["shaking_seq_len"]
+    assert N == 511
+    for k in TAGS:
+        rows = batch[k + "_matrix_spots"]
+        assert rows.dtype == torch.int32 and rows.shape[1] == 4
+        per_doc = [[tuple(r[1:].tolist()) for r in rows if int(r[0]) == b] for b in range(2)]
+        dense = HandshakingTaggingScheme.spots2shaking_tag4batch(per_doc, seq_len=N)
+        assert torch.equal(dense, _dense(fx["batch"][k + "_shaking_tag"]))
+        assert k + "_shaking_tag" not in batch
+
+
+def test_tokenizer_fetchers_match_reference(fx):
+    from peneo_amd.model import tokenizer_fetchers as tf
+    fns = {"roberta": tf.fetcher_RobertaTokenizer, "layoutlmv3": tf.fetcher_LayoutLMv3Tokenizer,
+           "layoutlmv2": tf.fetcher_LayoutLMv2Tokenizer, "xlm": tf.fetcher_XLMTokenizer}
+    n = 0
+    for name, rows in fx["fetchers"].items():
+        for text, tokens, want in rows:
+            if want == "IndexError":
+                with pytest.raises(IndexError):
+                    fns[name](text, list(tokens))
+            else:
+                assert fns[name](text, list(tokens)) == want, (name, text)
+                if want:
+                    assert "".join(want) == (text if name != "layoutlmv2" else text.translate(tf._ACCENT_FOLD)) or name == "xlm"
+            n += 1
+    assert n >= 20
+
+
+def test_image_processor_matches_hf_layoutlmv3_processor(fx):
+    from PIL import Image
+    from peneo_amd.data import PEneoImageProcessor
+    ims = [Image.open(os.path.join(ROOT, "images", "en", f)) for f in fx["batch"]["fname"]]
+    got = PEneoImageProcessor()(ims, return_tensors="pt")["pixel_values"]
+    assert got.shape == (2, 3, 224, 224) and got.dtype == torch.float32
+    assert float((got - fx["batch"]["image"]).abs().max()) <= 1e-6
+
+
+def test_metrics_match_reference_on_its_decode_results(fx):
+    from peneo_amd.pipeline import calculate_detail_KVPE_metric, calculate_KVPE_metric
+    ev = fx["eval"]
+    d = ev["decode"]
+    metric, detail = calculate_KVPE_metric(d["pred"], d["gt"], d["fname"])
+    assert metric == ev["metric"] and detail == ev["metric_detail"]
+    metric, detail = calculate_detail_KVPE_metric(d["pred"], d["gt"], d["fname"])
+    assert metric == ev["detail_metric"] and detail == ev["detail_metric_detail"]
+    assert list(metric.keys()) == list(ev["detail_metric"].keys())
+    # the fixture is not degenerate: the trained tiny model finds pairs, and not all of them
+    assert ev["metric"]["f1"] > 0.3 and sum(len(p[0]) for p in d["pred"]) > 0
+    # duplicated file names (a distributed sampler's padding) are counted once
+    m2, d2 = calculate_KVPE_metric(d["pred"] + d["pred"][:1], d["gt"] + d["gt"][:1], d["fname"] + d["fname"][:1])
+    assert m2 == ev["metric"] and d2["num_sample_processed"] == 2
+
+
+def test_decode_on_reference_logit_spots_gives_reference_pairs(fx):
+    """The graph walk on the reference's own spot lists (no model involved)."""
+    from peneo_amd.pipeline.decode import sample_decode_peneo
+    from peneo_amd.model.peneo_decoder import HandshakingTaggingScheme
+    ev = fx["eval"]
+    tagger = HandshakingTaggingScheme()
+    tags = [_dense(fx["batch"][k + "_shaking_tag"]) for k in TAGS]
+    for b in range(2):
+        gt = sample_decode_peneo(tagger, fx["batch"]["text"][b], *[t[b] for t in tags], seq_len=511, decode_gt=True)
+        assert gt == ev["decode"]["gt"][b]
+        # the page's key/value strings (dataset: joined entity texts) come back out of the label maps + token substrings:
+        # all of them on the short page; on the long page only those whose lines all fit under the token budget
+        want = {(r["key"], r["value"]) for r in fx["batch"]["relations"][b]}
+        got = set(gt[0])
+        assert got == want if b == 1 else (got <= want and len(got) >= 1), (b, got ^ want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_config1_end_to_end_on_the_hip_path(fx, tok):
+    from torch.utils.data import DataLoader
+    from peneo_amd.data import DataCollatorForPEneo, PEneoImageProcessor
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    from peneo_amd.pipeline import make_compute_metrics, prediction_loop
+
+    dev = torch.device("cuda:0")
+    ds, info = _dataset(tok, "dev", "layoutlmv3-base")
+    coll = DataCollatorForPEneo(tokenizer=tok, image_processor=info.image_processor(), max_length=info.max_token_len,
+                                require_image=info.image_processor is not None, add_cls_token=info.add_cls_token,
+                                add_sep_token=info.add_sep_token)
+    cfg = PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"})
+    model = PEneoModel(cfg)
+    missing = model.load_state_dict(fx["state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.to(dev).set_compute_dtype(torch.float32).eval()
+    ev = fx["eval"]
+
+    # model outputs on the collated batch against the reference's
+    batch = coll([ds[0], ds[1]])
+    with torch.no_grad():
+        out = model(**{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()})
+    for k, want in ev["losses"].items():
+        assert abs(float(out[k]) - float(want)) <= 1e-4, (k, float(out[k]), float(want))
+    assert torch.equal(out.orig_bbox.cpu(), ev["orig_bbox"])
+    from peneo_amd.model.peneo_decoder import HandshakingTaggingScheme
+    for h in HEADS:
+        lg = out[h + "_shaking_outputs"]
+        s = ev["samples"][h]
+        assert float((lg[:, s["idx"].to(dev)].cpu() - s["logits"]).abs().max()) <= 1e-3
+        for b in range(2):
+            got = HandshakingTaggingScheme.get_spots_from_shaking_tag(lg[b], seq_len=511)
+            want = ev["spots"][h][b]
+            assert [tuple(g[:3]) for g in got] == [tuple(w[:3]) for w in want], (h, b)      # indices bit-exact
+            assert all(abs(g[3] - w[3]) <= 1e-4 for g, w in zip(got, want))
+
+    # the whole evaluation pass, one page per batch (the short page alone pads to 88 + ... -> another N)
+    seen = {}
+    loader = DataLoader(ds, batch_size=2, shuffle=False, collate_fn=coll)
+    metrics = prediction_loop(model, loader, make_compute_metrics(detail_eval=True, on_detail=lambda d: seen.update(d)))
+    for k, want in ev["detail_metric"].items():
+        assert metrics["eval_" + k] == want, k
+    assert abs(metrics["eval_loss"] - float(ev["losses"]["loss"])) <= 1e-4
+    assert abs(metrics["eval_line_grouping_h2h_loss"] - float(ev["losses"]["line_grouping_t2t_loss"])) <= 1e-4
+    assert seen["kv_pair"] == ev["detail_metric_detail"]["kv_pair"]
+    assert [s["detail"] for s in seen["detail"]] == [s["detail"] for s in ev["detail_metric_detail"]["detail"]]
+
+    # sparse labels (device scatter) give the same losses as the dense maps
+    coll_sparse = DataCollatorForPEneo(tokenizer=tok, image_processor=info.image_processor(), max_length=info.max_token_len,
+                                       require_image=True, add_cls_token=True, add_sep_token=True, sparse_tags=True)
+    sb = coll_sparse([ds[0], ds[1]])
+    with torch.no_grad():
+        out2 = model(**{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sb.items()})
+    for k in ev["losses"]:
+        assert float(out2[k]) == float(out[k]), k
+    m2 = prediction_loop(model, DataLoader(ds, batch_size=2, collate_fn=coll_sparse), make_compute_metrics())
+    assert m2["eval_f1"] == ev["metric"]["f1"] and m2["eval_precision"] == ev["metric"]["precision"]
