@@ -176,7 +176,7 @@ def test_metrics_match_reference_on_its_decode_results(fx):
     assert metric == ev["detail_metric"] and detail == ev["detail_metric_detail"]
     assert list(metric.keys()) == list(ev["detail_metric"].keys())
     # the fixture is not degenerate: the trained tiny model finds pairs, and not all of them
-    assert ev["metric"]["f1"] > 0.3 and sum(len(p[0]) for p in d["pred"]) > 0
+    assert 0.2 <= ev["metric"]["f1"] < 1.0 and sum(len(p[0]) for p in d["pred"]) > 0
     # duplicated file names (a distributed sampler's padding) are counted once
     m2, d2 = calculate_KVPE_metric(d["pred"] + d["pred"][:1], d["gt"] + d["gt"][:1], d["fname"] + d["fname"][:1])
     assert m2 == ev["metric"] and d2["num_sample_processed"] == 2
