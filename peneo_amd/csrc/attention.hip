@@ -29,13 +29,31 @@ constexpr float LOG2E = 1.4426950408889634f;
 // raw v_exp_f32: arguments here are <= 0 (or hugely negative for masked keys), results in [0, 1]; no denormal fix-up needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Attention-probability dropout: keep(q row, key) = mix32(rowhash ^ key) >= thresh with one hash per (b, h, q) row
-// (computed once per lane or per staged row), i.e. one mix32 (two quarter-rate 32-bit multiplies) per element instead
-// of the three of the generic (seed, 64-bit element index) form.  Forward and both backward paths share it.
+// Attention-probability dropout.  keep(q row, key) compares 16 random bits with p * 2^16; ONE hash serves the two keys
+// (2j, 2j + 1) of a query row (low / high half), and the hash mixes with 24-bit multiplies (v_mul_u32_u24, full rate)
+// instead of mix32's two quarter-rate 32-bit multiplies.  With the softmax itself at ~50 VALU cycles per element and wave,
+// the former one-mix32-per-element mask (64 cycles) was the largest single cost of the forward and backward kernels; this
+// one is 24 (forward: both keys of a pair sit in one lane) to 32 (fused backward: lane = key, the pair's hash is
+// computed once per two rows and exchanged between the two lanes by DPP).  Row hashes stay mix32 (one per row).
+// Statistics against mix32 on 1.4 M elements (keep rate, bit balance, correlations along keys / rows / between the
+// halves): indistinguishable (tools/check_dropout_hash.py).  p is realised to 2^-17 (0.1 -> 6554 / 65536).
 __device__ __forceinline__ uint32_t attn_rowhash(uint32_t seed, int64_t rowid) {
   return mix32(seed ^ ((uint32_t)rowid * 0x9e3779b9u) ^ ((uint32_t)(rowid >> 32) * 0x85ebca6bu));
 }
-__device__ __forceinline__ bool attn_keep(uint32_t rowhash, int key, uint32_t thresh) { return mix32(rowhash ^ (uint32_t)key) >= thresh; }
+__device__ __forceinline__ uint32_t attn_mix24(uint32_t x) {
+  x ^= x >> 16; x = __umul24(x, 0x9E3779u); x ^= x >> 13; x = __umul24(x, 0x85EBCBu); x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t attn_thresh16(float p) { return (uint32_t)fminf(rintf(p * 65536.0f), 65535.0f); }
+// the 32 bits shared by keys (key & ~1, key | 1) of the row
+__device__ __forceinline__ uint32_t attn_pairhash(uint32_t rowhash, int key) { return attn_mix24(rowhash ^ ((uint32_t)key >> 1)); }
+__device__ __forceinline__ bool attn_keep(uint32_t rowhash, int key, uint32_t thresh16) {
+  return __builtin_amdgcn_ubfe(attn_pairhash(rowhash, key), (key & 1) * 16, 16) >= thresh16;
+}
+// value of the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ uint32_t lane_swap1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false);
+}
 
 // ---- LDS tiles: row-major [rows][COLS] of T, pitch = COLS*sizeof(T) + 16 bytes (odd number of 16-byte
 //      slots => 16 consecutive rows hit 16 different slots: conflict-free b128 column reads)
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
   const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int qrow = wave * 32 + (lane & 31);
-  const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+  const uint32_t thresh = attn_thresh16(p.drop_p);
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const float sc2 = p.scale * LOG2E;
   const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
@@ -365,11 +383,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float e = fast_exp2(s[kt][r] - m_new);
-        ls += e;
-        if (DROP) e = attn_keep(my_rh, k0 + kt * 32 + acc_row(r, lane), thresh) ? e * keep_scale : 0.f;
-        s[kt][r] = e;
+      for (int r = 0; r < 16; r += 2) {                 // registers (r, r + 1) hold keys (2j, 2j + 1)
+        float e0 = fast_exp2(s[kt][r] - m_new), e1 = fast_exp2(s[kt][r + 1] - m_new);
+        ls += e0 + e1;
+        if (DROP) {
+          const uint32_t h2 = attn_pairhash(my_rh, k0 + kt * 32 + acc_row(r, lane));
+          e0 = (h2 & 0xffffu) >= thresh ? e0 * keep_scale : 0.f;
+          e1 = (h2 >> 16) >= thresh ? e1 * keep_scale : 0.f;
+        }
+        s[kt][r] = e0;
+        s[kt][r + 1] = e1;
       }
     ls += __shfl_xor(ls, 32, 64);
     l_run = l_run * alpha + ls;
@@ -491,7 +514,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int qrow = wave * 32 + (lane & 31);
-  const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+  const uint32_t thresh = attn_thresh16(p.drop_p);
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const float sc2 = p.scale * LOG2E;
   const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((reinterpret_cast<uintptr_t>(V) & 15) == 0) &&
@@ -560,12 +583,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         float bb[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias) bias_read4<T>(sB, qrow, kl, bb);
         float dsv[4];
+        uint32_t h2[2] = {0u, 0u};
+        if (DROP) { h2[0] = attn_pairhash(my_rh, k0 + kl); h2[1] = attn_pairhash(my_rh, k0 + kl + 2); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(s[kt][4 * g + e], sc2, fmaf(bb[e], LOG2E, sKb[kl + e]));
           const float pr = (myq < Tn) ? fast_exp2(v - my_lse) : 0.f;
           float dpv = dp[kt][4 * g + e];
-          if (DROP) dpv = attn_keep(my_rh, k0 + kl + e, thresh) ? dpv * keep_scale : 0.f;
+          if (DROP) dpv = ((e & 1) ? h2[e >> 1] >> 16 : h2[e >> 1] & 0xffffu) >= thresh ? dpv * keep_scale : 0.f;
           dsv[e] = pr * (dpv - my_delta);
           s[kt][4 * g + e] = dsv[e];
         }
@@ -639,7 +664,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
   const int mykey = key0 + wave * 32 + (lane & 31);
   const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] * LOG2E : 0.f) : MASKED;
-  const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+  const uint32_t thresh = attn_thresh16(p.drop_p);
   const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const float sc2 = p.scale * LOG2E;
   const bool q_al = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
@@ -830,7 +855,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
   const int keyl = wave * 32 + (lane & 31);
   const int mykey = key0 + keyl;
   const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] * LOG2E : 0.f) : MASKED;
-  const uint32_t thresh = (uint32_t)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+  const uint32_t thresh = attn_thresh16(p.drop_p);
   const float keep_scale = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const float sc2 = p.scale * LOG2E;
   const bool q_al = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((p.ld * 2) % 16 == 0) && (d == DP);
@@ -915,7 +940,20 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
         const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
         uint4 h4 = make_uint4(0, 0, 0, 0);
         if (DROP) h4 = *reinterpret_cast<const uint4*>(sRh + qb);
-        const uint32_t rh4[4] = {h4.x, h4.y, h4.z, h4.w};
+        // the pair hash of (row qb + e, keys mykey & ~1 .. | 1): the even lane computes rows 0 and 2, the odd lane rows 1
+        // and 3, the neighbour's two arrive by DPP; each lane then takes its own 16 bits
+        uint32_t hv[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {
+          const bool odd = lane & 1;
+          const uint32_t kp = (uint32_t)mykey >> 1;
+          const uint32_t ha = attn_mix24((odd ? h4.y : h4.x) ^ kp), hb = attn_mix24((odd ? h4.w : h4.z) ^ kp);
+          const uint32_t oa = lane_swap1(ha), ob = lane_swap1(hb);
+          const uint32_t sh = odd ? 16u : 0u;
+          hv[0] = __builtin_amdgcn_ubfe(odd ? oa : ha, sh, 16);
+          hv[1] = __builtin_amdgcn_ubfe(odd ? ha : oa, sh, 16);
+          hv[2] = __builtin_amdgcn_ubfe(odd ? ob : hb, sh, 16);
+          hv[3] = __builtin_amdgcn_ubfe(odd ? hb : ob, sh, 16);
+        }
         float ds4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -927,7 +965,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
           float dpv = dp[r];
           float pdrop = pv;
           if (DROP) {
-            const bool keep = attn_keep(rh4[e], mykey, thresh);
+            const bool keep = hv[e] >= thresh;
             dpv = keep ? dpv * keep_scale : 0.f;
             pdrop = keep ? pv * keep_scale : 0.f;
           }

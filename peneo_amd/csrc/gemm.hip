@@ -451,6 +451,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
         epilogue_store8(p, m0 + r, n0 + c, v);
       }
     }
+  } else if (p.split_k > 1 && nrem == GB && (p.N & 3) == 0) {
+    // split-k partials: raw fp32 rows of the tile, 16 bytes per store (ws is 256-byte aligned, N % 4 == 0)
+    float* wsz = p.ws + ((int64_t)zsplit * p.M + m0) * p.N + n0;
+    for (int idx = tid; idx < GB * (GB / 4); idx += 256) {
+      const int r = idx >> 5, c = (idx & 31) * 4;
+      if (r < mrem) *reinterpret_cast<float4*>(wsz + (int64_t)r * p.N + c) = *reinterpret_cast<const float4*>(sC + r * GB + c);
+    }
   } else {
     for (int idx = tid; idx < GB * GB; idx += 256) {
       const int r = idx >> 7, c = idx & (GB - 1);
@@ -1124,6 +1131,40 @@ __global__ void splitk_reduce_kernel(GemmParams p) {
   for (int z = 0; z < p.split_k; ++z) s += p.ws[(int64_t)z * total + idx];
   epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), s);
 }
+// 8 consecutive columns per thread (N % 8 == 0, every operand of the epilogue 16-byte aligned per row): two 16-byte loads
+// per slice, four slices in flight.  The scalar kernel above moved 4 bytes per load and reached ~1.2 TB/s on the encoder's
+// weight gradients (14 slices of 2.4 MB: 26 us); same summation order (slice 0 first), so results are bit-identical.
+__global__ __launch_bounds__(256) void splitk_reduce8_kernel(GemmParams p) {
+  const int64_t v8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)p.M * p.N;
+  const int64_t idx = v8 * 8;
+  if (idx >= total) return;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const float* src = p.ws + idx;
+  int z = 0;
+  for (; z + 4 <= p.split_k; z += 4) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const float4*>(src + (int64_t)(z + u) * total);
+      b[u] = *reinterpret_cast<const float4*>(src + (int64_t)(z + u) * total + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] += a[u].x; acc[1] += a[u].y; acc[2] += a[u].z; acc[3] += a[u].w;
+      acc[4] += b[u].x; acc[5] += b[u].y; acc[6] += b[u].z; acc[7] += b[u].w;
+    }
+  }
+  for (; z < p.split_k; ++z) {
+    const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)z * total);
+    const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)z * total + 4);
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+  }
+  epilogue_store8(p, (int)(idx / p.N), (int)(idx % p.N), acc);
+}
 
 template <typename T>
 static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
@@ -1309,7 +1350,15 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
   if (rc != PENEO_OK) return rc;
   if (split_k > 1) {
     int64_t total = (int64_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    const peneo_gemm_epilogue& e = p.ep;
+    const int csz = p.c_dtype == PENEO_F32 ? 4 : 2;
+    auto al = [&](const void* ptr, int64_t ld, int esz) {
+      return ptr == nullptr || (((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && ((ld * esz) % 16 == 0));
+    };
+    const bool vec = (N % 8 == 0) && al(p.ws, 0, 4) && al(p.C, p.ldc, csz) && al(e.preact, e.ld_preact, csz) &&
+                     al(e.grad_src, e.ld_grad, csz) && al(e.residual, e.ld_res, csz) && al(e.bias, 0, 4);
+    if (vec) hipLaunchKernelGGL(splitk_reduce8_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     return check_launch("peneo_gemm(split-k reduce)");
   }
   return PENEO_OK;

@@ -467,6 +467,52 @@ def test_attention_bf16_single_pass_matches_two_kernel_path_with_dropout(ops, d)
         assert rel_err(b_, a_) < 1e-2
 
 
+def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops):
+    """The forward's keep mask is read off with one-hot V blocks (out = dropped probabilities), its rate is checked, and an
+    autograd statement of softmax -> that mask -> PV must give the gradients of the fused backward (same seed)."""
+    B, nh, T, d, p_drop, seed = 2, 3, 200, 64, 0.2, 1234
+    H = nh * d
+    g = torch.Generator().manual_seed(5)
+    qkv = (0.7 * torch.randn(B * T, 3 * H, generator=g)).to(DEV).to(torch.bfloat16)
+    bias = _padded_bias((0.5 * torch.randn(B, nh, T, T, generator=g)).to(DEV).to(torch.bfloat16), None)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    scale = 0.11
+    dropped = torch.zeros(B, nh, T, T, device=DEV)
+    for j in range(0, T, d):
+        vj = torch.zeros(B, T, nh, d, device=DEV)
+        n = min(d, T - j)
+        vj[:, j:j + n] = torch.eye(d, device=DEV)[:n].view(1, n, 1, d)
+        qkvj = qkv.clone()
+        qkvj[:, 2 * H:] = vj.view(B * T, H).to(torch.bfloat16)
+        oj, _ = ops.attn_fwd(qkvj[:, :H], qkvj[:, H:2 * H], qkvj[:, 2 * H:], B, nh, T, d, scale, bias, None, drop_p=p_drop,
+                             drop_seed=seed)
+        dropped[..., j:j + n] = oj.float().view(B, T, nh, d).permute(0, 2, 1, 3)[..., :n]
+    keep = dropped != 0          # probabilities are > 0 everywhere (no masked keys here)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p_drop)) < 4 * math.sqrt(p_drop * (1 - p_drop) / keep.numel()) + 1e-4, rate
+    # both keys of a pair share one hash but not one decision
+    assert 0.05 < float((keep[..., 0::2] != keep[..., 1::2]).float().mean()) < 2 * p_drop
+    # a different seed gives a different mask, the same seed the same one
+    o1, lse = ops.attn_fwd(q, k, v, B, nh, T, d, scale, bias, None, drop_p=p_drop, drop_seed=seed)
+    o2, _ = ops.attn_fwd(q, k, v, B, nh, T, d, scale, bias, None, drop_p=p_drop, drop_seed=seed)
+    o3, _ = ops.attn_fwd(q, k, v, B, nh, T, d, scale, bias, None, drop_p=p_drop, drop_seed=seed + 1)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    # autograd with the extracted mask
+    leaf = qkv.float().clone().requires_grad_(True)
+    hd = lambda t: t.view(B, T, nh, d).permute(0, 2, 1, 3)
+    sc = hd(leaf[:, :H]) @ hd(leaf[:, H:2 * H]).transpose(-1, -2) * scale + bias[..., :T].float()
+    pr = torch.softmax(sc, -1) * keep.float() / (1 - p_drop)
+    ref = (pr @ hd(leaf[:, 2 * H:])).permute(0, 2, 1, 3).reshape(B * T, H)
+    assert rel_err(o1, ref) < 2e-2
+    d_out = torch.randn(B * T, H, generator=g).to(DEV).to(torch.bfloat16)
+    ref.backward(d_out.float())
+    for single in (True, False):
+        dqkv = torch.zeros_like(qkv)
+        ops.attn_bwd(q, k, v, o1, d_out, lse, B, nh, T, d, scale, bias, None, dqkv, None, drop_p=p_drop, drop_seed=seed,
+                     single_pass=single)
+        assert rel_err(dqkv, leaf.grad) < 4e-2, (single, rel_err(dqkv, leaf.grad))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_key_bias_only(ops, dtype):
     """LiLT-style: no bias tensor, padding mask as an additive per-key row."""
