@@ -147,6 +147,19 @@ int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bs
                         float* dgamma, float* dbeta, int64_t rows, int H,
                         float drop_p, uint32_t drop_seed, void* dx_dropped, float drop2_p, uint32_t drop2_seed,
                         peneo_stream_t stream);
+/* The same backward with the parameter gradients left as per-workgroup partial sums, partials[P][2][H] (fp32; row 0 of a
+ * pair = gamma, row 1 = beta), P = peneo_layernorm_bwd_partial_rows(dtype, rows, H); 0 means this dtype / row length has
+ * no such form (use peneo_layernorm_bwd).  The caller reduces them with peneo_colsum over [P, 2H] whenever it likes (the
+ * model does it on its weight-gradient stream): no same-address atomics at the end of the kernel, one row per half-wave.
+ * All row bases 16-byte aligned. */
+int64_t peneo_layernorm_bwd_partial_rows(int dtype, int64_t rows, int H);
+int peneo_layernorm_bwd_partial(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bstride,
+                                const void* x, int64_t x_rpb, int64_t x_bstride,
+                                void* dx, int64_t dx_rpb, int64_t dx_bstride,
+                                const float* gamma, const float* mean, const float* rstd,
+                                float* partials, int64_t partial_rows, int64_t rows, int H,
+                                float drop_p, uint32_t drop_seed, void* dx_dropped, float drop2_p, uint32_t drop2_seed,
+                                peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K1 — text embeddings (modeling_layoutlmv3.py:131-227, modeling_lilt.py:75-130,160-210)

@@ -232,7 +232,7 @@ template <typename T, int NV, bool DROP>
 __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                        const float* gamma, const float* mean, const float* rstd,
                                                        float* dgamma, float* dbeta, int64_t rows, float drop_p,
-                                                       uint32_t seed, T* dx2, float drop2_p, uint32_t seed2) {
+                                                       uint32_t seed, T* dx2, float drop2_p, uint32_t seed2, float* partial) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = 32 * NV * VEC;
   const int hl = threadIdx.x & 31;
@@ -325,8 +325,13 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
-    if (dgamma) atomicAdd(dgamma + c, a);
-    if (dbeta) atomicAdd(dbeta + c, b);
+    if (partial) {   // [gridDim.x][2][H]: summed by a column-sum launch off the critical path (no same-address atomics)
+      partial[((int64_t)blockIdx.x * 2 + 0) * H + c] = a;
+      partial[((int64_t)blockIdx.x * 2 + 1) * H + c] = b;
+    } else {
+      if (dgamma) atomicAdd(dgamma + c, a);
+      if (dbeta) atomicAdd(dbeta + c, b);
+    }
   }
 }
 
@@ -344,17 +349,25 @@ static void launch_ln_fwd32(hipStream_t st, const void* x, LnMap xm, void* y, Ln
 template <typename T, int NV>
 static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const void* x, LnMap xm, void* dx, LnMap dxm,
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                            int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2) {
+                            int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2,
+                            float* partial = nullptr, int64_t partial_rows = 0) {
   static const int64_t cap = [] { const char* e = getenv("PENEO_LN_BWD_BLOCKS"); return (int64_t)(e ? atoi(e) : 256); }();   // 256: fewer same-address atomics on dgamma / dbeta (measured 64..1024)
   int64_t blocks = (rows + 7) / 8;
-  if (blocks > cap) blocks = cap;
+  if (partial) blocks = partial_rows;          // one partial row per block: the caller sized the buffer (ln_partial_rows)
+  else if (blocks > cap) blocks = cap;
   dim3 grid((unsigned)blocks);
   if (drop_p > 0.f)
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2);
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial);
   else
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2);
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial);
+}
+// blocks of the partial-sum form: one row per half-wave up to 1024 blocks (4 per CU), then a grid-stride loop
+static int64_t ln_partial_rows(int64_t rows) {
+  static const int64_t cap = [] { const char* e = getenv("PENEO_LN_BWD_PBLOCKS"); return (int64_t)(e ? atoi(e) : 1024); }();
+  int64_t blocks = (rows + 7) / 8;
+  return blocks > cap ? cap : blocks;
 }
 
 // true when a fast instantiation exists for this row length
@@ -453,4 +466,37 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
                        (const float*)x, xm, (float*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed,
                        (float*)dx_dropped, drop2_p, drop2_seed);
   return check_launch("peneo_layernorm_bwd");
+}
+
+// Same backward with the LayerNorm parameter gradients left as per-block partial sums: partials[P][2][H] (gamma row, beta
+// row per block), P = peneo_layernorm_bwd_partial_rows(dtype, rows, H) (0: this row length / dtype has no such form, use
+// peneo_layernorm_bwd).  The caller column-sums the partials whenever it likes (peneo_colsum over [P, 2H]); the kernel then
+// has no same-address atomics at its end and can run one row per half-wave.
+extern "C" int64_t peneo_layernorm_bwd_partial_rows(int dtype, int64_t rows, int H) {
+  if (rows <= 0 || (dtype != PENEO_F32 && dtype != PENEO_BF16)) return 0;
+  const bool ok = dtype == PENEO_BF16 ? ln32_dispatch<bf16_t>(H, [](auto) {}) : ln32_dispatch<float>(H, [](auto) {});
+  return ok ? ln_partial_rows(rows) : 0;
+}
+
+extern "C" int peneo_layernorm_bwd_partial(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bstride, const void* x,
+                                           int64_t x_rpb, int64_t x_bstride, void* dx, int64_t dx_rpb, int64_t dx_bstride,
+                                           const float* gamma, const float* mean, const float* rstd, float* partials,
+                                           int64_t partial_rows, int64_t rows, int H, float drop_p, uint32_t drop_seed,
+                                           void* dx_dropped, float drop2_p, uint32_t drop2_seed, peneo_stream_t stream) {
+  int rc = ln_check("peneo_layernorm_bwd_partial", dtype, rows, H);
+  if (rc) return rc;
+  PENEO_REQUIRE(dy && x && dx && gamma && mean && rstd && partials, "peneo_layernorm_bwd_partial: null pointer");
+  PENEO_REQUIRE(partial_rows > 0 && partial_rows == peneo_layernorm_bwd_partial_rows(dtype, rows, H),
+                "peneo_layernorm_bwd_partial: partial_rows must come from peneo_layernorm_bwd_partial_rows");
+  LnMap dym{dy_rpb, dy_bstride}, xm{x_rpb, x_bstride}, dxm{dx_rpb, dx_bstride};
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f && drop2_p >= 0.f && drop2_p < 1.f, "peneo_layernorm_bwd_partial: drop_p out of range");
+  PENEO_REQUIRE(ln_aligned(dy, dy_bstride, dtype) && ln_aligned(x, x_bstride, dtype) && ln_aligned(dx, dx_bstride, dtype) &&
+                (!dx_dropped || (reinterpret_cast<uintptr_t>(dx_dropped) & 15) == 0),
+                "peneo_layernorm_bwd_partial: rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PENEO_BF16)
+    ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_bwd32<bf16_t, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, nullptr, nullptr, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, partials, partial_rows); });
+  else
+    ln32_dispatch<float>(H, [&](auto nv) { launch_ln_bwd32<float, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, nullptr, nullptr, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, partials, partial_rows); });
+  return check_launch("peneo_layernorm_bwd_partial");
 }

@@ -389,22 +389,33 @@ class _LayerStage(torch.autograd.Function):
         dbo2, dbi, dbo, dbqkv = pool[o_:o_ + H], pool[o_ + H:o_ + H + I], pool[o_ + H + I:o_ + 2 * H + I], pool[o_ + 2 * H + I:]
         # LayerNorm backward writes d_h (for the residual branch) and, in the same pass, d_h through the dropout mask of
         # the dense layer that fed the LayerNorm (for that layer's dgrad / wgrad)
+        # LayerNorm parameter gradients: per-workgroup partial sums from the backward kernel (no same-address atomics at its
+        # end, one row per half-wave), column-summed on the weight-gradient stream (model.ln_partials; dg | db are adjacent)
+        side_keep = []
+
+        def ln_bwd(dy, hx, g, m, r, dgb, dxd, seed_):
+            if model.ln_partials and side is not None:
+                dxo, part = ops.layernorm_bwd_partial(dy, hx, g, m, r, dx_dropped=dxd, drop2_p=seeds.p_hidden, drop2_seed=seed_)
+                if part is not None:
+                    side_keep.append(part)       # read by the side stream: stays referenced until the join
+                    return dxo, (lambda: ops.colsum(part, out=dgb, accumulate=True))
+            return ops.layernorm_bwd(dy, hx, g, m, r, dgb[:H], dgb[H:], dx_dropped=dxd, drop2_p=seeds.p_hidden,
+                                     drop2_seed=seed_), (lambda: None)
+
         d_dense2 = torch.empty_like(h2) if seeds.p_hidden > 0 else None
-        d_h2 = ops.layernorm_bwd(d_out, h2, g2, m2, r2, dg2, db2, dx_dropped=d_dense2, drop2_p=seeds.p_hidden,
-                                 drop2_seed=seeds.seed(site + 3))
+        d_h2, red2 = ln_bwd(d_out, h2, g2, m2, r2, pool[:2 * H], d_dense2, seeds.seed(site + 3))
         if d_dense2 is None:
             d_dense2 = d_h2
-        r_o2 = on_side_late(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)))
+        r_o2 = on_side_late(lambda: (red2(), ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter))[1:])
         d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
         r_i = on_side_late(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
         d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
 
         d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
-        d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1, dx_dropped=d_dense1, drop2_p=seeds.p_hidden,
-                                 drop2_seed=seeds.seed(site + 2))
+        d_h1, red1 = ln_bwd(d_a, h1, g1, m1, r1, pool[2 * H:4 * H], d_dense1, seeds.seed(site + 2))
         if d_dense1 is None:
             d_dense1 = d_h1
-        r_o = on_side_late(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
+        r_o = on_side_late(lambda: (red1(), ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att))[1:])
         if jobs:
             # FFN2, FFN1 and the attention output projection (324 tiles) run beside the attention backward; the QKV weight
             # gradient needs dqkv and goes out alone afterwards (split-k), or the stage would end waiting for the group
@@ -451,7 +462,7 @@ class _LayerStage(torch.autograd.Function):
         if side is not None:
             if model.defer_wgrad_join and DEFER_ALLOWED[0] and all(p.grad is None for p in ctx.params):
                 # joined one stage later (engine.py): the critical path does not wait for dW_qkv
-                defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x))
+                defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x, *side_keep))
             else:
                 main.wait_stream(side)    # gradients are accumulated into existing .grad tensors on main right after this
         grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, db1,
@@ -496,6 +507,7 @@ class LayoutLMv3Model(nn.Module):
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
         self.defer_wgrad_join = os.environ.get("PENEO_DEFER_JOIN", "1") != "0"
+        self.ln_partials = os.environ.get("PENEO_LN_PARTIALS", "0") != "0"   # measured +-0 in the step; gives order-independent dgamma / dbeta
         self.wgrad_late = os.environ.get("PENEO_WGRAD_LATE", "1") != "0"   # +0.7 % (17.72 -> 17.59 ms per step)
         # one grouped launch (peneo_gemm_group) for three of a layer's four wgrads: 2x faster alone (97 vs 190 us for all four),
         # but in the step the long full-K workgroups crowd the critical path: enc. backward 7.9 vs 7.6 ms -> off by default

@@ -249,6 +249,30 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     return dx
 
 
+def layernorm_bwd_partial(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                          dx: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
+                          dx_dropped: Optional[torch.Tensor] = None, drop2_p: float = 0.0, drop2_seed: int = 0):
+    """LayerNorm backward with the parameter gradients left as per-workgroup partial sums: -> (dx, partials [P, 2H] fp32 with
+    [dgamma | dbeta] per row) or (None, None) when this dtype / row length has no such form.  ``colsum(partials)`` gives
+    [dgamma | dbeta]; the model runs that reduction on its weight-gradient stream."""
+    H = x.shape[-1]
+    rows, xr, xb = _rowmap(x, H)
+    drows, dr, db = _rowmap(dy, H)
+    assert drows == rows and dy.dtype == x.dtype
+    P = int(lib().peneo_layernorm_bwd_partial_rows(dtype_code(x.dtype), rows, H))
+    if P <= 0:
+        return None, None
+    if dx is None:
+        dx = torch.empty(dy.shape, dtype=x.dtype, device=x.device)
+    _, gr, gb = _rowmap(dx, H)
+    partials = torch.empty((P, 2 * H), dtype=torch.float32, device=x.device)
+    check(lib().peneo_layernorm_bwd_partial(dtype_code(x.dtype), ptr(dy), dr, db, ptr(x), xr, xb, ptr(dx), gr, gb, ptr(gamma),
+                                            ptr(mean), ptr(rstd), ptr(partials), P, rows, H, drop_p,
+                                            drop_seed & 0xFFFFFFFF, ptr(dx_dropped), drop2_p, drop2_seed & 0xFFFFFFFF, stream()),
+          "peneo_layernorm_bwd_partial")
+    return dx, partials
+
+
 # ----------------------------------------------------------------------------------------------
 # embeddings
 # ----------------------------------------------------------------------------------------------

@@ -949,3 +949,27 @@ def test_pair_bwd_fused_matches_autograd(ops, B, N, D):
     # rows outside the triangle are exactly zero in dz and finite in x; the valid ones carry every pair exactly once
     nz = (dz[:B * rows].float().abs().sum(-1) > 0).view(B, rows).sum(-1)
     assert int(nz.max()) <= P and bool(torch.isfinite(x[:B * rows].float()).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_bwd_partial_sums_equal_the_atomic_form(ops, dtype):
+    """peneo_layernorm_bwd_partial: same dx (and dropped second output) as peneo_layernorm_bwd, and its per-workgroup partial
+    rows column-sum to dgamma | dbeta."""
+    R, H = 5672 if dtype == torch.bfloat16 else 1000, 768
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(R, H, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(R, H, generator=g).to(DEV).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = torch.zeros(H, device=DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dxd1 = torch.empty_like(x)
+    dx1 = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dx_dropped=dxd1, drop2_p=0.1, drop2_seed=5)
+    dxd2 = torch.empty_like(x)
+    dx2, part = ops.layernorm_bwd_partial(dy, x, gamma, mean, rstd, dx_dropped=dxd2, drop2_p=0.1, drop2_seed=5)
+    assert part is not None and part.shape[1] == 2 * H and part.shape[0] == min((R + 7) // 8, 1024)
+    assert torch.equal(dx1, dx2) and torch.equal(dxd1, dxd2)
+    sums = ops.colsum(part)
+    assert rel_err(sums[:H], dg) < 1e-5 and rel_err(sums[H:], db) < 1e-5
+    # no partial form for a row length outside the fast instantiations
+    assert ops.layernorm_bwd_partial(dy[:, :40].contiguous(), x[:, :40].contiguous(), gamma[:40], mean, rstd)[0] is None
