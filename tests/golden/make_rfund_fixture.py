@@ -6,6 +6,8 @@ Writes (all committed; data, no reference source):
   tests/golden/rfund/en.train.json, en.val.json   RFUND-schema annotations authored here (docs/documentation.md:196-240)
   tests/golden/rfund/images/en/*.png              small synthetic page images
   tests/golden/rfund/tokenizer/tokenizer.json     a byte-level BPE trained here on the fixture's own text
+  tests/golden/rfund_train.pt                     (--only-train: just this) 12 AdamW steps of the reference on the collated batch
+                                                  from a stored initial state: loss of every step, six final tensors
   tests/golden/rfund_plumbing.pt                  what the reference made of them:
       items / items_boxaug / items_roberta        RFUNDDataset.__getitem__ dicts (layoutlmv3 flags; with box jitter under
                                                   random.seed; lilt-roberta flags)
@@ -295,5 +297,71 @@ def main() -> None:
     print("min margins", ev["min_margin"], f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def make_train_trajectory(steps: int = 12) -> None:
+    """tests/golden/rfund_train.pt: the reference trains a tiny LayoutLMv3 PEneo for a few AdamW steps on the collated two-page
+    batch (the reference's optimizer recipe: four groups, decoder lr x peneo_downstream_speedup_ratio, no decay on biases /
+    LayerNorm; pipeline/trainer.py:275-330) from a stored initial state; the loss of every step and the final weights are kept.
+    The build's model + FusedAdamW must follow the same trajectory (fp32 path)."""
+    ref = import_reference()
+    from data.collator import DataCollatorForPEneo
+    from data.datasets.rfund import RFUNDDataset
+    from model import backbone_mapping as ref_bm
+    from model.backbone.layoutlmv3 import LayoutLMv3Config
+    from transformers.models.layoutlmv3 import LayoutLMv3ImageProcessor
+    tok = load_tokenizer()
+    ds = RFUNDDataset(data_root=ROOT, split="train", language="en", tokenizer=tok,
+                      tokenizer_fetcher=ref_bm.fetcher_LayoutLMv3Tokenizer, max_token_len=510, add_cls_token=True, add_sep_token=True)
+    coll = DataCollatorForPEneo(tokenizer=tok, image_processor=LayoutLMv3ImageProcessor(apply_ocr=False), max_length=510,
+                                require_image=True, add_cls_token=True, add_sep_token=True)
+    batch = coll([ds[0], ds[1]])
+    bc = layoutlmv3_config("tiny")
+    bc.update(vocab_size=len(tok), max_position_embeddings=514, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    pcfg = peneo_config("layoutlmv3-base", bc)
+    bcfg = LayoutLMv3Config(**{k: v for k, v in bc.items() if k != "model_type"})
+    cfg = ref.PEneoConfig(backbone_config=bcfg.to_dict(),
+                          **{k: v for k, v in pcfg.items() if k not in ("model_type", "backbone_config")})
+    torch.manual_seed(23)
+    model = ref.PEneoModel(cfg)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    lr, wd, ratio = 2e-4, 0.01, float(pcfg["peneo_downstream_speedup_ratio"])
+    # the reference's four groups (pipeline/trainer.py:280-322).  Its decay set comes from transformers 4.40.1's
+    # Trainer.get_decay_parameter_names: every parameter that is not inside an nn.LayerNorm module and has no "bias" in its
+    # name (so the rel_pos_*_bias tables are not decayed either); restated here because the installed 5.x rule differs
+    ln_params = {f"{mn}.{pn}" if mn else pn for mn, m in model.named_modules() if isinstance(m, torch.nn.LayerNorm)
+                 for pn, _ in m.named_parameters(recurse=False)}
+    named = list(model.named_parameters())
+    decays = lambda n: n not in ln_params and "bias" not in n
+    sel = lambda dec, d: [p for n, p in named if ("peneo_decoder" in n) == dec and decays(n) == d]
+    groups = [{"params": sel(True, True), "weight_decay": wd, "lr": lr * ratio},
+              {"params": sel(True, False), "weight_decay": 0.0, "lr": lr * ratio},
+              {"params": sel(False, True), "weight_decay": wd, "lr": lr},
+              {"params": sel(False, False), "weight_decay": 0.0, "lr": lr}]
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8)
+    losses = []
+    for step in range(steps):
+        out = model(**batch)
+        opt.zero_grad()
+        out.loss.backward()
+        opt.step()
+        losses.append({k: float(v.detach()) for k, v in out.items() if k.endswith("loss")})
+        print(f"train step {step:2d} loss {losses[-1]['loss']:.6f}", flush=True)
+    fx = {"config": pcfg, "init": init, "lr": lr, "weight_decay": wd, "ratio": ratio, "losses": losses, "steps": steps,
+          "final": {k: v.detach().clone() for k, v in model.state_dict().items()
+                    if k in ("peneo_decoder.line_extraction_fc.3.weight", "peneo_decoder.handshaking_kernel.combine_fc.weight",
+                             "backbone.encoder.layer.1.output.dense.weight", "backbone.embeddings.word_embeddings.weight",
+                             "backbone.encoder.rel_pos_x_bias.weight", "backbone.LayerNorm.weight")}}
+    path = os.path.join(HERE, "rfund_train.pt")
+    torch.save(fx, path)
+    print(f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-train" in sys.argv:
+        make_train_trajectory()
+    else:
+        main()
+        make_train_trajectory()

@@ -258,3 +258,41 @@ def test_config1_end_to_end_on_the_hip_path(fx, tok):
         assert float(out2[k]) == float(out[k]), k
     m2 = prediction_loop(model, DataLoader(ds, batch_size=2, collate_fn=coll_sparse), make_compute_metrics())
     assert m2["eval_f1"] == ev["metric"]["f1"] and m2["eval_precision"] == ev["metric"]["precision"]
+
+
+@pytest.mark.gpu
+def test_training_trajectory_follows_the_reference(tok):
+    """12 optimizer steps on the collated two-page batch from the reference's initial state (tests/golden/rfund_train.pt): the
+    HIP model (fp32 path) + FusedAdamW with the reference's four parameter groups must reproduce the reference's loss at every
+    step — the loss falls from 5.06 to 0.044, so this covers forward, backward and the update together — and its final weights."""
+    from peneo_amd.data import DataCollatorForPEneo
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    from peneo_amd.optim import FusedAdamW, peneo_param_groups
+    tr = torch.load(os.path.join(HERE, "golden", "rfund_train.pt"), weights_only=False)
+    dev = torch.device("cuda:0")
+    ds, info = _dataset(tok, "train", "layoutlmv3-base")
+    coll = DataCollatorForPEneo(tokenizer=tok, image_processor=info.image_processor(), max_length=info.max_token_len,
+                                require_image=True, add_cls_token=True, add_sep_token=True)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in coll([ds[0], ds[1]]).items()}
+    model = PEneoModel(PEneoConfig(**{k: v for k, v in tr["config"].items() if k != "model_type"}))
+    model.load_state_dict(tr["init"], strict=True)
+    model.to(dev).set_compute_dtype(torch.float32).train()
+    opt = FusedAdamW(peneo_param_groups(model, tr["lr"], tr["weight_decay"], tr["ratio"]))
+    worst = 0.0
+    for step, want in enumerate(tr["losses"]):
+        out = model(**batch)
+        opt.zero_grad()
+        out.loss.backward()
+        opt.step()
+        for k, v in want.items():
+            got = float(out[k])
+            worst = max(worst, abs(got - v) / max(abs(v), 1e-3))
+            assert abs(got - v) <= 2e-4 * max(abs(v), 1e-2), (step, k, got, v)   # measured: 2e-5
+    sd = model.state_dict()
+    for k, want in tr["final"].items():
+        assert rel_err(sd[k].cpu(), want) < 1e-3, (k, rel_err(sd[k].cpu(), want))
+    print("worst relative loss deviation over the trajectory:", worst)
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6))
