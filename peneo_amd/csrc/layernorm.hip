@@ -176,13 +176,15 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
-template <typename T, int NV, bool DROP>
+// LW = lanes of the half-wave that carry data: 32, or 24 for row lengths like 192 = 24 x 8 (LiLT's layout stream)
+template <typename T, int NV, bool DROP, int LW = 32>
 __global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* y, LnMap ym, const float* gamma,
                                                        const float* beta, float eps, float* mean, float* rstd,
                                                        int64_t rows, float drop_p, uint32_t seed) {
   constexpr int VEC = Elem<T>::kVec;
-  constexpr int H = 32 * NV * VEC;
+  constexpr int H = LW * NV * VEC;
   const int hl = threadIdx.x & 31;
+  const bool act = LW == 32 || hl < LW;
   const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
   const int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -193,7 +195,11 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* 
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    unpack16<T>(*reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC), v[k]);
+    if (act) unpack16<T>(*reinterpret_cast<const uint4*>(xr + (hl + LW * k) * VEC), v[k]);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[k][e] = 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s += v[k][e];
   }
@@ -202,15 +208,16 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* 
 #pragma unroll
   for (int k = 0; k < NV; ++k)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { float d = v[k][e] - mu; q += d * d; }
+    for (int e = 0; e < VEC; ++e) { float d = act ? v[k][e] - mu : 0.f; q += d * d; }
   const float rs = rsqrtf(half_sum(q) * (1.0f / (float)H) + eps);
   if (hl == 0) {
     if (mean) mean[r] = mu;
     if (rstd) rstd[r] = rs;
   }
+  if (!act) return;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int c0 = (hl + 32 * k) * VEC;
+    const int c0 = (hl + LW * k) * VEC;
     float gm[VEC], bt[VEC], o[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; e += 4) {
@@ -228,14 +235,15 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* 
   }
 }
 
-template <typename T, int NV, bool DROP>
+template <typename T, int NV, bool DROP, int LW = 32>
 __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                        const float* gamma, const float* mean, const float* rstd,
                                                        float* dgamma, float* dbeta, int64_t rows, float drop_p,
                                                        uint32_t seed, T* dx2, float drop2_p, uint32_t seed2, float* partial) {
   constexpr int VEC = Elem<T>::kVec;
-  constexpr int H = 32 * NV * VEC;
+  constexpr int H = LW * NV * VEC;
   const int hl = threadIdx.x & 31;
+  const bool act = LW == 32 || hl < LW;
   const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
   const float keep_scale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
   const uint32_t thresh2 = (uint32_t)fminf(drop2_p * 4294967296.0f, 4294967040.0f);
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
   for (int k = 0; k < NV; ++k)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      gm[k][e] = gamma[(hl + 32 * k) * VEC + e];
+      gm[k][e] = act ? gamma[(hl + LW * k) * VEC + e] : 0.f;
       ag[k][e] = 0.f; ab[k][e] = 0.f;
     }
   // the rows of a half-wave are software-pipelined: the loads of its next row are in flight while this one is reduced
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
     const T* xr = x + ln_row_off(rr, xm, H);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      nd[k] = *reinterpret_cast<const uint4*>(dyr + (hl + 32 * k) * VEC);
-      nx[k] = *reinterpret_cast<const uint4*>(xr + (hl + 32 * k) * VEC);
+      nd[k] = act ? *reinterpret_cast<const uint4*>(dyr + (hl + LW * k) * VEC) : make_uint4(0, 0, 0, 0);
+      nx[k] = act ? *reinterpret_cast<const uint4*>(xr + (hl + LW * k) * VEC) : make_uint4(0, 0, 0, 0);
     }
     nmu = mean[rr]; nrs = rstd[rr];
   };
@@ -278,12 +286,12 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
       float d[VEC], xv[VEC];
       unpack16<T>(rd[k], d);
       unpack16<T>(rx[k], xv);
-      const uint32_t dbase = DROP ? dropout_base(seed, (uint64_t)r * H + (hl + 32 * k) * VEC) : 0u;
+      const uint32_t dbase = DROP ? dropout_base(seed, (uint64_t)r * H + (hl + LW * k) * VEC) : 0u;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float dd = d[e];
-        if (DROP) dd = dropout_keep_b(dbase, (uint32_t)((uint64_t)r * H + (hl + 32 * k) * VEC + e), thresh) ? dd * keep_scale : 0.f;
-        const float h = (xv[e] - mu) * rs;
+        if (DROP) dd = dropout_keep_b(dbase, (uint32_t)((uint64_t)r * H + (hl + LW * k) * VEC + e), thresh) ? dd * keep_scale : 0.f;
+        const float h = act ? (xv[e] - mu) * rs : 0.f;
         xh[k][e] = h;
         ag[k][e] += dd * h;
         ab[k][e] += dd;
@@ -297,28 +305,31 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
     s2 = half_sum(s2) * (1.0f / (float)H);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
+      if (!act) continue;
       float o[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = rs * (g[k][e] - s1 - xh[k][e] * s2);
-      *reinterpret_cast<uint4*>(dxr + (hl + 32 * k) * VEC) = pack16<T>(o);
+      *reinterpret_cast<uint4*>(dxr + (hl + LW * k) * VEC) = pack16<T>(o);
       if (dx2) {   // second output: dx through the dropout mask of the producer GEMM (contiguous [rows, H])
-        const uint32_t b2 = dropout_base(seed2, (uint64_t)r * H + (hl + 32 * k) * VEC);
+        const uint32_t b2 = dropout_base(seed2, (uint64_t)r * H + (hl + LW * k) * VEC);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          o[e] = (drop2_p > 0.f && !dropout_keep_b(b2, (uint32_t)((uint64_t)r * H + (hl + 32 * k) * VEC + e), thresh2)) ? 0.f : o[e] * keep2;
-        *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + (hl + 32 * k) * VEC) = pack16<T>(o);
+          o[e] = (drop2_p > 0.f && !dropout_keep_b(b2, (uint32_t)((uint64_t)r * H + (hl + LW * k) * VEC + e), thresh2)) ? 0.f : o[e] * keep2;
+        *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + (hl + LW * k) * VEC) = pack16<T>(o);
       }
     }
   }
   // parameter gradients: 8 half-waves -> LDS -> one atomic per column per block
-  __shared__ float red[2][8][32 * NV * VEC + 1];
+  __shared__ float red[2][8][LW * NV * VEC + 1];
   const int hw = threadIdx.x >> 5;
 #pragma unroll
   for (int k = 0; k < NV; ++k)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      red[0][hw][(hl + 32 * k) * VEC + e] = ag[k][e];
-      red[1][hw][(hl + 32 * k) * VEC + e] = ab[k][e];
+      if (act) {
+        red[0][hw][(hl + LW * k) * VEC + e] = ag[k][e];
+        red[1][hw][(hl + LW * k) * VEC + e] = ab[k][e];
+      }
     }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
@@ -335,18 +346,18 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
   }
 }
 
-template <typename T, int NV>
+template <typename T, int NV, int LW = 32>
 static void launch_ln_fwd32(hipStream_t st, const void* x, LnMap xm, void* y, LnMap ym, const float* gamma, const float* beta,
                             float eps, float* mean, float* rstd, int64_t rows, float drop_p, uint32_t seed) {
   dim3 grid((unsigned)((rows + 7) / 8));
   if (drop_p > 0.f)
-    hipLaunchKernelGGL((ln_fwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)x, xm, (T*)y, ym, gamma, beta, eps, mean,
+    hipLaunchKernelGGL((ln_fwd32_kernel<T, NV, true, LW>), grid, dim3(256), 0, st, (const T*)x, xm, (T*)y, ym, gamma, beta, eps, mean,
                        rstd, rows, drop_p, seed);
   else
-    hipLaunchKernelGGL((ln_fwd32_kernel<T, NV, false>), grid, dim3(256), 0, st, (const T*)x, xm, (T*)y, ym, gamma, beta, eps, mean,
+    hipLaunchKernelGGL((ln_fwd32_kernel<T, NV, false, LW>), grid, dim3(256), 0, st, (const T*)x, xm, (T*)y, ym, gamma, beta, eps, mean,
                        rstd, rows, drop_p, seed);
 }
-template <typename T, int NV>
+template <typename T, int NV, int LW = 32>
 static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const void* x, LnMap xm, void* dx, LnMap dxm,
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                             int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2,
@@ -357,10 +368,10 @@ static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const voi
   else if (blocks > cap) blocks = cap;
   dim3 grid((unsigned)blocks);
   if (drop_p > 0.f)
-    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
+    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true, LW>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
                        gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial);
   else
-    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
+    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false, LW>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
                        gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial);
 }
 // blocks of the partial-sum form: one row per half-wave up to 1024 blocks (4 per CU), then a grid-stride loop
@@ -370,19 +381,31 @@ static int64_t ln_partial_rows(int64_t rows) {
   return blocks > cap ? cap : blocks;
 }
 
-// true when a fast instantiation exists for this row length
+// true when a fast instantiation exists for this row length: f(NV, LW) with H = LW * NV * VEC, LW = 32 data lanes per half-wave
+// or 24 (H = 192 / 384-fp32 ...: LiLT's layout stream)
 template <typename T, typename F> static bool ln32_dispatch(int H, F&& f) {
   constexpr int VEC = sizeof(T) == 2 ? 8 : 4;
-  if (H % (32 * VEC)) return false;
-  switch (H / (32 * VEC)) {
-    case 1: f(std::integral_constant<int, 1>{}); return true;
-    case 2: f(std::integral_constant<int, 2>{}); return true;
-    case 3: f(std::integral_constant<int, 3>{}); return true;
-    case 4: f(std::integral_constant<int, 4>{}); return true;
-    case 6: if (sizeof(T) == 4) { f(std::integral_constant<int, 6>{}); return true; } return false;
-    case 8: if (sizeof(T) == 4) { f(std::integral_constant<int, 8>{}); return true; } return false;
-    default: return false;
+  using L32 = std::integral_constant<int, 32>;
+  using L24 = std::integral_constant<int, 24>;
+  if (H % (32 * VEC) == 0) {
+    switch (H / (32 * VEC)) {
+      case 1: f(std::integral_constant<int, 1>{}, L32{}); return true;
+      case 2: f(std::integral_constant<int, 2>{}, L32{}); return true;
+      case 3: f(std::integral_constant<int, 3>{}, L32{}); return true;
+      case 4: f(std::integral_constant<int, 4>{}, L32{}); return true;
+      case 6: if (sizeof(T) == 4) { f(std::integral_constant<int, 6>{}, L32{}); return true; } return false;
+      case 8: if (sizeof(T) == 4) { f(std::integral_constant<int, 8>{}, L32{}); return true; } return false;
+      default: return false;
+    }
   }
+  if (H % (24 * VEC) == 0) {
+    switch (H / (24 * VEC)) {
+      case 1: f(std::integral_constant<int, 1>{}, L24{}); return true;
+      case 2: f(std::integral_constant<int, 2>{}, L24{}); return true;
+      default: return false;
+    }
+  }
+  return false;
 }
 
 }  // namespace peneo
@@ -424,8 +447,8 @@ extern "C" int peneo_layernorm_fwd(int dtype, const void* x, int64_t x_rpb, int6
                   ln_aligned(beta, 0, PENEO_F32);
   if (al) {
     bool done = dtype == PENEO_BF16
-        ? ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_fwd32<bf16_t, decltype(nv)::value>(st, x, xm, y, ym, gamma, beta, eps, mean, rstd, rows, drop_p, drop_seed); })
-        : ln32_dispatch<float>(H, [&](auto nv) { launch_ln_fwd32<float, decltype(nv)::value>(st, x, xm, y, ym, gamma, beta, eps, mean, rstd, rows, drop_p, drop_seed); });
+        ? ln32_dispatch<bf16_t>(H, [&](auto nv, auto lw) { launch_ln_fwd32<bf16_t, decltype(nv)::value, decltype(lw)::value>(st, x, xm, y, ym, gamma, beta, eps, mean, rstd, rows, drop_p, drop_seed); })
+        : ln32_dispatch<float>(H, [&](auto nv, auto lw) { launch_ln_fwd32<float, decltype(nv)::value, decltype(lw)::value>(st, x, xm, y, ym, gamma, beta, eps, mean, rstd, rows, drop_p, drop_seed); });
     if (done) return check_launch("peneo_layernorm_fwd");
   }
   dim3 grid((unsigned)((rows + 3) / 4));
@@ -452,8 +475,8 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
   if (ln_aligned(dy, dy_bstride, dtype) && ln_aligned(x, x_bstride, dtype) && ln_aligned(dx, dx_bstride, dtype)) {
     hipStream_t st = (hipStream_t)stream;
     bool done = dtype == PENEO_BF16
-        ? ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_bwd32<bf16_t, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); })
-        : ln32_dispatch<float>(H, [&](auto nv) { launch_ln_bwd32<float, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); });
+        ? ln32_dispatch<bf16_t>(H, [&](auto nv, auto lw) { launch_ln_bwd32<bf16_t, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); })
+        : ln32_dispatch<float>(H, [&](auto nv, auto lw) { launch_ln_bwd32<float, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); });
     if (done) return check_launch("peneo_layernorm_bwd");
   }
   dim3 grid(ln_grid(rows, 8));  // <= 256 blocks: each wave reduces several rows; one atomic per column per block
@@ -474,7 +497,7 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
 // has no same-address atomics at its end and can run one row per half-wave.
 extern "C" int64_t peneo_layernorm_bwd_partial_rows(int dtype, int64_t rows, int H) {
   if (rows <= 0 || (dtype != PENEO_F32 && dtype != PENEO_BF16)) return 0;
-  const bool ok = dtype == PENEO_BF16 ? ln32_dispatch<bf16_t>(H, [](auto) {}) : ln32_dispatch<float>(H, [](auto) {});
+  const bool ok = dtype == PENEO_BF16 ? ln32_dispatch<bf16_t>(H, [](auto, auto) {}) : ln32_dispatch<float>(H, [](auto, auto) {});
   return ok ? ln_partial_rows(rows) : 0;
 }
 
@@ -495,8 +518,8 @@ extern "C" int peneo_layernorm_bwd_partial(int dtype, const void* dy, int64_t dy
                 "peneo_layernorm_bwd_partial: rows must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PENEO_BF16)
-    ln32_dispatch<bf16_t>(H, [&](auto nv) { launch_ln_bwd32<bf16_t, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, nullptr, nullptr, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, partials, partial_rows); });
+    ln32_dispatch<bf16_t>(H, [&](auto nv, auto lw) { launch_ln_bwd32<bf16_t, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, nullptr, nullptr, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, partials, partial_rows); });
   else
-    ln32_dispatch<float>(H, [&](auto nv) { launch_ln_bwd32<float, decltype(nv)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, nullptr, nullptr, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, partials, partial_rows); });
+    ln32_dispatch<float>(H, [&](auto nv, auto lw) { launch_ln_bwd32<float, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, nullptr, nullptr, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, partials, partial_rows); });
   return check_launch("peneo_layernorm_bwd_partial");
 }

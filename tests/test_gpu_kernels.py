@@ -179,7 +179,7 @@ def test_cast_copy_colsum(ops):
 
 # ---------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H", [768, 64, 1024, 24, 256, 192])
+@pytest.mark.parametrize("H", [768, 64, 1024, 24, 256, 192, 384, 96])
 def test_layernorm_fwd_bwd(ops, dtype, H):
     rows = 517
     g = torch.Generator().manual_seed(H)
@@ -201,7 +201,7 @@ def test_layernorm_fwd_bwd(ops, dtype, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("H", [768, 48])
+@pytest.mark.parametrize("H", [768, 48, 192])
 def test_layernorm_dropout_fwd_bwd_share_the_mask(ops, dtype, H):
     rows = 300
     g = torch.Generator().manual_seed(H + 1)
