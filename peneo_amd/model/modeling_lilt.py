@@ -244,8 +244,7 @@ class _LiltLayerStage(torch.autograd.Function):
         R = x.shape[0]
         cat = torch.empty((R, 3 * nh * dc), dtype=dt, device=dev)
         ops.head_concat(qkv[:, :H], lqkv[:, :Hl], nh, cat[:, :nh * dc], 1.0 / math.sqrt(d), 1.0 / math.sqrt(dl))
-        ops.head_concat(qkv[:, H:2 * H], lqkv[:, Hl:2 * Hl], nh, cat[:, nh * dc:2 * nh * dc])
-        ops.head_concat(qkv[:, 2 * H:], lqkv[:, 2 * Hl:], nh, cat[:, 2 * nh * dc:])
+        ops.head_concat(qkv[:, H:], lqkv[:, Hl:], 2 * nh, cat[:, nh * dc:])      # k and v in one launch: 2 nh "heads"
         qc, kc, vc = cat[:, :nh * dc], cat[:, nh * dc:2 * nh * dc], cat[:, 2 * nh * dc:]
         attc, lse = ops.attn_fwd(qc, kc, vc, B, nh, S, dc, 1.0, None, st.key_bias, drop_p=seeds.p_attn,
                                  drop_seed=seeds.seed(site))
@@ -299,8 +298,7 @@ class _LiltLayerStage(torch.autograd.Function):
         dqkv = torch.empty((R, 3 * H), dtype=dt, device=dev)
         dlqkv = torch.empty((R, 3 * Hl), dtype=dt, device=dev)
         ops.head_split(dcat[:, :nh * dc], nh, dqkv[:, :H], dlqkv[:, :Hl], 1.0 / math.sqrt(d), 1.0 / math.sqrt(dl))
-        ops.head_split(dcat[:, nh * dc:2 * nh * dc], nh, dqkv[:, H:2 * H], dlqkv[:, Hl:2 * Hl])
-        ops.head_split(dcat[:, 2 * nh * dc:], nh, dqkv[:, 2 * H:], dlqkv[:, 2 * Hl:])
+        ops.head_split(dcat[:, nh * dc:], 2 * nh, dqkv[:, H:], dlqkv[:, Hl:])
         Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
         Wlqkv = wc.cat_rows(f"L{idx}.lqkv", [lwq, lwk, lwv], dt)
         wg = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)

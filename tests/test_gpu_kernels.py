@@ -549,9 +549,10 @@ def test_head_transpose(ops):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_head_concat_split(ops, dtype):
+@pytest.mark.parametrize("nh,da,db", [(4, 48, 12), (12, 64, 16), (24, 64, 16)])   # scalar form; 16-byte form (LiLT-base q, k+v)
+def test_head_concat_split(ops, dtype, nh, da, db):
     """LiLT's [text | layout] per-head packing and its inverse, on strided slices of fused buffers."""
-    R, nh, da, db = 77, 4, 48, 12
+    R = 77
     g = torch.Generator().manual_seed(9)
     a = torch.randn(R, 3 * nh * da, generator=g).to(DEV).to(dtype)
     b = torch.randn(R, 3 * nh * db, generator=g).to(DEV).to(dtype)
