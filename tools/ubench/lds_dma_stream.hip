@@ -62,14 +62,64 @@ __global__ __launch_bounds__(256) void stream_kernel(const char* A, const char* 
   if (acc[0] == 123.f) sink[0] = acc[1];
 }
 
-int main() {
-  const int K = 3072, K2 = K * 2, ktiles = K / 64, maxg = 1024;
+// Hybrid fill: the A half of every k-tile by LDS-DMA (4 pieces per wave), the B half through registers (4 global_load_dwordx4 per
+// lane issued one k-tile ahead from inline asm, ds_write_b128 after the barrier).  MODE 1 = hybrid, MODE 2 = both halves through
+// registers.  Answers whether the ~20 B/clk of the all-DMA stream is a limit of the DMA path or of the CU's vector-memory path.
+__device__ __forceinline__ void gload16(uint4& r, const char* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_hybrid_kernel(const char* A, const char* B, int K2, int ktiles, int work, float* sink, int gx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  int mt = blockIdx.x, nt = 0;
+  if (gx > 0) {
+    const int total = gridDim.x, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = xcd * q8 + min(xcd, r8) + slot;
+    mt = tile / gx; nt = tile % gx;
+  }
+  const char* a = A + ((size_t)mt * 128 + wave * 32 + (lane >> 3)) * K2 + (lane & 7) * 16;
+  const char* b = B + ((size_t)nt * 128 + (wave * 32 + (lane >> 3))) * K2 + (lane & 7) * 16;
+  const size_t rstep = (size_t)8 * K2;
+  uint4 rb[4], ra[4];
+  auto issue = [&](int kt) {
+    const uint32_t d = lds0 + (kt & 1) * 32768 + wave * 4096;
+    const char* pa = a + (size_t)kt * 128;
+    const char* pb = b + (size_t)kt * 128;
+    if (MODE == 1) { dma1k<0>(pa, d); dma1k<0>(pa + rstep, d + 1024); dma1k<0>(pa + 2 * rstep, d + 2048); dma1k<0>(pa + 3 * rstep, d + 3072); }
+    else { gload16(ra[0], pa); gload16(ra[1], pa + rstep); gload16(ra[2], pa + 2 * rstep); gload16(ra[3], pa + 3 * rstep); }
+    gload16(rb[0], pb); gload16(rb[1], pb + rstep); gload16(rb[2], pb + 2 * rstep); gload16(rb[3], pb + 3 * rstep);
+  };
+  f32x16 acc = {0};
+  bf16x8 fa = {0}, fb = {0};
+  issue(0);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    wait_vm<0>();                               // tile kt: DMA half landed, register half arrived
+    char* st = smem + (kt & 1) * 32768 + wave * 4096 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<uint4*>(st + 16384 + j * 1024) = rb[j];
+      if (MODE == 2) *reinterpret_cast<uint4*>(st + j * 1024) = ra[j];
+    }
+    if (kt + 1 < ktiles) issue(kt + 1);         // next tile's loads fly during this tile's compute
+    __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the ds_writes
+    __builtin_amdgcn_s_barrier();
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + (kt & 1) * 32768 + tid * 16);
+    fa = __builtin_bit_cast(bf16x8, v);
+    for (int w = 0; w < work; ++w) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (acc[0] == 123.f) sink[0] = acc[1];
+}
+
+int main(int argc, char** argv) {
+  const int K = argc > 2 ? atoi(argv[2]) : 3072, pad = argc > 1 ? atoi(argv[1]) : 0, K2 = K * 2 + pad, ktiles = K / 64, maxg = 1080;
+  printf("K = %d, row stride %d bytes (%d lines of 128 B)\n", K, K2, K2 / 128);
   char *A, *B; float* sink;
   hipMalloc(&A, (size_t)maxg * 128 * K2); hipMalloc(&B, (size_t)32 * 128 * K2); hipMalloc(&sink, 64);
   hipMemset(A, 0, (size_t)maxg * 128 * K2); hipMemset(B, 0, (size_t)32 * 128 * K2);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int work : {0, 16}) {
-    for (int depth = 2; depth <= 4; ++depth) {
+    for (int depth = 2; depth <= 2; ++depth) {
       for (int cfg = 0; cfg < 9; ++cfg) {
         const int grids[9] = {256, 270, 512, 1024, 270, 540, 810, 1080, 1024}, gxs[9] = {0, 0, 0, 0, 6, 6, 18, 24, 32};
         const int grid = grids[cfg], gx = gxs[cfg];
@@ -94,5 +144,25 @@ int main() {
       }
     }
   }
+  for (int mode = 1; mode <= 2; ++mode)
+    for (int work : {0, 16})
+      for (int cfg = 0; cfg < 4; ++cfg) {
+        const int grids[4] = {270, 540, 810, 1080}, gxs[4] = {6, 6, 18, 24};
+        const int grid = grids[cfg], gx = gxs[cfg];
+        auto launch = [&]() {
+          if (mode == 1) hipLaunchKernelGGL(stream_hybrid_kernel<1>, dim3(grid), dim3(256), 65536, 0, A, B, K2, ktiles, work, sink, gx);
+          else hipLaunchKernelGGL(stream_hybrid_kernel<2>, dim3(grid), dim3(256), 65536, 0, A, B, K2, ktiles, work, sink, gx);
+        };
+        for (int i = 0; i < 3; ++i) launch();
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        const int n = 20;
+        for (int i = 0; i < n; ++i) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1e3 / n;
+        printf("mfma/wave/k-tile %2d  %s  grid %4d n-tiles %2d : %7.1f us  = %5.2f us per k-tile per workgroup, %6.0f GB/s moved\n", work,
+               mode == 1 ? "HYBRID (A dma, B regs)" : "REGISTERS (A and B)   ", grid, gx, us, us / ktiles, (double)grid * ktiles * 32768 / us / 1e3);
+      }
   return 0;
 }
