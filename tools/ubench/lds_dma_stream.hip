@@ -111,6 +111,43 @@ __global__ __launch_bounds__(256) void stream_hybrid_kernel(const char* A, const
   if (acc[0] == 123.f) sink[0] = acc[1];
 }
 
+// k-tiles of 32 elements (64-byte rows, 16 KiB per k-tile, two stages = 32 KiB): up to four workgroups per CU.  Does the aggregate
+// fill rate go up with the occupancy?
+__global__ __launch_bounds__(256) void stream_k32_kernel(const char* A, const char* B, int K2, int ktiles32, int work, float* sink, int gx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  int mt = blockIdx.x, nt = 0;
+  if (gx > 0) {
+    const int total = gridDim.x, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = xcd * q8 + min(xcd, r8) + slot;
+    mt = tile / gx; nt = tile % gx;
+  }
+  // piece = 16 rows x 64 bytes; this wave moves pieces 2w, 2w+1 of A and of B (32 rows each)
+  const char* a = A + ((size_t)mt * 128 + wave * 32 + (lane >> 2)) * K2 + (lane & 3) * 16;
+  const char* b = B + ((size_t)nt * 128 + wave * 32 + (lane >> 2)) * K2 + (lane & 3) * 16;
+  const size_t rstep = (size_t)16 * K2;
+  auto issue = [&](int kt) {
+    const uint32_t d = lds0 + (kt & 1) * 16384 + wave * 2048;
+    const char* pa = a + (size_t)kt * 64;
+    const char* pb = b + (size_t)kt * 64;
+    dma1k<0>(pa, d); dma1k<0>(pa + rstep, d + 1024);
+    dma1k<0>(pb, d + 8192); dma1k<0>(pb + rstep, d + 8192 + 1024);
+  };
+  f32x16 acc = {0};
+  bf16x8 fa = {0}, fb = {0};
+  issue(0);
+  for (int kt = 0; kt < ktiles32; ++kt) {
+    if (kt + 1 < ktiles32) { issue(kt + 1); wait_vm<4>(); } else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + (kt & 1) * 16384 + tid * 16);
+    fa = __builtin_bit_cast(bf16x8, v);
+    for (int w = 0; w < work; ++w) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (acc[0] == 123.f) sink[0] = acc[1];
+}
+
 int main(int argc, char** argv) {
   const int K = argc > 2 ? atoi(argv[2]) : 3072, pad = argc > 1 ? atoi(argv[1]) : 0, K2 = K * 2 + pad, ktiles = K / 64, maxg = 1080;
   printf("K = %d, row stride %d bytes (%d lines of 128 B)\n", K, K2, K2 / 128);
@@ -144,6 +181,22 @@ int main(int argc, char** argv) {
       }
     }
   }
+  for (int work : {0, 8})
+    for (int cfg = 0; cfg < 4; ++cfg) {
+      const int grids[4] = {270, 540, 810, 1080}, gxs[4] = {6, 6, 18, 24};
+      const int grid = grids[cfg], gx = gxs[cfg];
+      auto launch = [&]() { hipLaunchKernelGGL(stream_k32_kernel, dim3(grid), dim3(256), 32768, 0, A, B, K2, 2 * ktiles, work, sink, gx); };
+      for (int i = 0; i < 3; ++i) launch();
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      const int n = 20;
+      for (int i = 0; i < n; ++i) launch();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double us = ms * 1e3 / n;
+      printf("mfma/wave/k-tile %2d  K-TILE 32, 32 KiB per workgroup  grid %4d n-tiles %2d : %7.1f us  = %5.2f us per 64 k per workgroup, %6.0f GB/s moved\n",
+             work, grid, gx, us, us / ktiles, (double)grid * ktiles * 32768 / us / 1e3);
+    }
   for (int mode = 1; mode <= 2; ++mode)
     for (int work : {0, 16})
       for (int cfg = 0; cfg < 4; ++cfg) {
