@@ -64,9 +64,11 @@ def build_model(size: str, dtype, backbone: str = "layoutlmv3"):
 
 
 def cpu_baseline(pcfg, seq_len, n_lines, seed):
-    """The oracle (CPU restatement of the reference, pinned to reference-generated goldens) timed on the host
-    cores for ONE document, forward + backward, fp32.  Thread count is capped: oversubscribing the 256-thread
-    host made the as-executed form (materialised [N, N, 2D] handshaking + one-hot bias GEMMs) take 181 s."""
+    """The oracle (CPU restatement of the reference, pinned to reference-generated goldens) timed on the host cores for ONE
+    document, forward + backward, fp32 — in the reference's AS-EXECUTED form (materialised [N, N, 2D] handshaking input and
+    one-hot bias GEMMs, peneo_decoder.py:164-175) as `value`, and in the algebraically reduced form (a_i + b_j) the GPU path
+    is built on as `decomposed_value`.  The thread count is capped: oversubscribing the 256-thread host made the
+    as-executed form take 181 s instead of 3.5 s."""
     from oracle import peneo_oracle as O
     from peneo_amd.data import synthetic_rfund_batch
     from peneo_amd.model import PEneoConfig, PEneoModel
@@ -77,20 +79,28 @@ def cpu_baseline(pcfg, seq_len, n_lines, seed):
           for k, v in m.state_dict().items()}
     del m
     batch = synthetic_rfund_batch(1, seq_len, n_lines, pcfg["backbone_config"]["vocab_size"], seed=seed)
-    times = []
-    for _ in range(4):                               # one warm-up + three timed passes, ~3 s each
-        for v in sd.values():
-            if v.is_floating_point() and v.requires_grad:
-                v.grad = None
-        t0 = time.perf_counter()
-        out = O.peneo_forward(sd, pcfg, batch, training=False, as_executed=False)
-        out["loss"].backward()
-        times.append(time.perf_counter() - t0)
-    dt = sorted(times[1:])[1]
+
+    def timed(as_executed, n):
+        times = []
+        for _ in range(n):
+            for v in sd.values():
+                if v.is_floating_point() and v.requires_grad:
+                    v.grad = None
+            t0 = time.perf_counter()
+            out = O.peneo_forward(sd, pcfg, batch, training=False, as_executed=as_executed)
+            out["loss"].backward()
+            times.append(time.perf_counter() - t0)
+        return times
+
+    asx = timed(True, 4)                              # one warm-up + three timed passes, ~3.5 s each
+    red = timed(False, 3)                             # one warm-up + two timed passes, ~2.6 s each
+    dt, dr = sorted(asx[1:])[1], min(red[1:])
     return {"value": round(1.0 / dt, 4), "unit": "docs/s", "cores": threads, "kind": "port",
-            "sample": f"1 document seq{seq_len}/{n_lines} lines, fwd+bwd fp32, algebraically reduced handshaking "
-                      f"(a_i + b_j) — the reference's as-executed form is slower still; median of 3 after 1 warm-up "
-                      f"({dt:.2f}s; cold {times[0]:.1f}s) on {threads} of {os.cpu_count()} host threads"}
+            "decomposed_value": round(1.0 / dr, 4),
+            "sample": f"1 document seq{seq_len}/{n_lines} lines, fwd+bwd fp32 on {threads} of {os.cpu_count()} host threads: the "
+                      f"reference's as-executed form (materialised [N,N,2D] handshaking, one-hot bias GEMMs), median of 3 after 1 "
+                      f"warm-up ({dt:.2f}s; cold {asx[0]:.1f}s); decomposed_value = the algebraically reduced form (a_i + b_j), "
+                      f"best of 2 after 1 warm-up ({dr:.2f}s)"}
 
 
 def main():
