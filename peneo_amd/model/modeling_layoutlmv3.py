@@ -447,18 +447,27 @@ class _LayerStage(torch.autograd.Function):
         ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv,
                      st.g_bias if ds_out is None else None, drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1),
                      ds_out=ds_out)
-        if ds_out is not None and idx % model.rel_group == 0:
-            # the bias-table gradient of layers idx .. idx+group-1 (their dS^T slabs are complete): LDS-atomic bound, so it
-            # runs beside the GEMMs of the remaining layers instead of as one ~1 ms tail after layer 0
-            hi = min(idx + model.rel_group, cfg.num_hidden_layers)
-            rel_stream = model.side_stream(dev, "rel")       # its own stream: joined only by _EmbedStage.backward
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(rel_stream):
-                rel_stream.wait_event(ev)
-                model.reduce_rel_group(st, idx, hi, B, T)
         _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
+        def launch_rel():
+            if ds_out is not None and idx % model.rel_group == 0:
+                # the bias-table gradient of layers idx .. idx+group-1 (their dS^T slabs are complete), on its own stream
+                # (joined only by _EmbedStage.backward): LDS-atomic and HBM bound
+                hi = min(idx + model.rel_group, cfg.num_hidden_layers)
+                rel_stream = model.side_stream(dev, "rel")
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(rel_stream):
+                    rel_stream.wait_event(ev)
+                    model.reduce_rel_group(st, idx, hi, B, T)
+
+        # The reduction goes out BEHIND this stage's last dgrad GEMM (PENEO_REL_AFTER_DGRAD=0: in front of it): started first,
+        # the 277 us reduction stretched that GEMM from 54 to 247 us at the tail of the step; behind it, it runs beside the
+        # embedding stage's small kernels
+        if not model.rel_after_dgrad:
+            launch_rel()
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
+        if model.rel_after_dgrad:
+            launch_rel()
         if side is not None:
             if model.defer_wgrad_join and DEFER_ALLOWED[0] and all(p.grad is None for p in ctx.params):
                 # joined one stage later (engine.py): the critical path does not wait for dW_qkv
@@ -514,6 +523,7 @@ class LayoutLMv3Model(nn.Module):
         self.wgrad_group = os.environ.get("PENEO_WGRAD_GROUP", "0") != "0"
         self.enc_split = int(os.environ.get("PENEO_ENC_SPLIT", "1"))   # document groups (HIP streams) through the encoder
         self.enc_groups = [int(v) for v in os.environ.get("PENEO_ENC_GROUPS", "").split(",") if v.strip()]   # uneven groups
+        self.rel_after_dgrad = os.environ.get("PENEO_REL_AFTER_DGRAD", "1") != "0"
         self.rel_group = int(os.environ.get("PENEO_REL_GROUP", "1000"))   # layers per bias-table reduction; groups of 4 run beside the
         # remaining layers but measured slower (285 vs 302 docs/s): the histogram kernel crowds the GEMMs off the CUs
         self._luts = {}
