@@ -290,7 +290,9 @@ def test_training_trajectory_follows_the_reference(tok):
             assert abs(got - v) <= 2e-4 * max(abs(v), 1e-2), (step, k, got, v)   # measured: 2e-5
     sd = model.state_dict()
     for k, want in tr["final"].items():
-        assert rel_err(sd[k].cpu(), want) < 1e-3, (k, rel_err(sd[k].cpu(), want))
+        # AdamW turns a gradient into a step of about lr whatever its size, so elements whose gradients are at rounding level
+        # (the relative-position tables) may differ by a fraction of one step: 12 steps of lr 2e-4 on weights of ~0.03
+        assert rel_err(sd[k].cpu(), want) < 1e-2, (k, rel_err(sd[k].cpu(), want))
     print("worst relative loss deviation over the trajectory:", worst)
 
 
