@@ -91,6 +91,23 @@ def test_config_roundtrip(tmp_path):
     assert back.model_type == "peneo"
 
 
+def test_model_save_and_from_pretrained_roundtrip(tmp_path):
+    """``PEneoModel.save_pretrained`` / ``from_pretrained(dir, config=config)`` (start/run_rfund.py:199-202, Trainer.save_model):
+    the checkpoint keeps the reference's 241-tensor layout and comes back bit for bit (no GPU needed: nothing is launched)."""
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    fx = load_golden("lmv3_tiny")
+    cfg = PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"})
+    model = PEneoModel(cfg)
+    model.load_state_dict(fx["state_dict"], strict=True)
+    model.save_pretrained(tmp_path)
+    back = PEneoModel.from_pretrained(tmp_path, config=PEneoConfig.from_pretrained(tmp_path))
+    a, b = model.state_dict(), back.state_dict()
+    assert list(a) == list(b) == list(fx["state_dict"])
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    # decoder parameters keep the prefix the reference's optimizer groups key on (pipeline/trainer.py:280-284)
+    assert sum(1 for n, _ in back.named_parameters() if "peneo_decoder" in n) == 26
+
+
 def test_tagging_scheme_matches_oracle():
     from oracle import peneo_oracle as O
     from peneo_amd.data import spots_to_shaking_tag
