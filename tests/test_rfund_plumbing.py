@@ -298,3 +298,33 @@ def test_training_trajectory_follows_the_reference(tok):
 
 def rel_err(a, b):
     return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-6))
+
+
+@pytest.mark.gpu
+def test_huggingface_trainer_drives_the_model(tok, tmp_path):
+    """The reference trains through a ``transformers.Trainer`` subclass (pipeline/trainer.py); the stock Trainer must accept
+    this model, dataset and collator unchanged: batches with string lists pass through ``model(**inputs)``, the
+    ``PEneoOutput`` carries the loss, ``save_model`` writes a checkpoint ``from_pretrained`` reads back."""
+    from transformers import Trainer, TrainingArguments
+    from peneo_amd.data import DataCollatorForPEneo
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    tr = torch.load(os.path.join(HERE, "golden", "rfund_train.pt"), weights_only=False)
+    ds, info = _dataset(tok, "train", "layoutlmv3-base")
+    coll = DataCollatorForPEneo(tokenizer=tok, image_processor=info.image_processor(), max_length=info.max_token_len,
+                                require_image=True, add_cls_token=True, add_sep_token=True)
+    cfg = PEneoConfig(**{k: v for k, v in tr["config"].items() if k != "model_type"})
+    model = PEneoModel(cfg)
+    model.load_state_dict(tr["init"], strict=True)
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, max_steps=4, learning_rate=2e-4,
+                             weight_decay=0.01, remove_unused_columns=False, report_to=[], save_strategy="no",
+                             logging_steps=1, disable_tqdm=True, dataloader_num_workers=0, seed=3)
+    trainer = Trainer(model=model, args=args, data_collator=coll, train_dataset=ds)
+    result = trainer.train()
+    losses = [h["loss"] for h in trainer.state.log_history if "loss" in h]
+    assert result.global_step == 4 and len(losses) == 4
+    assert all(l == l and l < 10 for l in losses) and losses[-1] < losses[0]
+    assert abs(losses[0] - tr["losses"][0]["loss"]) < 1e-3          # first step = the fixture's first step (same init, same batch)
+    trainer.save_model(str(tmp_path / "final"))
+    back = PEneoModel.from_pretrained(str(tmp_path / "final"), config=PEneoConfig.from_pretrained(str(tmp_path / "final")))
+    sd, bd = trainer.model.state_dict(), back.state_dict()
+    assert all(torch.equal(sd[k].cpu(), bd[k].cpu()) for k in sd)
