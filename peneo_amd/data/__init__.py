@@ -1,3 +1,3 @@
 from .synthetic import synthetic_rfund_batch, spots_to_shaking_tag  # noqa: F401
 from .collator import DataCollatorForPEneo, PEneoImageProcessor  # noqa: F401
-from .rfund import RFUNDDataset  # noqa: F401
+from .rfund import RFUNDDataset, SIBRDataset  # noqa: F401

@@ -109,21 +109,35 @@ class RFUNDDataset(Dataset):
             line_text = line_text.replace(bad, good)
         return string_f2h(line_text)
 
+    # ---- what differs between the data sets: where documents come from, how a line's text and box are read ---------------
+    def _document(self, index: int) -> dict:
+        return self.annotation[index]
+
+    def _image_path(self, fname: str) -> str:
+        return os.path.join(self.image_root, fname)
+
+    def _line_text(self, text: str, first: bool) -> str:
+        """Later lines of an entity get a leading blank (not in zh / ja), then the character repairs (:130-134)."""
+        glue = "" if first or self.language in ("zh", "ja") else " "
+        return self._special_text_replace(glue + text)
+
+    def _line_box(self, bbox) -> list:
+        return list(bbox)
+
     # ---- pass 1: tokenise the lines entity by entity (:123-203) -----------------------------------------------------------
     def _collect(self, doc: dict) -> _Page:
         page = _Page()
         width, height = doc["img"]["width"], doc["img"]["height"]
-        glue = "" if self.language in ("zh", "ja") else " "
         for entity in doc["entities"]:
             kept_text: List[str] = []
             for line in entity["lines"]:
-                text = self._special_text_replace((glue if kept_text else "") + line["text"])
+                text = self._line_text(line["text"], first=not kept_text)
                 tokens = self.tokenizer.tokenize(text)
                 pieces = self.tokenizer_fetcher(text, tokens) if self.tokenizer_fetcher is not None else tokens
                 if len(pieces) == 0:
                     page.empty_lines.add(line["id"])
                     continue
-                box = list(line["bbox"])
+                box = self._line_box(line["bbox"])
                 if self.apply_box_aug:
                     box = list(box_augmentation(tuple(box), width, height))
                     for lo, hi in ((0, 2), (1, 3)):  # keep the jittered box at least one pixel wide and high
@@ -146,7 +160,7 @@ class RFUNDDataset(Dataset):
         return page
 
     def __getitem__(self, index):
-        doc = self.annotation[index]
+        doc = self._document(index)
         fname = doc["img"]["fname"]
         size = (doc["img"]["width"], doc["img"]["height"])
         page = self._collect(doc)
@@ -225,7 +239,7 @@ class RFUNDDataset(Dataset):
         assert len(grp_head) == len(grp_tail), f"line relation length mismatch {fname}"
         return {
             "fname": fname,
-            "image_path": os.path.join(self.image_root, fname),
+            "image_path": self._image_path(fname),
             "input_ids": input_ids,
             "bbox": bbox,
             "orig_bbox": orig_bbox,
@@ -237,3 +251,46 @@ class RFUNDDataset(Dataset):
             "line_grouping_head_rel_matrix_spots": grp_head,
             "line_grouping_tail_rel_matrix_spots": grp_tail,
         }
+
+
+class SIBRDataset(RFUNDDataset):
+    """SIBR (reference: data/datasets/sibr.py:25-460): one json per page under ``<data_root>/converted_label/``, listed by
+    ``<data_root>/<split>.txt``, images under ``<data_root>/images/``.  The item is built exactly like an RFUND item (the two
+    reference classes share everything from the reading-order pass on); what differs: no language, line texts are tokenised
+    as they are (no leading blank for later lines, no character repairs: :118-121) and box coordinates are truncated to
+    integers (:137-143)."""
+
+    SPLIT_LIST = ["train", "test"]
+
+    def __init__(self, data_root: str, split: str, tokenizer, tokenizer_fetcher: Optional[Callable] = None,
+                 max_token_len: int = 511, add_cls_token: bool = False, add_sep_token: bool = False,
+                 apply_box_aug: bool = False, **kwargs) -> None:
+        Dataset.__init__(self)
+        assert split in self.SPLIT_LIST, f"Split {split} not supported, should be one of {self.SPLIT_LIST}"
+        self.split, self.language = split, None
+        if isinstance(tokenizer, str):
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(tokenizer)
+        elif hasattr(tokenizer, "tokenizer") and not hasattr(tokenizer, "convert_tokens_to_ids"):
+            tokenizer = tokenizer.tokenizer
+        self.tokenizer, self.tokenizer_fetcher = tokenizer, tokenizer_fetcher
+        self.image_root = os.path.join(data_root, "images")
+        self.annotation_root = os.path.join(data_root, "converted_label")
+        with open(os.path.join(data_root, f"{split}.txt"), "r") as f:
+            self.annotation_fname_list = [os.path.basename(x.strip()) for x in f.readlines()]
+        self.max_token_len = max_token_len
+        self.add_cls_token, self.add_sep_token = add_cls_token, add_sep_token
+        self.apply_box_aug = apply_box_aug
+
+    def __len__(self) -> int:
+        return len(self.annotation_fname_list)
+
+    def _document(self, index: int) -> dict:
+        with open(os.path.join(self.annotation_root, self.annotation_fname_list[index]), "r", encoding="utf-8") as f:
+            return json.load(f)
+
+    def _line_text(self, text: str, first: bool) -> str:
+        return text
+
+    def _line_box(self, bbox) -> list:
+        return [int(v) for v in bbox]

@@ -6,6 +6,8 @@ Writes (all committed; data, no reference source):
   tests/golden/rfund/en.train.json, en.val.json   RFUND-schema annotations authored here (docs/documentation.md:196-240)
   tests/golden/rfund/images/en/*.png              small synthetic page images
   tests/golden/rfund/tokenizer/tokenizer.json     a byte-level BPE trained here on the fixture's own text
+  tests/golden/sibr/, tests/golden/sibr_items.pt  (--only-sibr: just these) the same pages in SIBR's file layout and the
+                                                  reference SIBRDataset's items
   tests/golden/rfund_train.pt                     (--only-train: just this) 12 AdamW steps of the reference on the collated batch
                                                   from a stored initial state: loss of every step, six final tensors
   tests/golden/rfund_plumbing.pt                  what the reference made of them:
@@ -359,9 +361,54 @@ def make_train_trajectory(steps: int = 12) -> None:
     print(f"-> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def make_sibr() -> None:
+    """tests/golden/sibr/ (one json per page under converted_label/, split lists, images) from the same two synthetic pages, with
+    fractional box coordinates (the class truncates them), and tests/golden/sibr_items.pt: the reference SIBRDataset's items
+    (layoutlmv3 flags, plain and with box jitter under random.seed)."""
+    import shutil
+    import_reference()
+    from data.datasets.sibr import SIBRDataset
+    from model import backbone_mapping as ref_bm
+    root = os.path.join(HERE, "sibr")
+    os.makedirs(os.path.join(root, "converted_label"), exist_ok=True)
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    docs = json.load(open(os.path.join(ROOT, "en.val.json"), encoding="utf-8"))["documents"]
+    names = []
+    for k, d in enumerate(docs):
+        for e in d["entities"]:
+            for j, ln in enumerate(e["lines"]):
+                ln["bbox"] = [v + (0.7 if (j + k) % 2 else 0.0) for v in ln["bbox"]]
+                # SIBRDataset tokenises the text as it is (no character repairs): keep it to what the byte-level fetcher can
+                # align, i.e. ASCII (the reference raises IndexError on the RFUND fixture's accents and full-width forms)
+                if not ln["text"].isascii():
+                    ln["text"] = "Topic of resume - ABC12"
+        name = f"page_{k}.json"
+        names.append(name)
+        with open(os.path.join(root, "converted_label", name), "w", encoding="utf-8") as f:
+            json.dump(d, f, ensure_ascii=False, indent=1)
+        shutil.copyfile(os.path.join(ROOT, "images", "en", d["img"]["fname"]), os.path.join(root, "images", d["img"]["fname"]))
+    for split in ("train", "test"):
+        with open(os.path.join(root, f"{split}.txt"), "w") as f:
+            f.write("".join(f"converted_label/{n}\n" for n in names))
+    tok = load_tokenizer()
+    kw = dict(tokenizer=tok, tokenizer_fetcher=ref_bm.fetcher_LayoutLMv3Tokenizer, max_token_len=510, add_cls_token=True,
+              add_sep_token=True)
+    ds = SIBRDataset(data_root=root, split="test", **kw)
+    fx = {"items": [ds[k] for k in range(len(ds))]}
+    random.seed(4321)
+    ds_aug = SIBRDataset(data_root=root, split="train", apply_box_aug=True, **kw)
+    fx["items_boxaug"] = [ds_aug[k] for k in range(len(ds_aug))]
+    path = os.path.join(HERE, "sibr_items.pt")
+    torch.save(fx, path)
+    print("sibr tokens per page:", [len(it["input_ids"]) for it in fx["items"]], f"-> {path} ({os.path.getsize(path) / 1e3:.0f} kB)")
+
+
 if __name__ == "__main__":
-    if "--only-train" in sys.argv:
+    if "--only-sibr" in sys.argv:
+        make_sibr()
+    elif "--only-train" in sys.argv:
         make_train_trajectory()
     else:
         main()
         make_train_trajectory()
+        make_sibr()

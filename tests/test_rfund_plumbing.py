@@ -328,3 +328,25 @@ def test_huggingface_trainer_drives_the_model(tok, tmp_path):
     back = PEneoModel.from_pretrained(str(tmp_path / "final"), config=PEneoConfig.from_pretrained(str(tmp_path / "final")))
     sd, bd = trainer.model.state_dict(), back.state_dict()
     assert all(torch.equal(sd[k].cpu(), bd[k].cpu()) for k in sd)
+
+
+def test_sibr_dataset_items_match_reference(tok):
+    """The reference's second data format (data/datasets/sibr.py, start/run_sibr.py): one json per page, split lists, fractional
+    boxes truncated to integers, texts taken as they are."""
+    from peneo_amd.data import SIBRDataset
+    from peneo_amd.model.backbone_mapping import BACKBONE_MAPPING
+    fxs = torch.load(os.path.join(HERE, "golden", "sibr_items.pt"), weights_only=False)
+    info = BACKBONE_MAPPING["layoutlmv3-base"]
+    kw = dict(data_root=os.path.join(HERE, "golden", "sibr"), tokenizer=tok, tokenizer_fetcher=info.tokenizer_fetcher,
+              max_token_len=info.max_token_len, add_cls_token=info.add_cls_token, add_sep_token=info.add_sep_token)
+    ds = SIBRDataset(split="test", **kw)
+    assert len(ds) == len(fxs["items"]) == 2
+    for k in range(len(ds)):
+        _same_item(ds[k], fxs["items"][k])
+    assert all(isinstance(v, int) for box in fxs["items"][1]["orig_bbox"] for v in box)
+    random.seed(4321)
+    ds_aug = SIBRDataset(split="train", apply_box_aug=True, **kw)
+    for k in range(len(ds_aug)):
+        _same_item(ds_aug[k], fxs["items_boxaug"][k])
+    with pytest.raises(AssertionError):
+        SIBRDataset(split="dev", **kw)
