@@ -1,3 +1,5 @@
+"""CPU oracle, one base-size document fwd + bwd on 32 host threads: the reference's as-executed form (materialised [N, N, 2D]
+handshaking input, one-hot bias GEMMs) against the algebraically reduced form — the two figures of bench.py's cpu_baseline."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, bench

@@ -1,3 +1,5 @@
+"""60 real training steps (forward, backward, FusedAdamW) at config 2: loss and allocator figures every 10 steps — nothing the
+held side-stream joins keep alive may accumulate."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, bench
