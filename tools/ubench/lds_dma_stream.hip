@@ -111,6 +111,41 @@ __global__ __launch_bounds__(256) void stream_hybrid_kernel(const char* A, const
   if (acc[0] == 123.f) sink[0] = acc[1];
 }
 
+// the same 32 KiB k-tiles issued by EIGHT waves (4 pieces each) instead of four (8 each): does the fill rate of a CU depend on how many
+// waves issue?
+__global__ __launch_bounds__(512) void stream_w8_kernel(const char* A, const char* B, int K2, int ktiles, int work, float* sink, int gx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  int mt = blockIdx.x, nt = 0;
+  if (gx > 0) {
+    const int total = gridDim.x, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = xcd * q8 + min(xcd, r8) + slot;
+    mt = tile / gx; nt = tile % gx;
+  }
+  const bool isb = wave >= 4;                       // waves 0-3 move the A tile, 4-7 the B tile, 4 pieces each
+  const int w4 = wave & 3;
+  const char* src = (isb ? B + (size_t)nt * 128 * K2 : A + (size_t)mt * 128 * K2) + ((size_t)w4 * 32 + (lane >> 3)) * K2 + (lane & 7) * 16;
+  const size_t rstep = (size_t)8 * K2;
+  auto issue = [&](int kt) {
+    const uint32_t d = lds0 + (kt & 1) * 32768 + (isb ? 16384 : 0) + w4 * 4096;
+    const char* ps = src + (size_t)kt * 128;
+    dma1k<0>(ps, d); dma1k<0>(ps + rstep, d + 1024); dma1k<0>(ps + 2 * rstep, d + 2048); dma1k<0>(ps + 3 * rstep, d + 3072);
+  };
+  f32x16 acc = {0};
+  bf16x8 fa = {0}, fb = {0};
+  issue(0);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + 1 < ktiles) { issue(kt + 1); wait_vm<4>(); } else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + (kt & 1) * 32768 + (tid & 255) * 16);
+    fa = __builtin_bit_cast(bf16x8, v);
+    for (int w = 0; w < work; ++w) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (acc[0] == 123.f) sink[0] = acc[1];
+}
+
 // k-tiles of 32 elements (64-byte rows, 16 KiB per k-tile, two stages = 32 KiB): up to four workgroups per CU.  Does the aggregate
 // fill rate go up with the occupancy?
 __global__ __launch_bounds__(256) void stream_k32_kernel(const char* A, const char* B, int K2, int ktiles32, int work, float* sink, int gx) {
@@ -181,6 +216,22 @@ int main(int argc, char** argv) {
       }
     }
   }
+  for (int work : {0, 8})
+    for (int cfg = 0; cfg < 4; ++cfg) {
+      const int grids[4] = {270, 540, 810, 1080}, gxs[4] = {6, 6, 18, 24};
+      const int grid = grids[cfg], gx = gxs[cfg];
+      auto launch = [&]() { hipLaunchKernelGGL(stream_w8_kernel, dim3(grid), dim3(512), 65536, 0, A, B, K2, ktiles, work, sink, gx); };
+      for (int i = 0; i < 3; ++i) launch();
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      const int n = 20;
+      for (int i = 0; i < n; ++i) launch();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double us = ms * 1e3 / n;
+      printf("mfma/wave/k-tile %2d  EIGHT WAVES per 32 KiB k-tile  grid %4d n-tiles %2d : %7.1f us  = %5.2f us per k-tile per workgroup, %6.0f GB/s moved\n",
+             work, grid, gx, us, us / ktiles, (double)grid * ktiles * 32768 / us / 1e3);
+    }
   for (int work : {0, 8})
     for (int cfg = 0; cfg < 4; ++cfg) {
       const int grids[4] = {270, 540, 810, 1080}, gxs[4] = {6, 6, 18, 24};
