@@ -285,6 +285,11 @@ typedef struct peneo_pair_heads_desc {
   const void* w_packed;                /* from peneo_pair_heads_pack (both layers, MFMA fragment order) */
   const float* b1;                     /* [num_heads * D] */
   const float* b2;                     /* [sum classes] */
+  float drop_p;                        /* K12 dropout between the two classifier layers (model/peneo_decoder.py:261); 0 = off.
+                                          keep(b, p, n) is a pure function of (drop_seed, document, pair, hidden column):
+                                          the backward entry points regenerate it from the same two numbers.  Realised as
+                                          round(p * 2^16) / 2^16 with the matching 1 / (1 - p) scale */
+  uint32_t drop_seed;
 } peneo_pair_heads_desc;
 
 size_t peneo_pair_heads_packed_bytes(int dtype, int num_heads, int D);
@@ -329,6 +334,10 @@ typedef struct peneo_pair_dz_args {
   const float* dlogits[PENEO_MAX_HEADS];  /* [npairs, classes[h]] (already offset to the chunk) */
   const float* w2[PENEO_MAX_HEADS];       /* [classes[h], D] fp32 */
   const float* scale;                     /* [num_heads] device fp32 */
+  float drop_p;                           /* the forward's K12 dropout (peneo_pair_heads_desc): y and dz are masked and scaled */
+  uint32_t drop_seed;
+  int drop_doc;                           /* chunked entry points: document index b and packed index p of the chunk's first */
+  int64_t drop_pair0;                     /* pair, i.e. what the forward hashed (peneo_pair_bwd_fused walks all of them itself) */
 } peneo_pair_dz_args;
 size_t peneo_pair_dz_workspace_bytes(int num_heads, int D);
 int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const peneo_pair_dz_args* args, float* workspace,

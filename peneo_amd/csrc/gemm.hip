@@ -1302,6 +1302,7 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
   if (p.ep.pair_dz) {
     const peneo_pair_dz_args* a = p.ep.pair_dz;
     PENEO_REQUIRE(p.ep.pair_dz_ws, "peneo_gemm: pair_dz needs its workspace");
+    PENEO_REQUIRE(a->drop_p == 0.f, "peneo_gemm: the pair_dz epilogue has no classifier dropout (peneo_pair_bwd_fused / peneo_pair_dz do)");
     PENEO_REQUIRE(a->num_heads > 0 && a->num_heads <= PENEO_MAX_HEADS && a->D > 0 && (int64_t)a->num_heads * a->D == N && a->scale,
                   "peneo_gemm: pair_dz expects N == num_heads * D");
     for (int h = 0; h < a->num_heads; ++h)

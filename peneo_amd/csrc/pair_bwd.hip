@@ -12,8 +12,7 @@
 // Against the kernel chain it replaces (peneo_pair_x_fwd, peneo_pair_dz_fused, the du GEMM with its SiLU' epilogue,
 // peneo_pair_x_bwd) dz is read back from HBM once instead of twice, and neither a_i + b_j nor du ever go through memory.
 //
-// Work unit: one workgroup (4 waves, one per SIMD: the kernel lives on ~450 registers per lane, mostly the 32 x D du
-// accumulator of each wave) owns a block of 8 rows i x 16 columns j of the pair triangle, wave w the rows 2w, 2w+1.  With
+// Work unit: one workgroup owns a block of 8 rows i x 16 columns j of the pair triangle, wave w the rows 2w, 2w+1.  With
 // pairs blocked in 2-D the sums over j (d_a) stay inside a wave and the sums over i (d_b) need 8x fewer atomics than a
 // row-major walk of the triangle.  dz and x are written in this block order ("rows" below); the dW1 GEMM only needs both
 // in the SAME order.  Pairs of a block outside the triangle (i > j, or beyond N) carry dlogits = 0: their dz rows are 0.
@@ -79,6 +78,7 @@ struct PairBwdParams {
   float* part_a; float* part_b;  // per-block partial sums [B][ntiles][8][D] / [B][ntiles][16][D] fp32
   float* ws;                     // [PB_SLOTS][4 * nh*D]
   int ntiles;
+  uint32_t drop_thr16, drop_seed; float drop_scale;   // K12 dropout of the forward (0 = off): mask regenerated, never stored
   unsigned long long* dbg;       // optional (tools/): per wave of the first 256 blocks: cycles in the loop, cycles waiting at the top
 };
 
@@ -99,461 +99,17 @@ template <int KS> constexpr int pb_chunk_count(int j) { int n = 0; for (int f = 
 template <int KS> constexpr int pb_chunk_first(int j) { for (int f = 0; f < KS; ++f) if (f * 8 / KS == j) return f; return KS; }
 constexpr int PB_MAXC = 3;   // fragments per chunk (KS = 24)
 
+// v_writelane_b32: lane LANE of `v` receives the wave-uniform `s` (no builtin that compiles in the host pass)
+template <int LANE> __device__ __forceinline__ void pb_writelane(uint32_t& v, uint32_t s) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(s)), "n"(LANE));
+}
+
 #ifndef PB_DBG
 #define PB_DBG 0      // tools/ab_pb_dbg.sh: 65536 = packed-fp32 dz arithmetic in the wave-specialised kernel (reproduces the corruption)
 #endif
 #ifndef PB_ABLATE
 #define PB_ABLATE 0   // timing experiments (tools/): 1 no dz stores, 2 no du MFMAs, 4 no z MFMAs, 8 no epilogue, 16 no du-half DMA, 32 no DMA (ws kernel)
 #endif
-
-template <int KS, bool PIPE>
-__global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_fused_kernel(PairBwdParams p) {
-  using T = bf16_t;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HALF_BYTES = KS * 1024;              // z fragments of a slab (= du fragments of a slab)
-  constexpr int PW = KS / PB_WAVES >= 1 ? KS / PB_WAVES : 1;   // 1 KiB DMA pieces per wave per half slab
-  constexpr int DMA_WAVES = KS >= PB_WAVES ? PB_WAVES : KS;    // tiny D: fewer waves carry the stream
-  static_assert(KS % 2 == 0 && (KS >= PB_WAVES ? KS % PB_WAVES == 0 : true), "unsupported decoder width");
-  constexpr int NDT = KS / 2;                        // 32-column tiles of the decoder dim
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
-  char* sA = smem;                                                          // [2][HALF_BYTES] z operands
-  char* sB = smem + 2 * HALF_BYTES;                                         // [2][HALF_BYTES] du operands
-  float4* sCol = reinterpret_cast<float4*>(smem + 4 * HALF_BYTES);          // [ncol]: W2 rows 0..2 of the column, b1
-  float4* sG = sCol + ncol;                                                 // [PB_WAVES][32]
-  float4* sPart = sG + PB_WAVES * 32;                                       // [2][PB_WAVES][32]
-  char* sT = reinterpret_cast<char*>(sPart + 2 * PB_WAVES * 32);            // [PB_WAVES][32 rows][64 B] dz tiles (bf16, swizzled)
-
-  // ---- which block of the triangle ----
-  int ti = 0;
-  {
-    const int nti = pb_row_tiles(N);
-    while (ti + 1 < nti && pb_tiles_before(ti + 1, N) <= (int)blockIdx.x) ++ti;
-  }
-  const int tj = (ti >> 1) + ((int)blockIdx.x - pb_tiles_before(ti, N));
-  const int b = blockIdx.y;
-  const int i0 = ti * PB_TI + 2 * wave, j0 = tj * PB_TJ;
-  const int pi = i0 + (r32 >> 4), pj = j0 + (r32 & 15);
-  const bool pair_ok = pi < N && pj < N && pi <= pj;
-  const int ci = min(pi, N - 1), cj = min(pj, N - 1);
-  const int64_t mypair = pair_row_start(ci, N) + (cj - ci);                 // only used when pair_ok
-  const int64_t rows_per_doc = (int64_t)p.ntiles * PB_ROWS;
-  const int64_t row = (int64_t)b * rows_per_doc + (int64_t)blockIdx.x * PB_ROWS + wave * 32 + r32;
-  const int nslab = ncol / 32, spb = D / 32;
-
-  for (int n = tid; n < ncol; n += PB_WAVES * 64) {
-    const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
-    sCol[n] = make_float4(p.a.w2[h][k], Cn > 1 ? p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? p.a.w2[h][(int64_t)2 * D + k] : 0.f,
-                          p.b1[n]);
-  }
-
-  // ---- x = SiLU(a_i + b_j) as operand fragments (row = pair, k = decoder dim); also what the dW1 GEMM reads ----
-  const T* abd = p.ab + (int64_t)b * N * 2 * D;
-  const T* arow = abd + (int64_t)ci * 2 * D;
-  const T* brow = abd + (int64_t)cj * 2 * D + D;
-  T* x_row = p.x + row * D + 8 * half;
-  Frag<T> xf[KS];
-  {
-    constexpr int G = KS % 4 == 0 ? 4 : 2;
-    uint4 ra[2][G], rb[2][G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-      ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
-      rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
-    }
-#pragma unroll
-    for (int g = 0; g < KS / G; ++g) {
-      if (g + 1 < KS / G) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-          ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (G * (g + 1) + i) + 8 * half);
-          rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (G * (g + 1) + i) + 8 * half);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        float a[8], bb[8];
-        unpack16<T>(ra[g & 1][i], a);
-        unpack16<T>(rb[g & 1][i], bb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
-        xf[G * g + i] = pack_frag8<T>(a);
-        asm volatile("" : "+v"(xf[G * g + i].v.x), "+v"(xf[G * g + i].v.y), "+v"(xf[G * g + i].v.z), "+v"(xf[G * g + i].v.w) :: "memory");
-        *reinterpret_cast<uint4*>(x_row + 16 * (G * g + i)) = xf[G * g + i].v;
-      }
-    }
-  }
-  __syncthreads();                                          // sCol visible
-
-  // ---- weight stream ----
-  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (PW * 1024) + lane * 16;
-  const uint32_t adst = lds_addr(sA) + wave * (PW * 1024), bdst = lds_addr(sB) + wave * (PW * 1024);
-  auto dma_z = [&](int s) {    // z fragments of slab s -> sA[s & 1]
-    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (3 * HALF_BYTES), __builtin_amdgcn_readfirstlane(adst + (s & 1) * HALF_BYTES));
-  };
-  auto dma_u = [&](int s) {    // du fragments of slab s -> sB[s & 1]
-    if (wave < DMA_WAVES) lds_dma_units<0, PW>(wsrc + (int64_t)s * (3 * HALF_BYTES) + HALF_BYTES, __builtin_amdgcn_readfirstlane(bdst + (s & 1) * HALF_BYTES));
-  };
-
-  float* slot = p.ws + (int64_t)(blockIdx.x % PB_SLOTS) * 4 * ncol;
-  auto flush = [&](int s) {    // the wave that owns slab s adds the four waves' column sums of that slab to the workspace
-    if (wave == (s & (PB_WAVES - 1)) && lane < 32) {
-      const float4* src = sPart + (s & 1) * (PB_WAVES * 32) + lane;
-      float4 t = src[0];
-#pragma unroll
-      for (int w = 1; w < PB_WAVES; ++w) { const float4 u = src[w * 32]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-      float* dst = slot + s * 32 + lane;
-      atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
-    }
-  };
-  auto stage_g = [&](int h) {  // scale_h * dlogits_h of the wave's 32 pairs -> LDS, two adjacent pairs interleaved
-    const int Cn = p.a.classes[h];
-    if (lane < 32) {
-      float gx = 0.f, gy = 0.f, gz = 0.f;
-      if (pair_ok) {
-        const float sc = p.a.scale[h];
-        const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
-        gx = dl[0] * sc;
-        if (Cn > 1) gy = dl[1] * sc;
-        if (Cn > 2) gz = dl[2] * sc;
-      }
-      float* gp = reinterpret_cast<float*>(sG + wave * 32) + (lane >> 1) * 8 + (lane & 1);
-      gp[0] = gx; gp[2] = gy; gp[4] = gz;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const f2 one2 = f2{1.f, 1.f}, nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
-  const float4* myG = sG + wave * 32;
-  char* myT = sT + wave * 2048;
-  const bool odd = (lane & 1) != 0;
-  // dz tile in LDS: row r (pair) = 64 bytes = four 16-byte chunks, chunk q stored at q ^ ((r >> 2) & 3)
-  const uint32_t t_read = lds_addr(myT) + r32 * 64;
-  const int t_swz = (r32 >> 2) & 3;
-  T* dz_row = p.dz + row * ncol + 8 * half;                 // + slab * 32 + 16 kk
-
-  f32x16_t du[NDT];
-#pragma unroll
-  for (int t = 0; t < NDT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
-  f32x16_t zp;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zp[r] = 0.f;
-
-  // phase Z(s): z of slab s on the matrix cores;  phase E(s): z -> dz, column sums, dz -> LDS tile;
-  // phase U(s): dz tile -> A fragments -> HBM, du += dz W1 (slab s)
-  auto phase_ze = [&](auto mma_c, auto epi_c, int s) {
-    constexpr bool MMA = decltype(mma_c)::value, EPI = decltype(epi_c)::value;
-    const char* wb = sA + (s & 1) * HALF_BYTES;
-    f32x16_t z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    const int es = MMA ? s - 1 : s;                          // slab whose z sits in zp
-    float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (EPI) cw = sCol[es * 32 + r32];
-    const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
-    f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if constexpr (MMA) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          if (ks * 8 / KS == j) {
-            Frag<T> wf = load_frag_linear<T>(wb, ks, lane);
-            if constexpr (PB_ABLATE & 4) z[ks & 15] += __uint_as_float(wf.v.x);
-            else mma_step(xf[ks], wf, z);                    // rows = pairs, columns = hidden units
-          }
-      }
-      if constexpr (EPI) {
-        const int r0 = 2 * j, rowc = (r0 & 3) + 8 * (r0 >> 2);   // accumulator registers 2j, 2j+1: pair rows rowc + 4*half + {0, 1}
-        const int row0 = rowc + 4 * half;
-        const float4 g01 = myG[row0];
-        const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
-        const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
-        const f2 zz = f2{zp[r0], zp[r0 + 1]} + b1;
-        const f2 t = zz * nl2e;
-        const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
-        const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-        const f2 y = zz * sg;
-        const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
-        const f2 dzv = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
-        s0 = __builtin_elementwise_fma(g0, y, s0);
-        s1 = __builtin_elementwise_fma(g1, y, s1);
-        s2 = __builtin_elementwise_fma(g2, y, s2);
-        sb = sb + dzv;
-        // even lanes keep columns (c, c+1) of pair row row0, odd lanes columns (c-1, c) of row0 + 1
-        const float give = odd ? dzv.x : dzv.y;
-        const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
-        const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
-        const int trow = row0 + (lane & 1);
-        const int boff = (r32 & ~1) * 2;                     // byte offset of the column pair inside the 64-byte row
-        const int f = ((rowc >> 2) + half) & 3;              // (trow >> 2) & 3 (rowc & 3 is 0 or 2: no carry from 4*half + odd)
-        *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
-      }
-    }
-    if constexpr (EPI) {
-      float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
-      part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
-      part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
-      if (lane < 32) sPart[(es & 1) * (PB_WAVES * 32) + wave * 32 + lane] = part;
-    }
-    if constexpr (MMA) zp = z;
-  };
-  auto phase_u = [&](int s) {
-    // the tile was written by this wave only: order its writes before its reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    Frag<T> a0, a1;
-    a0.v = *reinterpret_cast<const uint4*>(myT + r32 * 64 + (((0 + half) ^ t_swz) << 4));
-    a1.v = *reinterpret_cast<const uint4*>(myT + r32 * 64 + (((2 + half) ^ t_swz) << 4));
-    if constexpr (!(PB_ABLATE & 1)) {
-      *reinterpret_cast<uint4*>(dz_row + s * 32) = a0.v;
-      *reinterpret_cast<uint4*>(dz_row + s * 32 + 16) = a1.v;
-    }
-    if constexpr (!(PB_ABLATE & 2)) {
-      const char* ub = sB + (s & 1) * HALF_BYTES;
-#pragma unroll
-      for (int t = 0; t < NDT; ++t) {
-        Frag<T> w0 = load_frag_linear<T>(ub, 2 * t, lane), w1 = load_frag_linear<T>(ub, 2 * t + 1, lane);
-        mma_step(a0, w0, du[t]);
-        mma_step(a1, w1, du[t]);
-      }
-    } else {
-      du[0][0] += __uint_as_float(a0.v.x) + __uint_as_float(a1.v.y);
-    }
-    // the next E phase overwrites the tile: its reads above must have completed (they have: the MFMAs consumed them)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  using yes = std::integral_constant<bool, true>;
-  using no = std::integral_constant<bool, false>;
-  (void)t_read;
-
-  if constexpr (!PIPE) {
-    dma_z(0);
-    for (int s = 0; s < nslab; ++s) {
-      // z fragments of slab s (issued one iteration ago) have landed; every wave is done with the slots the next DMAs overwrite
-      wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nslab) dma_z(s + 1);
-      dma_u(s);
-      if (s > 0) flush(s - 1);
-      if (s % spb == 0) stage_g(s / spb);
-      phase_ze(yes{}, no{}, s);
-      phase_ze(no{}, yes{}, s);
-      // du fragments of slab s: issued just above, needed now -> wait for them (all waves' pieces)
-      wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-      phase_u(s);
-    }
-  } else {
-    // Three slabs in flight per iteration s (one wave per SIMD: the overlap has to be built into the instruction stream):
-    //   Z(s+1)  first-layer MFMAs of slab s+1                       (fragments: sA[(s+1) & 1])
-    //   E(s)    z of slab s -> dz (VALU), column sums, dz -> LDS tile
-    //   U(s-1)  du += dz(s-1) W1(s-1)                               (fragments: sB[(s-1) & 1]; A operand read from the tile
-    //                                                                 at the top of the iteration, before E(s) rewrites it)
-    // in 8 chunks: [MFMAs of chunk j] [issue the fragment reads of chunk j+1] [dz arithmetic of rows 2j, 2j+1] [wait].
-    // DMA: z fragments of slab s+2 and du fragments of slab s are issued at the top of iteration s; both have a whole
-    // iteration to land.
-    const uint32_t fbase = lds_addr(sA) + lane * 16;                 // sB = sA + 2 * HALF_BYTES
-    auto iteration = [&](auto z_c, auto e_c, auto u_c, int s) {
-      constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value, DOU = decltype(u_c)::value;
-      const uint32_t za = fbase + ((s + 1) & 1) * HALF_BYTES;
-      const uint32_t ua = fbase + (2 + ((s - 1) & 1)) * HALF_BYTES;
-      pb_u32x4 a0 = pb_u32x4{0u, 0u, 0u, 0u}, a1 = a0;
-      if constexpr (DOU) {
-        const uint32_t ta = lds_addr(myT) + r32 * 64;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(ta + (((0 + half) ^ t_swz) << 4)));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(ta + (((2 + half) ^ t_swz) << 4)));
-      }
-      // ONE register set for the fragments: the reads of chunk j+1 are issued behind the MFMAs of chunk j, which have read
-      // their operands long before the LDS data returns
-      pb_u32x4 fz[PB_MAXC], fu[PB_MAXC];
-#pragma unroll
-      for (int i = 0; i < PB_MAXC; ++i) { fz[i] = pb_u32x4{0u, 0u, 0u, 0u}; fu[i] = fz[i]; }
-      auto issue = [&](auto jc, pb_u32x4 (&dz_)[PB_MAXC], pb_u32x4 (&du_)[PB_MAXC]) {
-        constexpr int J = decltype(jc)::value;
-        constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
-        static_assert(C <= PB_MAXC, "chunk too large");
-        if constexpr (DOZ) {
-          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(dz_[0], za);
-          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(dz_[1], za);
-          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(dz_[2], za);
-        }
-        if constexpr (DOU) {
-          if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(du_[0], ua);
-          if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(du_[1], ua);
-          if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(du_[2], ua);
-        }
-      };
-      auto landed = [&](pb_u32x4 (&dz_)[PB_MAXC], pb_u32x4 (&du_)[PB_MAXC]) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(dz_[0]), "+v"(dz_[1]), "+v"(dz_[2]), "+v"(du_[0]), "+v"(du_[1]), "+v"(du_[2]), "+v"(a0), "+v"(a1) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      issue(std::integral_constant<int, 0>{}, fz, fu);
-      landed(fz, fu);
-      if constexpr (DOU && !(PB_ABLATE & 1)) {
-        *reinterpret_cast<pb_u32x4*>(dz_row + (s - 1) * 32) = a0;
-        *reinterpret_cast<pb_u32x4*>(dz_row + (s - 1) * 32 + 16) = a1;
-      }
-      f32x16_t z;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) z[r] = 0.f;
-      asm volatile("" : "+a"(z));      // opaque zero (see the wave-specialised kernel): no destination / operand overlap
-      float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (DOE) cw = sCol[s * 32 + r32];
-      const f2 w0 = f2{cw.x, cw.x}, w1 = f2{cw.y, cw.y}, w2 = f2{cw.z, cw.z}, b1 = f2{cw.w, cw.w};
-      f2 s0 = f2{0.f, 0.f}, s1 = s0, s2 = s0, sb = s0;
-      auto chunk = [&](auto jc, pb_u32x4 (&cz)[PB_MAXC], pb_u32x4 (&cu)[PB_MAXC], pb_u32x4 (&xz)[PB_MAXC], pb_u32x4 (&xu)[PB_MAXC]) {
-        constexpr int J = decltype(jc)::value;
-        constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
-        uint32_t packed_out = 0;
-        // (a) the MFMAs of this chunk: their fragments landed at the end of the previous chunk
-        if constexpr (DOZ && !(PB_ABLATE & 4)) {
-          if constexpr (C > 0) pb_mma(xf[F0 + 0], cz[0], z);
-          if constexpr (C > 1) pb_mma(xf[F0 + 1], cz[1], z);
-          if constexpr (C > 2) pb_mma(xf[F0 + 2], cz[2], z);
-        }
-        if constexpr (DOU && !(PB_ABLATE & 2)) {
-          // fragment f = 2 t + kk: tile t of the decoder dim, k half kk <-> a0 / a1
-          if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, cu[0], du[(F0 + 0) >> 1]);
-          if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, cu[1], du[(F0 + 1) >> 1]);
-          if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, cu[2], du[(F0 + 2) >> 1]);
-        }
-        // (b) fragment reads of the next chunk
-        if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{}, xz, xu);
-        // (c) dz arithmetic of accumulator registers 2J, 2J+1 in the shadow of the MFMAs
-        if constexpr (DOE) {
-          constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
-          const int row0 = rowc + 4 * half;
-          const float4 g01 = myG[row0];
-          const float2 g2v = *reinterpret_cast<const float2*>(myG + row0 + 1);
-          const f2 g0 = f2{g01.x, g01.y}, g1 = f2{g01.z, g01.w}, g2 = f2{g2v.x, g2v.y};
-          const f2 zz = f2{zp[r0], zp[r0 + 1]} + b1;
-          const f2 t = zz * nl2e;
-          const f2 den = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + one2;
-          const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-          const f2 y = zz * sg;
-          const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
-          const f2 dzv = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
-          s0 = __builtin_elementwise_fma(g0, y, s0);
-          s1 = __builtin_elementwise_fma(g1, y, s1);
-          s2 = __builtin_elementwise_fma(g2, y, s2);
-          sb = sb + dzv;
-          const float give = odd ? dzv.x : dzv.y;
-          const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
-          const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
-          packed_out = packed;
-        }
-        // (d) everything this chunk put on the LDS queue so far is done (the next chunk's fragments among it); the tile
-        // store goes out BEHIND the wait: its round trip is covered by the next chunk instead of being waited for here
-        if constexpr (J + 1 < 8) landed(xz, xu);
-        if constexpr (DOE) {
-          constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
-          const int trow = rowc + 4 * half + (lane & 1);
-          const int boff = (r32 & ~1) * 2;
-          const int f = ((rowc >> 2) + half) & 3;
-          *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed_out;
-        }
-      };
-      chunk(std::integral_constant<int, 0>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 1>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 2>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 3>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 4>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 5>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 6>{}, fz, fu, fz, fu);
-      chunk(std::integral_constant<int, 7>{}, fz, fu, fz, fu);
-      if constexpr (DOE) {
-        float4 part = make_float4(s0.x + s0.y, s1.x + s1.y, s2.x + s2.y, sb.x + sb.y);
-        part.x += __shfl_xor(part.x, 32); part.y += __shfl_xor(part.y, 32);
-        part.z += __shfl_xor(part.z, 32); part.w += __shfl_xor(part.w, 32);
-        if (lane < 32) sPart[(s & 1) * (PB_WAVES * 32) + wave * 32 + lane] = part;
-      }
-      if constexpr (DOZ) zp = z;
-    };
-    auto top = [&](int s) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // column sums are flushed by another wave
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // (spreading these pieces over the chunks of the iteration was slower and gave wrong last slabs: DESIGN.md §12)
-      if (s >= 0 && s + 2 < nslab) dma_z(s + 2);
-      if (s >= 0 && s < nslab) dma_u(s);
-      if (s >= 1) flush(s - 1);                               // column sums of E(s-1), written before this barrier
-      if (s >= 0 && s < nslab && s % spb == 0) stage_g(s / spb);
-    };
-    // prologue / steady state / epilogue as separate code (nslab >= 2 is checked by the launcher): inside one loop the five
-    // flavours of the iteration made the register allocator spill
-    dma_z(0);
-    dma_z(1);
-    top(-1); iteration(yes{}, no{}, no{}, -1);
-    top(0); iteration(yes{}, yes{}, no{}, 0);
-    // the du accumulators stay in the accumulator half of the register file across the loop (without the pin the
-    // allocator parked them in arch VGPRs at the back edge: 192 v_accvgpr moves per iteration)
-    auto pin_du = [&]() {
-#pragma unroll
-      for (int t = 0; t < NDT; ++t) asm volatile("" : "+a"(du[t]));
-    };
-    pin_du();
-    for (int s = 1; s + 1 < nslab; ++s) { top(s); iteration(yes{}, yes{}, yes{}, s); pin_du(); }
-    top(nslab - 1);
-    if (nslab > 1) iteration(no{}, yes{}, yes{}, nslab - 1);
-    top(nslab); iteration(no{}, no{}, yes{}, nslab);
-  }
-  __syncthreads();
-  if constexpr (!PIPE) flush(nslab - 1);
-
-  // ---- du * SiLU'(a_i + b_j), summed over j into d_a[i] and over i into d_b[j] ----
-  // accumulator register r of lane (c, half) of tile t: pair row rho = (r&3) + 8 (r>>2) + 4 half, decoder column 32 t + c;
-  // i = i0 + (r >> 3), j = j0 + 8 ((r >> 2) & 1) + 4 half + (r & 3).  The sums over j stay inside the wave (its two rows i);
-  // the sums over i meet in LDS (the weight rings are dead by now: 4 waves x [D/32][16][32] fp32 fill them exactly).  Both
-  // leave as plain per-block partial rows; pair_bwd_reduce_kernel adds the blocks of a row / column (no atomics: 108
-  // same-address-prone atomic instructions per lane cost a quarter of the kernel).
-  if constexpr (!(PB_ABLATE & 8)) {
-    float* red = reinterpret_cast<float*>(smem);                      // [PB_WAVES][NDT][16][32]
-    const int ia = min(i0, N - 1), ib = min(i0 + 1, N - 1);
-    float* pa = p.part_a + (((int64_t)b * p.ntiles + blockIdx.x) * PB_TI + 2 * wave + half) * D;
-#pragma unroll
-    for (int t = 0; t < NDT; ++t) {
-      const int d = 32 * t + r32;
-      const float a_lo = bf16_to_f32(abd[(int64_t)ia * 2 * D + d]), a_hi = bf16_to_f32(abd[(int64_t)ib * 2 * D + d]);
-      float bj[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = min(j0 + 8 * (q >> 2) + 4 * half + (q & 3), N - 1);
-        bj[q] = bf16_to_f32(abd[(int64_t)j * 2 * D + D + d]);
-      }
-      float sa0 = 0.f, sa1 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float v0 = du[t][q] * silu_grad_f(a_lo + bj[q]);          // i = i0     , registers 0..7
-        const float v1 = du[t][8 + q] * silu_grad_f(a_hi + bj[q]);      // i = i0 + 1 , registers 8..15
-        sa0 += v0; sa1 += v1;
-        red[((wave * NDT + t) * 16 + 8 * (q >> 2) + 4 * half + (q & 3)) * 32 + r32] = v0 + v1;
-      }
-      sa0 += __shfl_xor(sa0, 32);
-      sa1 += __shfl_xor(sa1, 32);
-      pa[d] = half ? sa1 : sa0;
-    }
-    __syncthreads();
-    float* pb = p.part_b + ((int64_t)b * p.ntiles + blockIdx.x) * PB_TJ * D;
-    for (int e = tid; e < NDT * 16 * 32; e += PB_WAVES * 64) {
-      const int c = e & 31, jl = (e >> 5) & 15, t = e >> 9;
-      float v = red[e];
-#pragma unroll
-      for (int w = 1; w < PB_WAVES; ++w) v += red[w * NDT * 512 + e];
-      pb[(int64_t)jl * D + 32 * t + c] = v;
-    }
-  }
-}
 
 // d_ab[b, i, :D] = sum over the blocks of row-tile i / 8 of part_a ; d_ab[b, j, D:] = sum over the blocks of column-tile j / 16 of part_b
 __global__ __launch_bounds__(256) void pair_bwd_reduce_kernel(const float* part_a, const float* part_b, int N, int D, int ntiles,
@@ -601,7 +157,7 @@ __global__ __launch_bounds__(256) void pair_bwd_reduce_kernel(const float* part_
 // ================================================================================================
 constexpr int PW_WAVES = 8;
 
-template <int KS>
+template <int KS, bool DROP>
 __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdParams p) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -619,6 +175,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   float4* sG = sCol + ncol;                                                 // [4][32]
   float4* sPart = sG + 4 * 32;                                              // [2][4][32]
   char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
+  uint32_t* sMask = reinterpret_cast<uint32_t*>(sT + 2 * 4 * 2048);         // [2][4][32]: keep bits of a slab, word = hidden unit, bit = pair of the group
 
   int ti = 0;
   {
@@ -639,7 +196,8 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
 
   for (int n = tid; n < ncol; n += PW_WAVES * 64) {
     const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
-    sCol[n] = make_float4(p.a.w2[h][k], Cn > 1 ? p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? p.a.w2[h][(int64_t)2 * D + k] : 0.f,
+    const float ds = DROP ? p.drop_scale : 1.f;     // dy = g W2 / (1 - p): the scale of the kept units rides on the W2 rows
+    sCol[n] = make_float4(ds * p.a.w2[h][k], Cn > 1 ? ds * p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? ds * p.a.w2[h][(int64_t)2 * D + k] : 0.f,
                           p.b1[n]);
   }
 
@@ -670,7 +228,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   // Scalar pairs, and this file is built with -fno-slp-vectorize: NO packed-fp32 VALU (v_pk_mul / v_pk_fma / v_pk_add_f32) in
   // this kernel.  With the partner wave's MFMAs running on the same SIMD the packed forms returned wrong low halves in lanes
   // 48-63 (sporadic wrong 16-byte pieces of dz, gone with the partner's MFMAs removed, gone with scalar arithmetic; the
-  // one-wave-per-SIMD kernel above, where nothing shares the SIMD, is unaffected).
+  // one-wave-per-SIMD form of this kernel (removed in round 3), where nothing shared the SIMD, was unaffected).
   struct f2 {
     float x, y;
     __device__ f2 operator+(const f2& o) const { return f2{x + o.x, y + o.y}; }
@@ -814,6 +372,10 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       }
       float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (DOE) cw = sCol[s * 32 + r32];
+      // K12 dropout: this lane's hidden unit, one keep bit per pair of the group (written by the consumer waves one iteration
+      // ago); shifted so that register r0's pair (rowc + 4 half) sits at the compile-time position rowc
+      uint32_t mws = 0xffffffffu;
+      if constexpr (DOE && DROP) mws = sMask[((s & 1) * 4 + grp) * 32 + r32] >> (4 * half);
       const f2 b1 = f2{cw.w, cw.w};
       // dy[pair, hid] = sum_c g[pair, c] W2[c, hid] on the matrix cores: B operand = this lane's column of W2 (k = class:
       // lanes 0-31 hold (w0, w1, w2, 0 ...), lanes 32-63 the zero half), same accumulator layout as z
@@ -853,9 +415,15 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
           const f2 den = f2{__builtin_amdgcn_exp2f(t.x) + 1.f, __builtin_amdgcn_exp2f(t.y) + 1.f};
           const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
           const f2 y = zz * sg;
-          yv[r0] = y.x; yv[r0 + 1] = y.y;
           // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
-          const f2 dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
+          f2 dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
+          if constexpr (DROP) {
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)mws, rowc, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)mws, rowc + 1, 1);
+            yv[r0] = __uint_as_float(__float_as_uint(y.x) & m0); yv[r0 + 1] = __uint_as_float(__float_as_uint(y.y) & m1);
+            dzv = f2{__uint_as_float(__float_as_uint(dzv.x) & m0), __uint_as_float(__float_as_uint(dzv.y) & m1)};
+          } else {
+            yv[r0] = y.x; yv[r0 + 1] = y.y;
+          }
           sbx += dzv.x; sby += dzv.y;
           const float give = odd ? dzv.x : dzv.y;
           const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
@@ -897,7 +465,8 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         pb_mma(gT1, y1, acc);
         float sbt = sbx + sby;
         sbt += __shfl_xor(sbt, 32);
-        if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = make_float4(acc[0], acc[1], acc[2], sbt);
+        const float ys = DROP ? p.drop_scale : 1.f;     // dW2 = sum g (y m) / (1 - p)
+        if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = make_float4(acc[0] * ys, acc[1] * ys, acc[2] * ys, sbt);
       }
     };
     using yes = std::integral_constant<bool, true>;
@@ -938,8 +507,32 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
     T* dz_row = p.dz + row * ncol + 8 * half;
     __syncthreads();                                          // matches the producers' barrier
+    const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
+    const uint32_t drop_base = (uint32_t)(mypair * (ncol / 4)) + 4u * (uint32_t)half;
     for (int s = -1; s <= nslab; ++s) {
       top();
+      if constexpr (DROP) {
+        // keep bits of slab s + 1 for the producers' E(s + 1): lane = (pair r32 of the group, hidden units 16 half .. + 15) =
+        // four word pairs of the forward's hash; a compare yields the 64-lane ballot = [pairs of unit k | pairs of unit 16 + k],
+        // i.e. the producers' words (bit = pair) for free; lane L keeps word L and stores it
+        if (s + 1 < nslab) {
+          uint32_t mine = 0u;
+          auto quad = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            uint32_t w0, w1;
+            pair_drop_words(drop_key, drop_base + (uint32_t)((s + 1) * 8 + q), w0, w1);
+            const unsigned long long k0 = __ballot((w0 & 0xffffu) >= p.drop_thr16), k1 = __ballot((w0 >> 16) >= p.drop_thr16);
+            const unsigned long long k2 = __ballot((w1 & 0xffffu) >= p.drop_thr16), k3 = __ballot((w1 >> 16) >= p.drop_thr16);
+            pb_writelane<4 * q + 0>(mine, (uint32_t)k0); pb_writelane<16 + 4 * q + 0>(mine, (uint32_t)(k0 >> 32));
+            pb_writelane<4 * q + 1>(mine, (uint32_t)k1); pb_writelane<16 + 4 * q + 1>(mine, (uint32_t)(k1 >> 32));
+            pb_writelane<4 * q + 2>(mine, (uint32_t)k2); pb_writelane<16 + 4 * q + 2>(mine, (uint32_t)(k2 >> 32));
+            pb_writelane<4 * q + 3>(mine, (uint32_t)k3); pb_writelane<16 + 4 * q + 3>(mine, (uint32_t)(k3 >> 32));
+          };
+          quad(std::integral_constant<int, 0>{}); quad(std::integral_constant<int, 1>{});
+          quad(std::integral_constant<int, 2>{}); quad(std::integral_constant<int, 3>{});
+          if (lane < 32) sMask[(((s + 1) & 1) * 4 + grp) * 32 + lane] = mine;
+        }
+      }
       if (s < 1) dma_iter(s);
       if (s >= 1) {
         const int u = s - 1;
@@ -1006,7 +599,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
     }
     report();
     __syncthreads();     // every wave is done with the rings
-    // ---- du * SiLU'(a_i + b_j): sums over j stay in the wave, sums over i meet in LDS (see the single-wave kernel) ----
+    // ---- du * SiLU'(a_i + b_j): sums over j stay in the wave, sums over i meet in LDS (the rings are dead) ----
     float* red = reinterpret_cast<float*>(smem);                      // [4][NDT][16][32]
     const int ia = min(i0, N - 1), ib = min(i0 + 1, N - 1);
     float* pa = p.part_a + (((int64_t)b * p.ntiles + blockIdx.x) * PB_TI + 2 * grp + half) * D;
@@ -1044,40 +637,23 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   }
 }
 
-template <int KS>
+template <int KS, bool DROP>
 static int launch_pair_bwd_ws(const PairBwdParams& p, hipStream_t st) {
   const int ncol = p.a.num_heads * p.D;
-  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 16 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048;
+  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 16 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)2 * 4 * 32 * 4;
   if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (sh > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_ws_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_ws_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
     set_error("peneo_pair_bwd_fused: cannot raise dynamic LDS to %zu bytes", sh);
     return PENEO_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((pair_bwd_ws_kernel<KS>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PW_WAVES * 64), sh, st, p);
+  hipLaunchKernelGGL((pair_bwd_ws_kernel<KS, DROP>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PW_WAVES * 64), sh, st, p);
   return check_launch("peneo_pair_bwd_fused");
 }
 
-template <int KS, bool PIPE>
-static int launch_pair_bwd_v(const PairBwdParams& p, hipStream_t st) {
-  const int ncol = p.a.num_heads * p.D;
-  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 16 + (size_t)PB_WAVES * 32 * 16 * 3 + (size_t)PB_WAVES * 2048;
-  if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
-  if (sh > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_fused_kernel<KS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
-    set_error("peneo_pair_bwd_fused: cannot raise dynamic LDS to %zu bytes", sh);
-    return PENEO_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL((pair_bwd_fused_kernel<KS, PIPE>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PB_WAVES * 64), sh, st, p);
-  return check_launch("peneo_pair_bwd_fused");
-}
 template <int KS>
 static int launch_pair_bwd(const PairBwdParams& p, hipStream_t st) {
-  // PENEO_PB_MODE: "ws" (default) = wave-specialised kernel, "1w" = one wave per SIMD (PENEO_PB_PIPE = 0 / 1: its two schedules)
-  static const bool ws = [] { const char* e = getenv("PENEO_PB_MODE"); return !(e && e[0] == '1'); }();
-  if (ws) return launch_pair_bwd_ws<KS>(p, st);
-  static const bool pipe = [] { const char* e = getenv("PENEO_PB_PIPE"); return e ? atoi(e) != 0 : true; }();
-  return pipe ? launch_pair_bwd_v<KS, true>(p, st) : launch_pair_bwd_v<KS, false>(p, st);
+  return p.drop_thr16 ? launch_pair_bwd_ws<KS, true>(p, st) : launch_pair_bwd_ws<KS, false>(p, st);
 }
 
 }  // namespace peneo
@@ -1126,6 +702,8 @@ extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int
   p.wp = w_packed; p.b1 = b1; p.a = *args;
   p.dz = reinterpret_cast<bf16_t*>(dz); p.x = reinterpret_cast<bf16_t*>(x); p.ws = workspace;
   p.ntiles = pb_num_tiles(N);
+  PENEO_REQUIRE(args->drop_p >= 0.f && args->drop_p < 1.f, "peneo_pair_bwd_fused: drop_p must be in [0, 1)");
+  p.drop_thr16 = pair_drop_thr16_host(args->drop_p); p.drop_seed = args->drop_seed; p.drop_scale = pair_drop_scale_host(args->drop_p);
   p.dbg = g_pb_dbg;
   p.part_a = partials; p.part_b = partials + (size_t)B * p.ntiles * PB_TI * D;
   hipStream_t st = (hipStream_t)stream;

@@ -90,6 +90,7 @@ struct PairFwdParams {
   const float* cw[PENEO_MAX_HEADS];
   float* partials;   // [B * gridDim.x][32]: num[8] | den[8] | dl_sum[16] per workgroup
   float* dlogits[PENEO_MAX_HEADS];
+  uint32_t drop_thr16, drop_seed; float drop_scale;   // K12 dropout (common.h: pair_drop_*): threshold 0 = off, scale = 1 / (1 - p)
 };
 
 constexpr float NEG_INF_F = -3.0e38f;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void pair_epilogue(const PairFwdParams& p, const f32x
         const int C = p.classes[h];
         float l[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) l[c] = (c < C) ? cls_at(cls, off + c) + p.b2[off + c] : NEG_INF_F;
+        for (int c = 0; c < 4; ++c) l[c] = (c < C) ? cls_at(cls, off + c) * p.drop_scale + p.b2[off + c] : NEG_INF_F;
         if (writer && p.logits[h]) {
           float* dst = p.logits[h] + ((int64_t)b * p.P + mypair) * C;
           for (int c = 0; c < C; ++c) dst[c] = l[c];
@@ -213,151 +214,13 @@ __device__ __forceinline__ void pair_epilogue(const PairFwdParams& p, const f32x
 }
 
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-// hand-issued LDS reads: hipcc neither counts them nor (crucially) drains the in-flight LDS-DMA ring in front of them;
-// the reader owns lgkmcnt (s_waitcnt + sched_barrier before the first consumer, guide §5.7 / rule 18)
-#define DS_READ_B128(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
-#define LGKM_WAIT(n_)                                         \
-  asm volatile("s_waitcnt lgkmcnt(" #n_ ")" ::: "memory");    \
-  __builtin_amdgcn_sched_barrier(0);
-
-__device__ __forceinline__ void mma_bf16(const u32x4_t& a, const Frag<bf16_t>& b, f32x16_t& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
-}
-
-template <int OFF> __device__ __forceinline__ void dsr128(u32x4_t& d, uint32_t a) { DS_READ_B128(d, a, OFF); }
-template <int G> __device__ __forceinline__ void rd4(u32x4_t (&f)[4], uint32_t wa) {
-  dsr128<(G * 4 + 0) * 1024>(f[0], wa); dsr128<(G * 4 + 1) * 1024>(f[1], wa);
-  dsr128<(G * 4 + 2) * 1024>(f[2], wa); dsr128<(G * 4 + 3) * 1024>(f[3], wa);
-}
-// software pipeline over the first-layer fragments of one slab: while group G feeds the matrix pipe, group G+1
-// (or the tail: second-layer fragments + bias) is already on its way out of LDS into the other register set
-template <int G, int NG4, int KS>
-__device__ __forceinline__ void slab_steps(u32x4_t (&cur)[4], u32x4_t (&nxt)[4], u32x4_t& w2a, u32x4_t& w2b, u32x4_t (&bq)[4],
-                                           uint32_t wa, uint32_t ba, const Frag<bf16_t> (&xf)[KS], f32x16_t& z) {
-  if constexpr (G + 1 < NG4) {
-    rd4<G + 1>(nxt, wa);
-    LGKM_WAIT(4)
-  } else {
-    dsr128<KS * 1024>(w2a, wa); dsr128<(KS + 1) * 1024>(w2b, wa);
-    dsr128<0>(bq[0], ba); dsr128<32>(bq[1], ba); dsr128<64>(bq[2], ba); dsr128<96>(bq[3], ba);
-    LGKM_WAIT(6)
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) mma_bf16(cur[i], xf[G * 4 + i], z);
-  if constexpr (G + 1 < NG4) slab_steps<G + 1, NG4, KS>(nxt, cur, w2a, w2b, bq, wa, ba, xf, z);
-}
-
-// bf16 throughput variant (KS a multiple of 4): 3-deep LDS-DMA ring with counted vmcnt, and the A-fragment LDS reads
-// software-pipelined by hand in groups of 4 (two register sets), so the matrix pipe never waits on a just-issued ds_read.
-template <int KS>
-__global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_pipe_kernel(PairFwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef bf16_t T;
-  constexpr int NSTAGE = 3;
-  constexpr int NF = KS + 2;
-  constexpr int UPW = (NF + PH_WAVES - 1) / PH_WAVES;       // 1 KiB DMA units per wave per slab
-  constexpr int SLAB_BYTES = UPW * PH_WAVES * 1024;          // padded slab (== packed slab stride)
-  constexpr int NG4 = KS / 4;
-  char* sW = smem;
-  float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = p.D, N = p.N;
-  const int b = blockIdx.y;
-  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
-  const int64_t mypair = p0 + wave * 32 + (lane & 31);
-  const bool pair_ok = mypair < p.P;
-  int pi, pj;
-  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
-  const int nslab = p.num_heads * D / 32;
-
-  for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
-
-  const T* abd = reinterpret_cast<const T*>(p.ab) + (int64_t)b * N * 2 * D;
-  const T* arow = abd + (int64_t)pi * 2 * D;
-  const T* brow = abd + (int64_t)pj * 2 * D + D;
-  Frag<T> xf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = 16 * ks + 8 * half;
-    float a[8], bb[8];
-    unpack16<T>(*reinterpret_cast<const uint4*>(arow + c), a);
-    unpack16<T>(*reinterpret_cast<const uint4*>(brow + c), bb);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
-    xf[ks] = pack_frag8<T>(a);
-    if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep at most 8 gathers in flight (else the raw loads spill)
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                          // sB1 visible
-
-  // this wave's UPW consecutive 1 KiB units of every slab: one per-lane pointer + immediate offsets
-  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
-  char* wdst = sW + wave * (UPW * 1024);
-#define PIPE_DMA(slab_, buf_)                                                                                 \
-  {                                                                                                           \
-    const __attribute__((address_space(1))) char* g_ =                                                        \
-        (const __attribute__((address_space(1))) char*)(wsrc + (int64_t)(slab_) * SLAB_BYTES);                \
-    __attribute__((address_space(3))) char* l_ = (__attribute__((address_space(3))) char*)(wdst + (buf_) * SLAB_BYTES); \
-    __builtin_amdgcn_global_load_lds(g_, l_, 16, 0, 0);                                                       \
-    if constexpr (UPW > 1) __builtin_amdgcn_global_load_lds(g_ + 1024, l_ + 1024, 16, 0, 0);                  \
-    if constexpr (UPW > 2) __builtin_amdgcn_global_load_lds(g_ + 2048, l_ + 2048, 16, 0, 0);                  \
-    if constexpr (UPW > 3) __builtin_amdgcn_global_load_lds(g_ + 3072, l_ + 3072, 16, 0, 0);                  \
-    if constexpr (UPW > 4) __builtin_amdgcn_global_load_lds(g_ + 4096, l_ + 4096, 16, 0, 0);                  \
-  }
-  static_assert(UPW <= 5, "slab too large");
-  PIPE_DMA(0, 0)
-  if (nslab > 1) PIPE_DMA(1, 1)
-
-  f32x16_t lg;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lg[r] = 0.f;
-  const uint32_t lbase = lds_addr(sW) + lane * 16;
-  const uint32_t bbase = lds_addr(sB1) + half * 16;          // + slab*128 bytes; the 4 groups are +0,+32,+64,+96
-
-  for (int slab = 0; slab < nslab; ++slab) {
-    // slab (and slab+1, unless this is the last) are in flight: wait for the older one only
-    if (slab + 1 < nslab) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(UPW) : "memory"); }
-    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (slab + 2 < nslab) PIPE_DMA(slab + 2, (slab + 2) % NSTAGE)
-    const uint32_t wa = lbase + (slab % NSTAGE) * SLAB_BYTES;
-    const uint32_t ba = bbase + slab * 128;
-
-    u32x4_t fa[4], fb[4], w2a, w2b, bq[4];
-    f32x16_t z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    rd4<0>(fa, wa);
-    slab_steps<0, NG4, KS>(fa, fb, w2a, w2b, bq, wa, ba, xf, z);
-    LGKM_WAIT(0)
-    float y[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      y[4 * g + 0] = silu_f(z[4 * g + 0] + __uint_as_float(bq[g][0]));
-      y[4 * g + 1] = silu_f(z[4 * g + 1] + __uint_as_float(bq[g][1]));
-      y[4 * g + 2] = silu_f(z[4 * g + 2] + __uint_as_float(bq[g][2]));
-      y[4 * g + 3] = silu_f(z[4 * g + 3] + __uint_as_float(bq[g][3]));
-    }
-    Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
-    mma_bf16(w2a, y0, lg);
-    mma_bf16(w2b, y1, lg);
-  }
-#undef PIPE_DMA
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
-}
-
-
 // Generic kernel (bf16 and fp32).  Per workgroup: 8 waves x 32 pairs.  Weight slabs (32 hidden rows: KS first-layer
 // fragments + 2 second-layer fragments, padded to UPW KiB per wave) stream L2 -> LDS through a ring of NSTAGE buffers,
 // NSTAGE-1 slabs ahead; one s_barrier per slab publishes them.  VARIANT bits (A/B-tested on the GPU):
 //   1: LDS-DMA issued from inline asm with counted vmcnt (else the builtin, which hipcc drains before every ds_read)
 //   2: bias + SiLU + second layer of slab s-1 software-pipelined into the first-layer MFMA stream of slab s
 //   4: two independent first-layer accumulator chains (even / odd k-steps)
-template <typename T, int KS, int NSTAGE, int VARIANT>
+template <typename T, int KS, int NSTAGE, int VARIANT, bool DROP>
 __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool ASM_DMA = (VARIANT & 1) != 0, PIPE_EPI = (VARIANT & 2) != 0, DUAL = (VARIANT & 4) != 0;
@@ -473,6 +336,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
     float zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     w2p0 = pack_frag8<T>(zero); w2p1 = w2p0;
   }
+  const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
+  const uint32_t drop_base = (uint32_t)(mypair * (p.num_heads * D / 4)) + (uint32_t)half;
   auto second_layer = [&](const f32x16_t& zz, int bias_slab, const Frag<T>& wa_, const Frag<T>& wb_) {
     float y[16];
 #pragma unroll
@@ -485,6 +350,19 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
         y[4 * g + 1] = silu_f(zz[4 * g + 1] + bv.y);
         y[4 * g + 2] = silu_f(zz[4 * g + 2] + bv.z);
         y[4 * g + 3] = silu_f(zz[4 * g + 3] + bv.w);
+      }
+    }
+    if constexpr (DROP) {
+      // K12 dropout (peneo_decoder.py:261): rows 8g + 4 half + 0..3 of the slab = one aligned group of four hidden units of
+      // this lane's pair = the four 16-bit fields of one word pair; the 1 / (1 - p) factor is applied to the logits
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint32_t w0, w1;
+        pair_drop_words(drop_key, drop_base + (uint32_t)(bias_slab * 8 + 2 * g), w0, w1);
+        y[4 * g + 0] = (w0 & 0xffffu) >= p.drop_thr16 ? y[4 * g + 0] : 0.f;
+        y[4 * g + 1] = (w0 >> 16) >= p.drop_thr16 ? y[4 * g + 1] : 0.f;
+        y[4 * g + 2] = (w1 & 0xffffu) >= p.drop_thr16 ? y[4 * g + 2] : 0.f;
+        y[4 * g + 3] = (w1 >> 16) >= p.drop_thr16 ? y[4 * g + 3] : 0.f;
       }
     }
     Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
@@ -728,6 +606,10 @@ __global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzPa
     for (int e = 0; e < VEC; ++e) db1[e] = 0.f;
     const float sc = a.scale[h];
     const float* dl = a.dlogits[h];
+    // K12 dropout of the forward (common.h): regenerated per element; this kernel is the chunked / fp32 path, speed is secondary
+    const uint32_t thr16 = pair_drop_thr16_dev(a.drop_p);
+    const uint32_t dkey = pair_drop_key(a.drop_seed, a.drop_doc);
+    const float dscale = thr16 ? 65536.f / (65536.f - (float)thr16) : 1.f;
     // four rows in flight per step (every load issued before the first use): the loop is latency-bound otherwise
     for (int64_t r0 = blockIdx.x; r0 < npairs; r0 += 4 * (int64_t)gridDim.x) {
       uint4 raw[4]; float g[4][3];
@@ -748,9 +630,10 @@ __global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzPa
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float sg = sigmoid_f(zv[e]);
-            const float y = zv[e] * sg;
+            const float keep = (!thr16 || pair_drop_keep(dkey, a.drop_pair0 + r, col + e, ncol / 4, thr16)) ? dscale : 0.f;
+            const float y = zv[e] * sg * keep;
             const float dy = fmaf(g[u][2], w2[2][e], fmaf(g[u][1], w2[1][e], g[u][0] * w2[0][e]));
-            const float dz = dy * (sg * fmaf(zv[e], 1.f - sg, 1.f));
+            const float dz = dy * keep * (sg * fmaf(zv[e], 1.f - sg, 1.f));
             dw2[0][e] = fmaf(g[u][0], y, dw2[0][e]); dw2[1][e] = fmaf(g[u][1], y, dw2[1][e]); dw2[2][e] = fmaf(g[u][2], y, dw2[2][e]);
             db1[e] += dz;
             o[e] = dz;
@@ -878,22 +761,7 @@ __global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits
   if (threadIdx.x == 0) *count = base;
 }
 
-template <int KS>
-static int launch_pair_fwd_pipe(const PairFwdParams& p, hipStream_t st) {
-  size_t sh = 3 * (size_t)slab_stride_bytes(KS * 16, 2) + (size_t)p.num_heads * p.D * sizeof(float);
-  if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
-  if (sh > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_pipe_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
-      set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
-      return PENEO_ERR_LAUNCH;
-    }
-  }
-  dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
-  hipLaunchKernelGGL((pair_heads_fwd_pipe_kernel<KS>), grid, dim3(PH_WAVES * 64), sh, st, p);
-  return check_launch("peneo_pair_heads_fwd");
-}
-
-template <typename T, int KS, int VARIANT>
+template <typename T, int KS, int VARIANT, bool DROP>
 static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
   constexpr int NSTAGE = (VARIANT & 128) ? 4 : (sizeof(T) == 2 ? 3 : 2);
   const size_t slab = (size_t)slab_stride_bytes(KS * 16, (int)sizeof(T));
@@ -901,13 +769,13 @@ static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
   if (sh < (size_t)PH_WAVES * 32 * sizeof(float)) sh = (size_t)PH_WAVES * 32 * sizeof(float);
   if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (sh > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS, NSTAGE, VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_kernel<T, KS, NSTAGE, VARIANT, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
       set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
       return PENEO_ERR_LAUNCH;
     }
   }
   dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
-  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS, NSTAGE, VARIANT>), grid, dim3(PH_WAVES * 64), sh, st, p);
+  hipLaunchKernelGGL((pair_heads_fwd_kernel<T, KS, NSTAGE, VARIANT, DROP>), grid, dim3(PH_WAVES * 64), sh, st, p);
   return check_launch("peneo_pair_heads_fwd");
 }
 
@@ -916,36 +784,8 @@ static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
 constexpr int PH_DEFAULT_VARIANT = 1;
 template <typename T, int KS>
 static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
-  const char* ev = getenv("PENEO_PAIR_VARIANT");
-  if constexpr (sizeof(T) == 2 && KS == 24) {   // the headline shape carries the A/B variants
-    if (getenv("PENEO_PAIR_PIPE")) return launch_pair_fwd_pipe<KS>(p, st);
-    switch (ev ? atoi(ev) : PH_DEFAULT_VARIANT) {
-      case 0: return launch_pair_fwd_v<T, KS, 0>(p, st);
-      case 1: return launch_pair_fwd_v<T, KS, 1>(p, st);
-      case 2: return launch_pair_fwd_v<T, KS, 2>(p, st);
-      case 3: return launch_pair_fwd_v<T, KS, 3>(p, st);
-      case 4: return launch_pair_fwd_v<T, KS, 4>(p, st);
-      case 5: return launch_pair_fwd_v<T, KS, 5>(p, st);
-      case 6: return launch_pair_fwd_v<T, KS, 6>(p, st);
-      case 7: return launch_pair_fwd_v<T, KS, 7>(p, st);
-      case 8: return launch_pair_fwd_v<T, KS, 8>(p, st);
-      case 12: return launch_pair_fwd_v<T, KS, 12>(p, st);
-      case 14: return launch_pair_fwd_v<T, KS, 14>(p, st);
-      case 129: return launch_pair_fwd_v<T, KS, 129>(p, st);   // asm DMA + one barrier per two slabs
-      case 16: return launch_pair_fwd_v<T, KS, 16>(p, st);
-      case 17: return launch_pair_fwd_v<T, KS, 17>(p, st);
-      case 18: return launch_pair_fwd_v<T, KS, 18>(p, st);
-      case 19: return launch_pair_fwd_v<T, KS, 19>(p, st);
-      case 22: return launch_pair_fwd_v<T, KS, 22>(p, st);
-      case 23: return launch_pair_fwd_v<T, KS, 23>(p, st);
-      case 40: return launch_pair_fwd_v<T, KS, 40>(p, st);    // no stream, no epilogue
-      case 72: return launch_pair_fwd_v<T, KS, 72>(p, st);    // no stream, no LDS reads
-      case 104: return launch_pair_fwd_v<T, KS, 104>(p, st);  // no stream, no epilogue, no LDS reads: MFMA only
-      case 108: return launch_pair_fwd_v<T, KS, 108>(p, st);   // ... with dual chains
-      default: return launch_pair_fwd_v<T, KS, 108>(p, st);
-    }
-  }
-  return launch_pair_fwd_v<T, KS, (sizeof(T) == 2 ? PH_DEFAULT_VARIANT : 0)>(p, st);
+  constexpr int V = sizeof(T) == 2 ? PH_DEFAULT_VARIANT : 0;
+  return p.drop_thr16 ? launch_pair_fwd_v<T, KS, V, true>(p, st) : launch_pair_fwd_v<T, KS, V, false>(p, st);
 }
 
 template <typename T>
@@ -1308,6 +1148,10 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
   p.total_classes = total_classes(desc->classes, desc->num_heads);
   PENEO_REQUIRE(p.total_classes <= NCP, "peneo_pair_heads_fwd: more than %d classes in total", NCP);
   p.wp = desc->w_packed; p.b1 = desc->b1; p.b2 = desc->b2;
+  PENEO_REQUIRE(desc->drop_p >= 0.f && desc->drop_p < 1.f, "peneo_pair_heads_fwd: drop_p must be in [0, 1)");
+  PENEO_REQUIRE((int64_t)p.P * (desc->num_heads * desc->D / 4) < ((int64_t)1 << 32), "peneo_pair_heads_fwd: pair space too large for the dropout counter");
+  p.drop_thr16 = pair_drop_thr16_host(desc->drop_p); p.drop_seed = desc->drop_seed;
+  p.drop_scale = p.drop_thr16 ? 65536.f / (65536.f - (float)p.drop_thr16) : 1.f;
   for (int h = 0; h < desc->num_heads; ++h) {
     PENEO_REQUIRE(desc->classes[h] >= 1 && desc->classes[h] <= 4, "peneo_pair_heads_fwd: classes[%d] must be 1..4", h);
     p.classes[h] = desc->classes[h];
@@ -1390,6 +1234,7 @@ extern "C" int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, 
     PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3,
                   "peneo_pair_dz_fused: head %d arguments invalid (classes must be 1..3)", h);
   PENEO_REQUIRE((reinterpret_cast<uintptr_t>(ab_doc) & 15) == 0, "peneo_pair_dz_fused: ab must be 16-byte aligned");
+  PENEO_REQUIRE(args->drop_p == 0.f, "peneo_pair_dz_fused: the classifier dropout is implemented by peneo_pair_bwd_fused and peneo_pair_dz");
   DzFusedParams p;
   p.abd = reinterpret_cast<const bf16_t*>(ab_doc); p.N = N; p.D = D;
   p.pbase = pair_row_start(i0, N); p.npairs = pair_row_start(i1, N) - p.pbase;
@@ -1422,6 +1267,7 @@ extern "C" int peneo_pair_dz(int dtype, void* z_inout, int64_t npairs, const pen
   for (int h = 0; h < args->num_heads; ++h)
     PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3,
                   "peneo_pair_dz: head %d arguments invalid (classes must be 1..3)", h);
+  PENEO_REQUIRE(args->drop_p >= 0.f && args->drop_p < 1.f, "peneo_pair_dz: drop_p must be in [0, 1)");
   DzParams pp; pp.a = *args;
   const int blocks = (int)(npairs < DZ_SLOTS ? npairs : DZ_SLOTS);
   if (dtype == PENEO_BF16) hipLaunchKernelGGL(pair_dz_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)z_inout, npairs, pp, workspace);

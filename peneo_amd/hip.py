@@ -55,7 +55,8 @@ class EmbedGrads(C.Structure):
 
 
 class PairHeadsDesc(C.Structure):
-    _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("w_packed", _vp), ("b1", _vp), ("b2", _vp)]
+    _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("w_packed", _vp), ("b1", _vp), ("b2", _vp),
+                ("drop_p", _f), ("drop_seed", _u32)]
 
 
 class PairLoss(C.Structure):
@@ -65,7 +66,8 @@ class PairLoss(C.Structure):
 
 class PairDzArgs(C.Structure):
     _fields_ = [("num_heads", _i), ("D", _i), ("classes", _i * MAX_HEADS), ("dlogits", _vp * MAX_HEADS),
-                ("w2", _vp * MAX_HEADS), ("scale", _vp)]
+                ("w2", _vp * MAX_HEADS), ("scale", _vp), ("drop_p", _f), ("drop_seed", _u32), ("drop_doc", _i),
+                ("drop_pair0", _i64)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/peneo_hip.h appears here

@@ -144,45 +144,102 @@ def side_stream(device, role: str) -> "torch.cuda.Stream":
 # A backward stage that put its weight-gradient kernels on a side stream used to end with main.wait_stream(side): the main
 # stream (= the activation-gradient critical path) then idles until the last weight gradient of the layer is done (~50 us
 # per encoder layer, the QKV wgrad can only start once the attention backward has produced dqkv).  When the gradients are
-# freshly assigned (p.grad is None: autograd's AccumulateGrad only stores the tensor, no kernel reads it) the join can wait:
-# the stage leaves an event here, the NEXT stage's end (one layer of slack) or the end-of-backward callback waits for it on
-# the main stream.  Anything that reads gradients on the main stream before the backward has ended (the data-parallel
-# wrapper's early pack) calls join_pending() first.
-_PENDING: list = []
-_PENDING_HELD: list = []     # joins that only the end of the backward (or join_pending) waits for
-_CALLBACK_ARMED = [False]
+# freshly assigned (p.grad is None, no grad mode, no hooks: autograd's AccumulateGrad only stores the tensor, no kernel reads
+# it) the join can wait: the stage leaves an event here, the NEXT stage's end (one layer of slack) or the end-of-backward
+# callback waits for it on the main stream.  Anything that reads gradients on the main stream before the backward has ended
+# (the data-parallel wrapper's early pack, a user hook) must call join_pending() first.
+#
+# State is per DEVICE (one record per device index).  The product runs one process per GPU and calls the model from one
+# thread; two models on ONE device share that device's record, which is correct (the joins are stream-level
+# waits, whoever issues them) but serialises their side streams.
+class _Pending:
+    __slots__ = ("next_stage", "held", "armed")
+
+    def __init__(self) -> None:
+        self.next_stage: list = []   # (event, kept tensors): joined by the next stage that defers, or by join_pending()
+        self.held: list = []         # joins that only the end of the backward (or join_pending) waits for
+        self.armed = False           # an end-of-backward callback is queued on the running graph task
+
+
+_STATE: Dict[int, _Pending] = {}
 DEFER_ALLOWED = [True]       # False: every stage joins its side stream before it returns (torch DDP reads .grad in hooks)
+LATE_PARAMS: set = set()     # id()s of parameters whose gradient DATA is complete only when the backward has ended (held joins)
+TRUSTED_GRAD_HOOKS = [False]  # True while the only parameter hooks are ones that call join_pending() before reading .grad
 
 
-def _end_of_backward_join() -> None:
-    _CALLBACK_ARMED[0] = False
-    join_pending()
+def _state(device: Optional[int] = None) -> _Pending:
+    idx = torch.cuda.current_device() if device is None else device
+    st = _STATE.get(idx)
+    if st is None:
+        st = _STATE[idx] = _Pending()
+    return st
+
+
+def can_defer(params) -> bool:
+    """True when nothing can read the stage's parameter gradients on the main stream before the backward has ended:
+    deferral is allowed, the backward is not being recorded (create_graph makes AccumulateGrad clone), every .grad is unset
+    (AccumulateGrad stores the tensor instead of adding into an existing one), and no parameter carries a tensor hook or a
+    post-accumulate hook other than the data-parallel wrapper's (which joins before it reads)."""
+    if not DEFER_ALLOWED[0] or torch.is_grad_enabled():
+        return False
+    for p in params:
+        if p is None:
+            continue
+        if p.grad is not None or getattr(p, "_backward_hooks", None):
+            return False
+        if getattr(p, "_post_accumulate_grad_hooks", None) and not TRUSTED_GRAD_HOOKS[0]:
+            return False
+    return True
+
+
+def _end_of_backward_join(device: int) -> None:
+    st = _state(device)
+    st.armed = False
+    with torch.cuda.device(device):
+        join_pending()
 
 
 def defer_join(side: "torch.cuda.Stream", keep=(), hold: bool = False) -> None:
     """Record `side`'s progress; waits for the events left by EARLIER stages (they are long complete) on the current stream.
-    `keep`: tensors the side stream is still reading; they were allocated on the main stream, so they must stay referenced
-    until the join (the caching allocator would hand their memory to the next main-stream allocation otherwise).
+    `keep`: tensors the side stream is still READING; they were allocated on the main stream, so they must stay referenced
+    until the join (the caching allocator would hand their memory to the next main-stream allocation otherwise).  Never a
+    tensor the stage returns as a gradient: the extra reference makes AccumulateGrad clone it on the main stream.
     `hold`: long side work (the decoder's dW1 GEMM) that later stages must NOT wait for: joined by join_pending() only."""
+    st = _state()
     ev = torch.cuda.Event()
     ev.record(side)
     if hold:
-        _PENDING_HELD.append((ev, tuple(keep)))
+        st.held.append((ev, tuple(keep)))
     else:
-        older = list(_PENDING)
-        _PENDING.clear()
-        _PENDING.append((ev, tuple(keep)))
+        older = list(st.next_stage)
+        st.next_stage.clear()
+        st.next_stage.append((ev, tuple(keep)))
         main = torch.cuda.current_stream()
         for e, _ in older:
             main.wait_event(e)
-    if not _CALLBACK_ARMED[0]:
-        _CALLBACK_ARMED[0] = True
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
+    if not st.armed:
+        st.armed = True
+        device = torch.cuda.current_device()
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward_join(device))
 
 
-def join_pending() -> None:
-    """Make the current stream wait for every deferred side-stream event."""
+def join_pending(held: bool = True) -> None:
+    """Make the current stream wait for every deferred side-stream event of the current device (`held=False`: all but the
+    held ones, whose outputs the caller does not read)."""
+    st = _state()
     main = torch.cuda.current_stream()
-    for pending in (_PENDING, _PENDING_HELD):
+    for pending in ((st.next_stage, st.held) if held else (st.next_stage,)):
         while pending:
             main.wait_event(pending.pop()[0])
+
+
+def reset_pending() -> None:
+    """Called at the start of every model forward: a backward that raised after defer_join() (an out-of-memory error the
+    training loop caught) never ran its end-of-backward callback, so its events would stay queued and `armed` would stay
+    set, and no later backward would arm a join again.  Joining here is free when the lists are empty."""
+    if not torch.cuda.is_available():
+        return
+    st = _state()
+    if st.next_stage or st.held:
+        join_pending()
+    st.armed = False

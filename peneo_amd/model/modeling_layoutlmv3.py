@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import ops
 from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
 from .configuration_peneo import LayoutLMv3Config
-from .engine import DEFER_ALLOWED, DropoutSeeds, WeightCache, defer_join, join_pending, zeros_like_param, zeros_like_params
+from .engine import DropoutSeeds, can_defer, WeightCache, defer_join, join_pending, zeros_like_param, zeros_like_params
 from .engine import side_stream as engine_side_stream
 from .relpos import bucket_lut, visual_xy
 
@@ -117,28 +117,6 @@ class _FwdState:
         self.dtype = torch.float32
         self.dims = None       # (B, S, T)
         self.grad_pools = None  # [layers, pool] fp32 accumulators of the layer stages' backward (one zero fill per step)
-        self.children = None   # per-stream slices of this state when the encoder runs document groups on several streams
-
-    def child(self, k: int, lo: int, hi: int) -> "_FwdState":
-        """State of document group k = documents lo..hi-1 (documents are independent): slices of the shared tensors, own
-        gradient buffers, own dropout streams."""
-        import copy
-        B, S, T = self.dims
-        Bh = hi - lo
-        sl = slice(lo, hi)
-        c = _FwdState()
-        c.dtype, c.dims = self.dtype, (Bh, S, T)
-        c.bias = self.bias[sl] if self.bias is not None else None
-        c.key_bias = self.key_bias[sl] if self.key_bias is not None else None
-        c.key_mask = self.key_mask[sl] if self.key_mask is not None else None
-        c.buckets = tuple(t[sl] if t is not None else None for t in self.buckets)
-        if self.bucket_inputs is not None:
-            pos_t, xs, ys, lut1, lut2 = self.bucket_inputs
-            cut = lambda t: t[sl].contiguous() if t is not None else None
-            c.bucket_inputs = (cut(pos_t), cut(xs), cut(ys), lut1, lut2)
-        c.seeds = copy.copy(self.seeds)
-        c.seeds.base = (self.seeds.base ^ ((k + 1) * 0x9E3779B9)) & 0xFFFFFFFF
-        return c
 
 
 # ------------------------------------------------------------------------------------------------
@@ -256,10 +234,7 @@ class _EmbedStage(torch.autograd.Function):
                       pad_id=cfg.pad_token_id)
         ops.colsum(d_x0.view(B * S, H), out=g[id(type_w)][0], accumulate=True)
         # rel-pos tables: every layer has accumulated its dS into st.g_bias by now
-        for stc in (st.children or [st]):
-            if not ((stc.g_bias is not None or stc.ds_layers is not None) and rel):
-                continue
-            st_parent, st = st, stc
+        if (st.g_bias is not None or st.ds_layers is not None) and rel:
             use1, use2 = cfg.has_relative_attention_bias, cfg.has_spatial_attention_bias
             ri = iter(rel)
             w1 = next(ri) if use1 else None
@@ -280,7 +255,6 @@ class _EmbedStage(torch.autograd.Function):
                 ops.relpos_bias_bwd(st.g_bias, st.buckets[0], st.buckets[1], st.buckets[2], gw[0], gw[1], gw[2],
                                     1.0 / math.sqrt(d))
                 st.g_bias = None
-            st = st_parent
         join_pending()     # weight-gradient work the layer stages left on the side stream
         grads = tuple(g[id(p)] if p.requires_grad else None for p in ctx.params)
         return (None, None, None, None, None, None) + grads
@@ -364,18 +338,8 @@ class _LayerStage(torch.autograd.Function):
             held.append((fn, box))
             return box
 
-        # optional (PENEO_WGRAD_GROUP=1): weight gradients dW = dy^T x collected into one grouped launch (full K per tile,
-        # no split-k reductions)
-        group_ok = model.wgrad_group and dt == torch.bfloat16 and H % 8 == 0 and cfg.intermediate_size % 8 == 0 and not model.wgrad_late
-        jobs = []
-
         def wgrad(dy, xin):
-            nonlocal group_ok
-            if not group_ok:
-                return ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
-            out = torch.empty((dy.shape[1], xin.shape[1]), dtype=torch.float32, device=dev)
-            jobs.append((dy, xin, out))
-            return out
+            return ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
         # all small fp32 accumulators of the stage (LayerNorm and bias gradients) carved from ONE zero-filled buffer:
         # one fill launch instead of eight fills / memsets per layer
         I = cfg.intermediate_size
@@ -416,13 +380,6 @@ class _LayerStage(torch.autograd.Function):
         if d_dense1 is None:
             d_dense1 = d_h1
         r_o = on_side_late(lambda: (red1(), ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att))[1:])
-        if jobs:
-            # FFN2, FFN1 and the attention output projection (324 tiles) run beside the attention backward; the QKV weight
-            # gradient needs dqkv and goes out alone afterwards (split-k), or the stage would end waiting for the group
-            first = list(jobs)
-            on_side(lambda: ops.gemm_group(first, a_kmajor=False, b_kmajor=False))
-            jobs.clear()
-            group_ok = False
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
         dqkv = torch.empty_like(qkv)
@@ -449,10 +406,10 @@ class _LayerStage(torch.autograd.Function):
                      ds_out=ds_out)
         _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
         def launch_rel():
-            if ds_out is not None and idx % model.rel_group == 0:
-                # the bias-table gradient of layers idx .. idx+group-1 (their dS^T slabs are complete), on its own stream
-                # (joined only by _EmbedStage.backward): LDS-atomic and HBM bound
-                hi = min(idx + model.rel_group, cfg.num_hidden_layers)
+            if ds_out is not None and idx == 0:
+                # the bias-table gradient of all layers (their dS^T slabs are complete), on its own stream (joined only by
+                # _EmbedStage.backward): LDS-atomic and HBM bound
+                hi = cfg.num_hidden_layers
                 rel_stream = model.side_stream(dev, "rel")
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -469,7 +426,7 @@ class _LayerStage(torch.autograd.Function):
         if model.rel_after_dgrad:
             launch_rel()
         if side is not None:
-            if model.defer_wgrad_join and DEFER_ALLOWED[0] and all(p.grad is None for p in ctx.params):
+            if model.defer_wgrad_join and can_defer(ctx.params):
                 # joined one stage later (engine.py): the critical path does not wait for dW_qkv
                 defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x, *side_keep))
             else:
@@ -518,14 +475,7 @@ class LayoutLMv3Model(nn.Module):
         self.defer_wgrad_join = os.environ.get("PENEO_DEFER_JOIN", "1") != "0"
         self.ln_partials = os.environ.get("PENEO_LN_PARTIALS", "0") != "0"   # measured +-0 in the step; gives order-independent dgamma / dbeta
         self.wgrad_late = os.environ.get("PENEO_WGRAD_LATE", "1") != "0"   # +0.7 % (17.72 -> 17.59 ms per step)
-        # one grouped launch (peneo_gemm_group) for three of a layer's four wgrads: 2x faster alone (97 vs 190 us for all four),
-        # but in the step the long full-K workgroups crowd the critical path: enc. backward 7.9 vs 7.6 ms -> off by default
-        self.wgrad_group = os.environ.get("PENEO_WGRAD_GROUP", "0") != "0"
-        self.enc_split = int(os.environ.get("PENEO_ENC_SPLIT", "1"))   # document groups (HIP streams) through the encoder
-        self.enc_groups = [int(v) for v in os.environ.get("PENEO_ENC_GROUPS", "").split(",") if v.strip()]   # uneven groups
         self.rel_after_dgrad = os.environ.get("PENEO_REL_AFTER_DGRAD", "1") != "0"
-        self.rel_group = int(os.environ.get("PENEO_REL_GROUP", "1000"))   # layers per bias-table reduction; groups of 4 run beside the
-        # remaining layers but measured slower (285 vs 302 docs/s): the histogram kernel crowds the GEMMs off the CUs
         self._luts = {}
 
     # ---- small host-side constants ---------------------------------------------------------
@@ -618,45 +568,6 @@ class LayoutLMv3Model(nn.Module):
         x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(), attention_mask.contiguous(), image,
                               *self.embed_params())
         _, _, T = st.dims
-        # document groups: PENEO_ENC_GROUPS = "7,1" (sizes, must add up to the batch) or PENEO_ENC_SPLIT = n equal groups
-        sizes = [B]
-        if self.enc_groups and sum(self.enc_groups) == B and len(self.enc_groups) > 1:
-            sizes = list(self.enc_groups)
-        elif self.enc_split > 1 and B % self.enc_split == 0:
-            sizes = [B // self.enc_split] * self.enc_split
-        n = len(sizes)
-        bounds = [sum(sizes[:k]) for k in range(n + 1)]
-        if n == 1:
-            for i, layer in enumerate(self.encoder.layer):
-                x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
-            return (x.view(B, T, cfg.hidden_size),)
-        # Documents are independent through the encoder: run n groups of documents on n HIP streams.  The kernels of one
-        # group fill the tails / small launches of the other, in the forward and (autograd replays each stage on the
-        # stream of its forward) in the backward.  Working copies of the weights are cast on the main stream first.
-        H, dt, dev = cfg.hidden_size, st.dtype, x.device
         for i, layer in enumerate(self.encoder.layer):
-            s_, o_ = layer.attention.self, layer.attention.output
-            self.weight_cache.cat_rows(f"L{i}.qkv", [s_.query.weight, s_.key.weight, s_.value.weight], dt)
-            self.weight_cache.get((f"L{i}.bqkv",), [s_.query.bias, s_.key.bias, s_.value.bias],
-                                  lambda: torch.cat([s_.query.bias.detach(), s_.key.bias.detach(), s_.value.bias.detach()]))
-            self.weight_cache.cast(f"L{i}.o", o_.dense.weight, dt)
-            self.weight_cache.cast(f"L{i}.i", layer.intermediate.dense.weight, dt)
-            self.weight_cache.cast(f"L{i}.o2", layer.output.dense.weight, dt)
-        main = torch.cuda.current_stream()
-        st.children = [st.child(k, bounds[k], bounds[k + 1]) for k in range(n)]
-        x3 = x.view(B, T, H)
-        streams = [self.side_stream(dev, f"enc{k}") for k in range(n)]
-        parts = []
-        for k in range(n):
-            streams[k].wait_stream(main)
-            with torch.cuda.stream(streams[k]):
-                parts.append(x3[bounds[k]:bounds[k + 1]].reshape(sizes[k] * T, H))
-        for i, layer in enumerate(self.encoder.layer):
-            params = layer_params(layer)
-            for k in range(n):
-                with torch.cuda.stream(streams[k]):
-                    parts[k] = _LayerStage.apply(self, st.children[k], i, parts[k], *params)
-        for k in range(n):
-            main.wait_stream(streams[k])
-        x = torch.cat([p.view(sizes[k], T, H) for k, p in enumerate(parts)], dim=0)
-        return (x,)
+            x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
+        return (x.view(B, T, cfg.hidden_size),)

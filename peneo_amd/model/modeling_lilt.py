@@ -26,7 +26,7 @@ from .. import ops
 from ..hip import ACT_GELU, PeneoHipError
 from .configuration_peneo import LiltConfig
 from .engine import DropoutSeeds, WeightCache, zeros_like_param, zeros_like_params
-from .engine import DEFER_ALLOWED, defer_join, join_pending
+from .engine import can_defer, defer_join, join_pending
 from .engine import side_stream as engine_side_stream
 
 
@@ -114,8 +114,10 @@ def _post_attn_fwd(wc: WeightCache, key: str, dt, eps, seeds: DropoutSeeds, site
 
 
 def _post_attn_bwd(wc: WeightCache, key: str, dt, seeds: DropoutSeeds, site: int, d_out, saved, params, on_side):
-    """-> (d_att, d_x_residual, grads in parameter order).  ``on_side(fn)`` runs the parameter-gradient work (wgrad
-    GEMMs, bias column sums) on the stage's second stream, off the activation-gradient critical path."""
+    """-> (d_att, d_x_residual, grads in parameter order).  ``on_side(fn, operands)`` runs the parameter-gradient work
+    (wgrad GEMMs, bias column sums) on the stage's second stream, off the activation-gradient critical path; ``operands``
+    are the tensors that work READS (kept alive until the join).  Its outputs are never kept: they are returned as
+    gradients, and an extra reference would make AccumulateGrad clone them on the main stream instead of storing them."""
     wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2 = params
     att, h1, m1, r1, a, zi, inter, h2, m2, r2 = saved
     Wo, Wi, Wo2 = wc.cast(key + ".o", wo, dt), wc.cast(key + ".i", wi, dt), wc.cast(key + ".o2", wo2, dt)
@@ -130,16 +132,16 @@ def _post_attn_bwd(wc: WeightCache, key: str, dt, seeds: DropoutSeeds, site: int
                              drop2_seed=seeds.seed(site + 1))
     if d_dense2 is None:
         d_dense2 = d_h2
-    _, dwo2 = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)))
+    _, dwo2 = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)), (d_dense2, inter))
     d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
-    _, dwi = on_side(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
+    _, dwi = on_side(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)), (d_zi, a))
     d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
     d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
     d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1, dx_dropped=d_dense1, drop2_p=seeds.p_hidden,
                              drop2_seed=seeds.seed(site))
     if d_dense1 is None:
         d_dense1 = d_h1
-    _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
+    _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)), (d_dense1, att))
     d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
     return d_att, d_h1, (dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2)
 
@@ -277,10 +279,14 @@ class _LiltLayerStage(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = model.side_stream(dev)
 
-        kept = []        # closures of the side-stream work: they hold the operand tensors until the (deferred) join
+        # operand tensors of the side-stream work, referenced until the (deferred) join.  Only what the side stream READS:
+        # a reference to one of its OUTPUTS (the bias-gradient slices are returned as gradients) would push that tensor's
+        # use count to 2, AccumulateGrad would clone it on the main stream instead of storing it, and the clone would race
+        # the side stream's column sums
+        kept = []
 
-        def on_side(fn):
-            kept.append(fn)
+        def on_side(fn, operands=()):
+            kept.extend(operands)
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(side):
@@ -302,10 +308,11 @@ class _LiltLayerStage(torch.autograd.Function):
         Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
         Wlqkv = wc.cat_rows(f"L{idx}.lqkv", [lwq, lwk, lwv], dt)
         wg = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
-        dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)))
+        dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)),
+                                               (dqkv, dlqkv, x, l))
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_x_res)
         d_l = ops.gemm(dlqkv, Wlqkv, b_kmajor=False, residual=d_l_res)
-        if os.environ.get("PENEO_DEFER_JOIN", "1") != "0" and DEFER_ALLOWED[0] and all(p.grad is None for p in ctx.params):
+        if os.environ.get("PENEO_DEFER_JOIN", "1") != "0" and can_defer(ctx.params):
             defer_join(side, keep=kept)   # joined one stage later: the critical path does not wait for the QKV wgrads (engine.py)
         else:
             main.wait_stream(side)

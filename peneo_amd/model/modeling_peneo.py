@@ -20,6 +20,7 @@ from .. import ops
 from ..hip import PeneoHipError, load_library
 from .backbone_mapping import BACKBONE_MAPPING
 from .configuration_peneo import PEneoConfig
+from .engine import reset_pending
 from .peneo_decoder import PEneoDecoder
 
 logger = logging.getLogger(__name__)
@@ -42,6 +43,66 @@ class _CropStage(torch.autograd.Function):
         d_hidden = torch.zeros((B, T, H), dtype=d_out.dtype, device=d_out.device)
         ops.copy_rows(d_out.contiguous(), d_hidden[:, lo:hi], drop_p=drop_p, drop_seed=seed)
         return d_hidden, None, None, None, None
+
+
+def build_backbone(info, backbone_config: dict):
+    """Backbone from a config dict (unknown keys of a hub config.json are dropped)."""
+    bcfg = dict(backbone_config)
+    bcfg.pop("model_type", None)
+    known = set(inspect.signature(info.config.__init__).parameters) | \
+        set(inspect.signature(info.config.__mro__[1].__init__).parameters)
+    return info.model(info.config(**{k: v for k, v in bcfg.items() if k in known}))
+
+
+def load_pretrained_backbone(info, name_or_path: str):
+    """``info.model.from_pretrained(name_or_path)`` of the reference (model/modeling_peneo.py:58-79) for LOCAL checkpoint
+    directories: ``config.json`` + ``model.safetensors`` / ``pytorch_model.bin`` in the HF layout of the backbone
+    (keys optionally prefixed ``layoutlmv3.`` / ``lilt.`` / ``backbone.``).  "auto" and unreadable paths resolve to the
+    registry's hub name, which needs network access: OSError."""
+    import json
+    import os
+
+    def read(path):
+        if not os.path.isdir(path) or not os.path.isfile(os.path.join(path, "config.json")):
+            raise OSError(f"{path!r} is not a local checkpoint directory (config.json + weights); the HuggingFace hub is "
+                          f"not reachable from this process")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        st = os.path.join(path, "model.safetensors")
+        if os.path.isfile(st):
+            from safetensors.torch import load_file
+            state = load_file(st)
+        elif os.path.isfile(os.path.join(path, "pytorch_model.bin")):
+            state = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        else:
+            raise OSError(f"no model.safetensors / pytorch_model.bin in {path!r}")
+        return cfg, state
+
+    if name_or_path == "auto":
+        cfg, state = read(info.hf_name)
+    else:
+        try:
+            cfg, state = read(name_or_path)
+        except OSError:
+            logger.warning(f"Could not load pretrained model from {name_or_path}. "
+                           f"Load from {info.hf_name} in huggingface_hub instead.")
+            cfg, state = read(info.hf_name)
+    backbone = build_backbone(info, cfg)
+    own = backbone.state_dict()
+    mapped = {}
+    for k, v in state.items():
+        for prefix in ("backbone.", "layoutlmv3.", "lilt.", ""):
+            if k.startswith(prefix) and k[len(prefix):] in own:
+                mapped[k[len(prefix):]] = v
+                break
+    missing = [k for k in own if k not in mapped and not k.endswith("position_ids")]
+    if missing:
+        logger.warning(f"backbone checkpoint lacks {len(missing)} tensors (left at their initial values): {missing[:8]}")
+    if not mapped:
+        raise OSError(f"{name_or_path!r} holds no tensor of a {type(backbone).__name__} state dict")
+    backbone.load_state_dict(mapped, strict=False)
+    backbone._loaded_from_checkpoint = set(mapped)
+    return backbone
 
 
 class PEneoPreTrainedModel(PreTrainedModel):
@@ -72,14 +133,15 @@ class PEneoModel(PEneoPreTrainedModel):
             raise ValueError(
                 "You cannot initialize a model with a config file that has no backbone config "
                 "and without specifying the path to a pretrained model.")
-        if backbone_name_or_path is not None and config.backbone_config is None:
-            raise ValueError("initialising the backbone from a hub / local checkpoint needs network access or HF "
-                             "weights; pass config.backbone_config and load a PEneo state dict instead")
-        bcfg = dict(config.backbone_config)
-        bcfg.pop("model_type", None)
-        known = set(inspect.signature(self.backbone_info.config.__init__).parameters) | \
-            set(inspect.signature(self.backbone_info.config.__mro__[1].__init__).parameters)
-        self.backbone = self.backbone_info.model(self.backbone_info.config(**{k: v for k, v in bcfg.items() if k in known}))
+        if backbone_name_or_path is not None:
+            # fine-tuning start (reference :58-79): backbone weights from a checkpoint directory, "auto" = the registry's hub
+            # name; a path that cannot be read falls back to the hub name like the reference, and with no network that
+            # raises OSError instead of silently training from random weights
+            self.backbone = load_pretrained_backbone(self.backbone_info, backbone_name_or_path)
+            if config.backbone_config is None:
+                config.backbone_config = self.backbone.config.to_dict()
+        else:
+            self.backbone = build_backbone(self.backbone_info, config.backbone_config)
         self.dropout = nn.Dropout(config.backbone_config["hidden_dropout_prob"])
         self.loss_ratio = config.peneo_loss_ratio
         if self.loss_ratio is not None:
@@ -92,10 +154,16 @@ class PEneoModel(PEneoPreTrainedModel):
         self.peneo_decoder = PEneoDecoder(config=config, input_size=downstream_input_size)
         self._compute_dtype = torch.float32
         self._step = 0
+        loaded = None
+        if backbone_name_or_path is not None:        # post_init() re-initialises every module: keep the checkpoint's tensors
+            loaded = {k: v.detach().clone() for k, v in self.backbone.state_dict().items()
+                      if k in self.backbone._loaded_from_checkpoint}
         try:
             self.post_init()
         except AttributeError:  # transformers < 4.x naming
             self.init_weights()
+        if loaded is not None:
+            self.backbone.load_state_dict(loaded, strict=False)
 
     # ---- precision of the HIP path ------------------------------------------------------------
     def set_compute_dtype(self, dtype: torch.dtype) -> "PEneoModel":
@@ -113,6 +181,7 @@ class PEneoModel(PEneoPreTrainedModel):
     def forward(self, input_ids, bbox, orig_bbox, attention_mask, image=None, **kwargs):
         kwargs.update({"input_ids": input_ids, "bbox": bbox, "orig_bbox": orig_bbox, "attention_mask": attention_mask,
                        "image": image})
+        reset_pending()   # joins left behind by a backward that raised (engine.py)
         names = [p.name for p in inspect.signature(self.backbone.forward).parameters.values()]
         backbone_kwargs = {n: kwargs.get(n, None) for n in names if n not in ("unused", "kwargs")}
         self.backbone.compute_dtype = self._compute_dtype

@@ -21,7 +21,7 @@ from transformers.modeling_outputs import ModelOutput
 
 from .. import ops
 from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
-from .engine import DEFER_ALLOWED, DropoutSeeds, WeightCache, defer_join
+from .engine import LATE_PARAMS, DropoutSeeds, WeightCache, can_defer, defer_join
 
 HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
@@ -198,9 +198,13 @@ class _DecoderStage(torch.autograd.Function):
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         b2cat = wc.get(("dec.b2",), b2s, lambda: torch.cat([b.detach() for b in b2s]))
         cws = [dec.le_loss.weight] + [dec.link_loss.weight] * 4 if tags is not None else None
+        # the Dropout between the two layers of every classifier (reference :261) acts on the [B, P, 5D] hidden inside the
+        # kernel; the backward regenerates the mask from (p, seed)
+        saved["k12_drop"] = (seeds.p_hidden, seeds.seed(903))
         logits, partials, dlog = ops.pair_heads_fwd(ab, wp, b1cat, b2cat, HEAD_CLASSES, want_logits=want_logits,
                                                     tags=tags, class_weights=cws,
-                                                    want_dlogits=need_grad and tags is not None)
+                                                    want_dlogits=need_grad and tags is not None,
+                                                    drop_p=seeds.p_hidden, drop_seed=seeds.seed(903))
         outs = []
         if tags is not None and dec.le_loss.ohem:
             # OHEM: the kept pairs of each head are chosen from its finished logit map; the un-normalised dlogits of the
@@ -265,10 +269,13 @@ class _DecoderStage(torch.autograd.Function):
         W1cat = wc.cat_rows("dec.w1cat", w1s, dt)                      # [nh*D, D]
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         dW1cat = torch.zeros((nh * D, D), dtype=torch.float32, device=dev)
-        dz_ws = ops.pair_dz_workspace(nh, D, dev, slots=256)   # rows both dz producers used here spread their atomics over
         P = N * (N + 1) // 2
         w2d = [w.detach().contiguous() for w in w2s]
+        drop_p, drop_seed = sv["k12_drop"]
         use_fused_bwd = dec.fused_bwd and ops.pair_bwd_supported(dt, D)
+        # rows the dz producers spread their partial sums over: 256 for the fused kernels / the GEMM epilogue, the full
+        # 1024 for the stand-alone peneo_pair_dz (the chunked path with the classifier dropout active)
+        dz_ws = ops.pair_dz_workspace(nh, D, dev, slots=256 if (use_fused_bwd or drop_p == 0.0) else None)
         # the fused kernel overwrites d_ab; the chunked path accumulates into it
         d_ab = (torch.empty if use_fused_bwd else torch.zeros)((B, N, 2 * D), dtype=torch.float32, device=dev)
         if use_fused_bwd:
@@ -278,7 +285,7 @@ class _DecoderStage(torch.autograd.Function):
             rows = ops.pair_bwd_rows(N)
             dzbuf = torch.empty((B * rows, nh * D), dtype=dt, device=dev)
             xbuf1 = torch.empty((B * rows, D), dtype=dt, device=dev)
-            dza = ops.pair_dz_args(D, HEAD_CLASSES, sv["dlog"], w2d, scale)
+            dza = ops.pair_dz_args(D, HEAD_CLASSES, sv["dlog"], w2d, scale, drop_p=drop_p, drop_seed=drop_seed)
             ops.pair_bwd_fused(ab, wp2, b1cat, dza, dzbuf, xbuf1, d_ab, dz_ws)
             # dW1 = dz^T x (2 ms of pure MFMA work, needed by nobody until the optimizer) runs on the side stream beside the
             # shrink-MLP backward and the first encoder layers, whose short kernels leave CUs idle; joined one stage later
@@ -295,7 +302,7 @@ class _DecoderStage(torch.autograd.Function):
                     # encoder backward instead and is joined when the backward ends (split 11 / 7 / 5 / 4 / 3: 18.56 /
                     # 18.79 / 18.34 / 18.16 / 18.10 ms per step on one box).
                     # Only when the join can wait for the end of the backward (fresh .grad tensors, no DDP hooks reading them).
-                    can_hold = dec.dw1_hold and DEFER_ALLOWED[0] and all(p.grad is None for p in params)
+                    can_hold = dec.dw1_hold and can_defer(params)
                     split = None if not can_hold else \
                         dec.dw1_side_split or max(1, dec.dw1_side_wgs // (-(-nh * D // 128) * -(-D // 128)))
                     ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat, split_k=split)
@@ -315,25 +322,18 @@ class _DecoderStage(torch.autograd.Function):
         prebuf = [torch.empty((maxp, D), dtype=dt, device=dev) for _ in range(2)]   # a_i + b_j: SiLU' source of the dx GEMM
         zbuf = [torch.empty((maxp, nh * D), dtype=dt, device=dev) for _ in range(2)]
         dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
-        fused_dz = (dec.fused_dz and not dec.three_streams and dt == torch.bfloat16 and D % 32 == 0
+        # with the classifier dropout active the chunked path runs z = x W1^T + b1 as a plain GEMM and the stand-alone
+        # peneo_pair_dz kernel (the one chunked form that regenerates the mask)
+        fused_dz = (dec.fused_dz and dt == torch.bfloat16 and D % 32 == 0 and drop_p == 0.0
                     and D // 16 in (2, 4, 6, 8, 12, 16, 24, 32))
         if fused_dz:
             wp = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
                                                                                  [w.detach() for w in w2s]))
-        # measured (docs/s, B = 8): x on main + dW1 on main 368.8, x on side + dW1 on main 368.4, x on main 366.6, both on side 362.5
-        x_on_side = os.environ.get("PENEO_DZ_X_SIDE", "0") != "0"
-        dw_on_main = os.environ.get("PENEO_DZ_DW_MAIN", "1") != "0"
-        x_from_dz = fused_dz and os.environ.get("PENEO_DZ_WRITES_X", "0") != "0"   # no separate pair_x_fwd pass at all
-        x_ready = [torch.cuda.Event() for _ in range(2)]
         main = torch.cuda.current_stream()
         side = main if os.environ.get("PENEO_DEC_STREAMS", "2") == "1" else dec.side_stream(dev)   # "1": strictly serial
-        third = dec.side_stream(dev, 1) if dec.three_streams else None   # the weight-gradient GEMM on its own stream
         ready = [torch.cuda.Event() for _ in range(2)]
         done = [torch.cuda.Event() for _ in range(2)]
-        done_w = [torch.cuda.Event() for _ in range(2)]
         side.wait_stream(main)                       # d_ab / dW1cat zero fills, ab, weights
-        if third is not None:
-            third.wait_stream(main)
         idx = 0
         for b in range(B):
             for (i0, i1) in chunks:
@@ -344,42 +344,28 @@ class _DecoderStage(torch.autograd.Function):
                 x, z, dx, pre = xbuf[k][:npairs], zbuf[k][:npairs], dxbuf[:npairs], prebuf[k][:npairs]
                 if idx >= 2:
                     main.wait_event(done[k])         # stage 2 of chunk idx-2 has released x[k] / z[k]
-                    if third is not None:
-                        main.wait_event(done_w[k])
-                dza = ops.pair_dz_args(D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, scale)
+                dza = ops.pair_dz_args(D, HEAD_CLASSES, [sv["dlog"][h][b, p0:p1] for h in range(nh)], w2d, scale,
+                                       drop_p=drop_p, drop_seed=drop_seed, drop_doc=b, drop_pair0=p0)
                 if fused_dz:
                     # dz straight from ab: x lives in registers, z in the MFMA accumulators; x / pre are only needed by
-                    # the dW1 / dx GEMMs.  Which stream produces x and which runs the dW1 GEMM only balances the two queues.
-                    if not x_on_side and not x_from_dz:
-                        ops.pair_x_fwd(ab[b], i0, i1, x, pre)
-                    if x_from_dz:
-                        ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws, x, pre)   # x / pre from its fragments
-                    else:
-                        ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws)
-                    if dw_on_main:
-                        if x_on_side and not x_from_dz:
-                            with torch.cuda.stream(side):
-                                ops.pair_x_fwd(ab[b], i0, i1, x, pre)
-                                x_ready[k].record(side)
-                            main.wait_event(x_ready[k])
-                        ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
+                    # the dW1 / dx GEMMs (measured best split of the two queues: x and dW1 on the main stream)
+                    ops.pair_x_fwd(ab[b], i0, i1, x, pre)
+                    ops.pair_dz_fused(ab[b], i0, i1, wp, b1cat, dza, z, dz_ws)
+                    ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
                 else:
                     ops.pair_x_fwd(ab[b], i0, i1, x, pre)
-                    # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
-                    ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
+                    if drop_p > 0.0:
+                        ops.gemm(x, W1cat, bias=b1cat, out=z)
+                        ops.pair_dz(z, npairs, D, HEAD_CLASSES, None, None, dz_ws, None, args=dza)
+                    else:
+                        # z = x W1^T + b1 and, in the same kernel's epilogue, z -> dz plus the dW2 / db1 partial sums
+                        ops.gemm(x, W1cat, bias=b1cat, out=z, pair_dz=dza, pair_dz_ws=dz_ws)
                 ready[k].record(main)
-                if third is not None:
-                    with torch.cuda.stream(third):
-                        third.wait_event(ready[k])
-                        ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
-                        done_w[k].record(third)
                 with torch.cuda.stream(side):
-                    if fused_dz and x_on_side and not dw_on_main and not x_from_dz:
-                        ops.pair_x_fwd(ab[b], i0, i1, x, pre)   # x[k] / pre[k] were released by this stream's own chunk idx-2
                     side.wait_event(ready[k])
                     if idx > 0:
                         side.wait_event(done_x)      # dxbuf is single-buffered: the previous chunk's scatter has read it
-                    if third is None and not (fused_dz and dw_on_main):
+                    if not fused_dz:
                         ops.gemm(z, x, a_kmajor=False, b_kmajor=False, out=dW1cat, accumulate=True)
                     # du = (dz W1) * SiLU'(a_i + b_j) in the GEMM epilogue, then plain segmented sums into d_a / d_b
                     ops.gemm(z, W1cat, b_kmajor=False, out=dx, grad_src=pre, grad_act=ACT_SILU)
@@ -388,8 +374,6 @@ class _DecoderStage(torch.autograd.Function):
                     done_x = done[k]
                 idx += 1
         main.wait_stream(side)
-        if third is not None:
-            main.wait_stream(third)
         return _DecoderStage._finish_backward(ctx, dec, sv, params, scale, dW1cat, dz_ws, d_ab, heads, w1s, b1s, w2s, b2s)
 
     @staticmethod
@@ -440,7 +424,9 @@ class _DecoderStage(torch.autograd.Function):
         if side_work is not None:
             side, keep, can_hold = side_work
             ctx.side_work = None
-            if DEFER_ALLOWED[0] and all(p.grad is None for p in params):
+            if can_defer(params):
+                if can_hold:   # the data-parallel wrapper lays these out last: their data is complete only at the end of the backward
+                    LATE_PARAMS.update(id(w) for w in w1s)
                 defer_join(side, keep=keep, hold=can_hold)
             else:
                 torch.cuda.current_stream().wait_stream(side)
@@ -495,10 +481,10 @@ class PEneoDecoder(nn.Module):
         self.le_loss = _ClassWeightedCE(torch.tensor(cw[:-1]).float(), config.peneo_ohem_num_positive,
                                         config.peneo_ohem_num_negative)
         self.weight_cache = WeightCache()
+        self.train_logits = False    # True: PEneoOutput.*_shaking_outputs are also written in training steps
         # pairs per backward chunk: the z / dz buffer is chunk x 5D (a whole base document is 0.5 GB in bf16, small against
         # 288 GB of HBM), and long launches amortise tile tails and the split-k reduction of the weight-gradient GEMM
         self.bwd_chunk_pairs = int(os.environ.get("PENEO_BWD_CHUNK_PAIRS", 1 << 18))
-        self.three_streams = os.environ.get("PENEO_DEC_STREAMS", "2") == "3"   # measured: no gain over two
         self.fused_dz = os.environ.get("PENEO_DZ_FUSED", "1") != "0"            # bf16: dz without x / z in memory
         self.fused_bwd = os.environ.get("PENEO_BWD_FUSED", "1") != "0"          # bf16: the whole pair-space backward in one kernel
         self.dw1_on_side = os.environ.get("PENEO_DW1_SIDE", "1") != "0"          # its dW1 GEMM beside the following stages
@@ -559,7 +545,12 @@ class PEneoDecoder(nn.Module):
         params = self.stage_params()
         # autograd is off inside Function.forward, so decide here whether the backward will need dlogits
         need_grad = torch.is_grad_enabled() and (sequence_output.requires_grad or any(p.requires_grad for p in params))
-        res = _DecoderStage.apply(self, sequence_output.reshape(B * N, Hin), B, N, tags, True, need_grad, *params)
+        # The logit maps of a TRAINING step (7.3 MB per document in fp32) are read by nobody: the reference's trainer takes
+        # outputs["loss"] and decodes predictions under model.eval() only (pipeline/trainer.py:116-156).  They stay in the
+        # kernel's registers unless `train_logits` asks for them; eval / inference always returns them.
+        want_logits = bool(self.train_logits) or not (self.training and need_grad and tags is not None) \
+            or (tags is not None and self.le_loss.ohem)
+        res = _DecoderStage.apply(self, sequence_output.reshape(B * N, Hin), B, N, tags, want_logits, need_grad, *params)
         loss, l_le, l_elh, l_elt, l_lgh, l_lgt, o_le, o_elh, o_elt, o_lgh, o_lgt = res
         if self.inference_mode:
             # NB the reference's tuple order differs from the dataclass field order (:365-373)

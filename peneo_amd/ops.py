@@ -493,8 +493,10 @@ def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence
 
 def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor,
                    classes: Sequence[int], *, want_logits: bool = True, tags: Optional[Sequence[torch.Tensor]] = None,
-                   class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False):
-    """ab: [B, N, 2D].  Returns (logits list | None, loss partials [n, 32] | None, dlogits list | None)."""
+                   class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False,
+                   drop_p: float = 0.0, drop_seed: int = 0):
+    """ab: [B, N, 2D].  Returns (logits list | None, loss partials [n, 32] | None, dlogits list | None).
+    drop_p / drop_seed: the Dropout between the two classifier layers (train mode, model/peneo_decoder.py:261)."""
     _c(ab)
     B, N, D2 = ab.shape
     D = D2 // 2
@@ -505,6 +507,7 @@ def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: tor
     for h, c in enumerate(classes):
         desc.classes[h] = c
     desc.w_packed, desc.b1, desc.b2 = ptr(wp), ptr(b1), ptr(b2)
+    desc.drop_p, desc.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
     logits = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes] if want_logits else None
     lp = _ptr_list(logits) if logits is not None else None
     loss = None
@@ -552,8 +555,11 @@ def pair_dz_workspace(nh: int, D: int, device, slots: Optional[int] = None) -> t
 
 
 def pair_dz_args(D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor], w2: Sequence[torch.Tensor],
-                 scale: torch.Tensor) -> "hip.PairDzArgs":
+                 scale: torch.Tensor, drop_p: float = 0.0, drop_seed: int = 0, drop_doc: int = 0,
+                 drop_pair0: int = 0) -> "hip.PairDzArgs":
+    """drop_*: the forward's classifier dropout; drop_doc / drop_pair0 locate a chunk (document, packed index of its first pair)."""
     a = hip.PairDzArgs()
+    a.drop_p, a.drop_seed, a.drop_doc, a.drop_pair0 = float(drop_p), int(drop_seed) & 0xFFFFFFFF, int(drop_doc), int(drop_pair0)
     a.num_heads, a.D = len(classes), D
     for h, c in enumerate(classes):
         a.classes[h] = c
@@ -563,8 +569,9 @@ def pair_dz_args(D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor]
 
 
 def pair_dz(z: torch.Tensor, npairs: int, D: int, classes: Sequence[int], dlogits: Sequence[torch.Tensor],
-            w2: Sequence[torch.Tensor], workspace: torch.Tensor, scale: torch.Tensor) -> None:
-    a = pair_dz_args(D, classes, dlogits, w2, scale)
+            w2: Sequence[torch.Tensor], workspace: torch.Tensor, scale: torch.Tensor,
+            args: Optional["hip.PairDzArgs"] = None) -> None:
+    a = args if args is not None else pair_dz_args(D, classes, dlogits, w2, scale)
     check(lib().peneo_pair_dz(dtype_code(z.dtype), ptr(z), npairs, C.byref(a), ptr(workspace), stream()), "peneo_pair_dz")
 
 

@@ -1,7 +1,7 @@
 """Data-parallel plumbing: one process per GPU, documents sharded across ranks, gradients
-all-reduced over RCCL/xGMI (``backend="nccl"`` is RCCL on ROCm) in large bf16-compressed buckets that
-overlap with the remaining backward stages (the model's autograd stages hand their parameter
-gradients to DDP layer by layer, decoder first).
+all-reduced over RCCL/xGMI (``backend="nccl"`` is RCCL on ROCm) from one flat wire buffer laid out in
+stage-execution order, in chunks of ~64 MB that go on the wire as the backward completes them
+(``FlatGradDataParallel``; the first step learns the order and runs un-overlapped).
 
 Reference counterpart: the implicit ``torchrun`` + HF Trainer -> accelerate -> DistributedDataParallel
 path (README.md:206-218); evaluation metrics are merged there with barrier + all_gather_object
@@ -38,58 +38,131 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
 
 
 class FlatGradDataParallel(torch.nn.Module):
-    """Data parallel for the staged model: ONE flat wire buffer, ONE all-reduce per step, no per-parameter hooks.
+    """Data parallel for the staged model: ONE flat wire buffer laid out in the order the backward PRODUCES the gradients,
+    all-reduced in a few large chunks while the rest of the backward is still running.
 
     torch's DistributedDataParallel copies every gradient into its bucket from a per-parameter autograd hook; on this
     stack that is 241 `hipMemcpyAsync` calls per step issued by the autograd thread, and the host falls behind the GPU
     (measured with RCCL at a world of one rank: 252 docs/s against 370 without the wrapper, 5 ms of idle gaps per step).
-    Here the gradients are packed into a flat bf16 buffer by one multi-tensor copy when the backward pass has finished (an
-    end-of-backward engine callback armed from the outputs), summed across ranks by a single RCCL all-reduce (few large
-    transfers suit the per-link bound xGMI ring), and unpacked / averaged by two more multi-tensor launches.
-    `module`, `no_sync()` and the initial parameter broadcast follow DistributedDataParallel."""
+    Here a parameter's post-accumulate hook only counts.  The flat buffer is cut into chunks of about `chunk_mb` of wire
+    bytes (few large transfers suit the per-link bound xGMI ring); when the last gradient of chunk c has been stored (and
+    chunks 0..c-1 are on the wire: every rank issues the collectives in index order) the chunk is packed by ONE multi-tensor
+    copy and all-reduced asynchronously.  The last chunk goes out when the backward has ended (an engine callback armed
+    from the outputs); then the buffer is scaled and unpacked by two more multi-tensor launches.
 
-    def __init__(self, module: torch.nn.Module, compress: str = "bf16"):
+    Layout.  Gradient arrival is not parameter registration order: the decoder's gradients come first, then encoder layers
+    L-1 .. 0, then the embedding stage (whose rel-pos tables, patch embedding and LayerNorms are registered AFTER
+    encoder.layer.*), and the decoder's held dW1 GEMM completes only when the backward ends (engine.LATE_PARAMS).  The
+    first synchronised step therefore runs with one chunk and records the arrival order; rank 0's order is broadcast and
+    the buffer is re-laid-out: arrival order, parameters that never reported next, late parameters last.  From the
+    second step on the chunks follow the stages (about four chunks of 64 MB for the 254 MB of LayoutLMv3-base in bf16).
+
+    Wire precision: "bf16" (default on RCCL) halves the bytes; the ranks' gradients are then SUMMED in bf16 by the
+    collective (relative error of an 8-rank sum <= 2^-8 * log2(8) per element, tested), "fp32" (PENEO_DP_WIRE=fp32) sums
+    exactly like the reference's DistributedDataParallel.  `module`, `no_sync()` and the initial parameter broadcast
+    follow DistributedDataParallel."""
+
+    def __init__(self, module: torch.nn.Module, compress: str = "bf16", chunk_mb: Optional[float] = None,
+                 wire_dtype: Optional[torch.dtype] = None):
         super().__init__()
         self.module = module
         self.world = dist.get_world_size()
         self.params = [p for p in module.parameters() if p.requires_grad]
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         dev = self.params[0].device
+        compress = os.environ.get("PENEO_DP_WIRE", compress)
         wire = torch.bfloat16 if (compress == "bf16" and dev.type == "cuda" and dist.get_backend() == "nccl") else torch.float32
-        offs, total = [], 0
-        for p in self.params:
-            offs.append(total)
-            total += (p.numel() + 7) // 8 * 8
-        self.flat = torch.zeros(total, dtype=wire, device=dev)
-        self.views = [self.flat[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, offs)]
+        if wire_dtype is not None:                   # tests: the bf16 wire format on a backend that would default to fp32
+            wire = wire_dtype
+        self.flat = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p in self.params), dtype=wire, device=dev)
+        # PENEO_DP_CHUNKS=1: one all-reduce after the backward (no overlap); otherwise chunks of PENEO_DP_CHUNK_MB wire bytes
+        self.overlap = os.environ.get("PENEO_DP_CHUNKS", "") != "1"
+        self.chunk_bytes = int(float(os.environ.get("PENEO_DP_CHUNK_MB", chunk_mb if chunk_mb is not None else 64)) * (1 << 20))
         self.require_sync = True
         self._armed = False
-        self.sync_calls = 0                          # all-reduces issued so far (tests)
-        # Optional overlap (PENEO_DP_CHUNKS=2, off by default: it cannot be measured on one GPU).  The upper half of the flat
-        # buffer (by bytes; mostly the decoder and the upper encoder layers) is packed and all-reduced asynchronously while
-        # the backward of the rest is still running.  Gradient arrival order is NOT parameter order (the embedding-stage
-        # parameters registered after encoder.layer.* get theirs last; the order inside one stage is undefined), so the
-        # early collective starts only when EVERY upper-half parameter has reported its gradient this step (counted
-        # post-accumulate hooks); parameters that report late, or never, are handled by the fall-back in sync_gradients.
-        self._split = None
-        self._early = None
-        self.early_calls = 0
-        self._upper_ids = set()
-        chunks = int(os.environ.get("PENEO_DP_CHUNKS", "1"))
-        if chunks >= 2 and len(self.params) >= 2:
-            half, acc, split = total // 2, 0, len(self.params) - 1
-            for i in range(len(self.params) - 1, 0, -1):
-                acc += self.params[i].numel()
-                if acc >= half:
-                    split = i
-                    break
-            self._split = max(1, split)
-            self._split_off = offs[self._split]
-            for p in self.params[self._split:]:
-                p.register_post_accumulate_grad_hook(self._upper_grad_ready)
+        self._learned = not self.overlap            # False until the arrival order of one step has been recorded
+        self._arrival: List[int] = []
+        self._works: list = []
+        self._next = 0                               # next chunk to go on the wire
+        self.sync_calls = 0                          # synchronised steps so far (tests)
+        self.early_calls = 0                         # chunks that went on the wire before the backward had ended (tests)
+        self._layout(list(range(len(self.params))), chunked=False)
+        if self.overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._grad_ready)
+            try:
+                from .model import engine
+                engine.TRUSTED_GRAD_HOOKS[0] = True  # these hooks join the side streams before they read a gradient
+            except Exception:
+                pass
         with torch.no_grad():                       # every rank starts from rank 0's parameters and buffers
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0)
         _invalidate_working_weights()
+
+    # ---- layout -------------------------------------------------------------------------------------------------------
+    def _layout(self, order: List[int], chunked: bool, n_tail: int = 0) -> None:
+        """Views of the flat buffer in `order`; chunk boundaries at ~chunk_bytes.  The last `n_tail` parameters of `order`
+        (late / never reported) always share the final chunk."""
+        esz = self.flat.element_size()
+        self.order = list(order)
+        self.views: List[Optional[torch.Tensor]] = [None] * len(self.params)
+        offs, off = {}, 0
+        for i in order:
+            p = self.params[i]
+            offs[i] = off
+            self.views[i] = self.flat[off:off + p.numel()].view(p.shape)
+            off += (p.numel() + 7) // 8 * 8
+        self.chunks: List[tuple] = []                # (parameter indices, first element, one past the last element)
+        if not chunked or len(order) < 2:
+            self.chunks = [(list(order), 0, off)]
+        else:
+            cur, lo = [], 0
+            body = order[:len(order) - n_tail] if n_tail else order
+            for i in body:
+                cur.append(i)
+                hi = offs[i] + (self.params[i].numel() + 7) // 8 * 8
+                if (hi - lo) * esz >= self.chunk_bytes:
+                    self.chunks.append((cur, lo, hi))
+                    cur, lo = [], hi
+            tail = cur + (order[len(order) - n_tail:] if n_tail else [])
+            if tail:
+                # a small remainder rides with the previous chunk unless it carries the late parameters' tail
+                if self.chunks and not n_tail and (off - lo) * esz < self.chunk_bytes // 2:
+                    pc, plo, _ = self.chunks.pop()
+                    self.chunks.append((pc + tail, plo, off))
+                else:
+                    self.chunks.append((tail, lo, off))
+        self._chunk_of = [0] * len(self.params)
+        for c, (idxs, _, _) in enumerate(self.chunks):
+            for i in idxs:
+                self._chunk_of[i] = c
+        self._reset_counts()
+
+    def _reset_counts(self) -> None:
+        self._remaining = [len(idxs) for idxs, _, _ in self.chunks]
+        self._seen = bytearray(len(self.params))
+        self._next = 0
+
+    def _relayout_from_arrival(self) -> None:
+        """After the first synchronised step: rank 0's arrival order becomes everybody's layout."""
+        late = set()
+        try:
+            from .model import engine
+            late = {self._index[i] for i in engine.LATE_PARAMS if i in self._index}
+        except Exception:
+            pass
+        seen = set(self._arrival)
+        early = [i for i in self._arrival if i not in late]
+        never = [i for i in range(len(self.params)) if i not in seen and i not in late]
+        tail = never + [i for i in range(len(self.params)) if i in late]
+        order = torch.tensor(early + tail + [len(tail)], dtype=torch.int64, device=self.flat.device)
+        dist.broadcast(order, 0)
+        order = order.tolist()
+        n_tail = order.pop()
+        assert sorted(order) == list(range(len(self.params)))
+        self._layout(order, chunked=True, n_tail=n_tail)
+        self._learned = True
 
     def no_sync(self):
         import contextlib
@@ -115,62 +188,79 @@ class FlatGradDataParallel(torch.nn.Module):
     def _backward_started(self, grad):
         if not self._armed:
             self._armed = True
+            self._reset_counts()
+            self._arrival = []
             torch.autograd.Variable._execution_engine.queue_callback(self.sync_gradients)
         return grad
 
-    def _pack(self, lo: int, hi: int) -> None:
-        _join_side_streams()                        # gradients may still be in flight on the model's side streams
-        have = [(p, v) for p, v in zip(self.params[lo:hi], self.views[lo:hi]) if p.grad is not None]
-        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
-            if p.grad is None:
-                v.zero_()
-        if have:
-            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+    # ---- the step -----------------------------------------------------------------------------------------------------
+    def _pack(self, c: int, final: bool) -> None:
+        # gradients may still be in flight on the model's side streams; an early chunk must not wait for the HELD work
+        # (the decoder's dW1 GEMM runs beside the whole encoder backward and only the last chunk contains its output)
+        _join_side_streams(held=final)
+        idxs = self.chunks[c][0]
+        src, dst = [], []
+        for i in idxs:
+            g = self.params[i].grad
+            if g is None:
+                self.views[i].zero_()
+            else:
+                src.append(g)
+                dst.append(self.views[i])
+        if dst:
+            torch._foreach_copy_(dst, src)
 
-    def _upper_grad_ready(self, param) -> None:
-        if not (self._armed and self.require_sync) or self._early is not None:
+    def _launch(self, c: int, final: bool) -> None:
+        self._pack(c, final)
+        _, lo, hi = self.chunks[c]
+        self._works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+        self._next = c + 1
+
+    def _grad_ready(self, param) -> None:
+        if not (self._armed and self.require_sync):
             return
-        if id(param) in self._upper_ids:             # a second accumulation into the same parameter: counted once
+        i = self._index[id(param)]
+        if self._seen[i]:
             return
-        self._upper_ids.add(id(param))
-        if len(self._upper_ids) == len(self.params) - self._split:
-            self._pack(self._split, len(self.params))
-            self._early = dist.all_reduce(self.flat[self._split_off:], async_op=True)
+        self._seen[i] = 1
+        if not self._learned:
+            self._arrival.append(i)
+            return
+        c = self._chunk_of[i]
+        self._remaining[c] -= 1
+        # collectives are issued in chunk order on every rank; the last chunk always waits for the end of the backward
+        while self._next < len(self.chunks) - 1 and self._remaining[self._next] == 0:
+            self._launch(self._next, final=False)
             self.early_calls += 1
 
     def sync_gradients(self) -> None:
         """Average the gradients over the ranks (runs by itself at the end of backward())."""
         self._armed = False
         self.sync_calls += 1
-        self._upper_ids.clear()
-        have = [(p, v) for p, v in zip(self.params, self.views) if p.grad is not None]
-        if self._split is not None:
-            if self._early is None:                  # the hook did not fire on this rank: same two collectives, same order
-                self._pack(self._split, len(self.params))
-                self._early = dist.all_reduce(self.flat[self._split_off:], async_op=True)
-            self._pack(0, self._split)               # the upper half is already on the wire
-            dist.all_reduce(self.flat[:self._split_off])
-            self._early.wait()
-            self._early = None
-        else:
-            self._pack(0, len(self.params))
-            dist.all_reduce(self.flat)
+        have = [i for i, p in enumerate(self.params) if p.grad is not None]
+        while self._next < len(self.chunks):
+            self._launch(self._next, final=True)
+        for w in self._works:
+            w.wait()
+        self._works = []
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)         # one pass over the wire buffer (half the bytes of the fp32 gradients)
         if have:
-            torch._foreach_copy_([p.grad for p, _ in have], [v for _, v in have])
-        for p, v in zip(self.params, self.views):
+            torch._foreach_copy_([self.params[i].grad for i in have], [self.views[i] for i in have])
+        for i, p in enumerate(self.params):
             if p.grad is None:                       # unused on this rank, used elsewhere
-                p.grad = v.to(torch.float32)
+                p.grad = self.views[i].to(torch.float32)
+        if not self._learned:
+            self._relayout_from_arrival()
 
 
-def _join_side_streams() -> None:
+def _join_side_streams(held: bool = True) -> None:
     try:
         from .model.engine import join_pending
     except Exception:
         return
     if torch.cuda.is_available():
-        join_pending()
+        join_pending(held=held)
 
 
 def _invalidate_working_weights() -> None:

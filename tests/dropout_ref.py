@@ -1,0 +1,43 @@
+"""Host restatement (numpy, 64-bit arithmetic masked to 32 bits) of the counter-based mask of the classifier dropout
+(peneo_amd/csrc/common.h: pair_drop_key / pair_drop_words): keep(b, p, n) for document b, packed pair index p, hidden
+column n of the [B, P, nh * D] classifier hidden (model/peneo_decoder.py:261).  Test infrastructure."""
+import numpy as np
+import torch
+
+_M = np.uint64(0xFFFFFFFF)
+_u = np.uint64
+
+
+def _mix32(x):
+    x = x.astype(np.uint64)
+    x ^= x >> _u(16); x = (x * _u(0x7FEB352D)) & _M; x ^= x >> _u(15); x = (x * _u(0x846CA68B)) & _M; x ^= x >> _u(16)
+    return x
+
+
+def _mul24(a, k):
+    return ((a & _u(0xFFFFFF)) * _u(k)) & _M
+
+
+def k12_threshold(p: float) -> int:
+    return int(p * 65536.0 + 0.5) if p > 0 else 0
+
+
+def k12_scale(p: float) -> float:
+    t = k12_threshold(p)
+    return 65536.0 / (65536.0 - t) if t else 1.0
+
+
+def k12_keep(seed: int, b: int, p0: int, p1: int, ncol: int, p: float) -> torch.Tensor:
+    """bool [p1 - p0, ncol]: True where the hidden unit is kept."""
+    thr = k12_threshold(p)
+    if thr == 0:
+        return torch.ones((p1 - p0, ncol), dtype=torch.bool)
+    key = _mix32(np.array([(seed ^ (((b + 1) * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF], dtype=np.uint64))[0]
+    pp = np.arange(p0, p1, dtype=np.uint64)[:, None]
+    g = np.arange(ncol // 4, dtype=np.uint64)[None, :]
+    x = ((pp * _u(ncol // 4) + g) & _M) ^ key
+    x ^= x >> _u(16); x = _mul24(x, 0x9E3779); x ^= x >> _u(13); x = _mul24(x, 0x85EBCB); x ^= x >> _u(16)
+    w0 = x
+    w1 = _mul24(w0 ^ (w0 >> _u(11)), 0xC2B2AF) ^ (w0 >> _u(9))
+    f = np.stack([w0 & _u(0xFFFF), w0 >> _u(16), w1 & _u(0xFFFF), w1 >> _u(16)], -1).reshape(p1 - p0, ncol)
+    return torch.from_numpy(f >= thr)

@@ -241,6 +241,132 @@ def test_full_width_shapes_match_the_oracle(which):
             assert torch.isfinite(p.grad).all(), n
 
 
+def _grad_agreement(m, batch, ref_dtype=torch.float32):
+    """(loss_ref, loss_bf16, {name: (cosine, norm ratio)}) of the default bf16 path against the fp32 path of the same model."""
+    res = {}
+    for dt in (ref_dtype, torch.bfloat16):
+        m.set_compute_dtype(dt)
+        for p in m.parameters():
+            p.grad = None
+        out = m(**batch)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[dt] = (float(out["loss"]), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    stats = {}
+    for n, g in res[ref_dtype][1].items():
+        a, r = res[torch.bfloat16][1][n].double().flatten(), g.double().flatten()
+        stats[n] = (float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300)), float(a.norm() / (r.norm() + 1e-300)), float(r.norm()))
+    return res[ref_dtype][0], res[torch.bfloat16][0], stats
+
+
+def test_bf16_path_matches_fp32_path_at_the_benchmark_size():
+    """BASELINE config 2 exactly as bench.py runs it (LayoutLMv3-base, B = 8 documents, S = 512, N = 511, bf16; dropout off):
+    every parameter gradient of the default bf16 path -- fused pair backward (8 448 blocks, the 256-slot workspace wrapped
+    33x) with the held side-stream dW1 GEMM, single-pass attention backward at T = 709 / 576 workgroups, the bf16 dS^T-slab
+    rel-pos reduction over 12 layers, LDS-DMA GEMMs -- against the fp32 path of the same model, which
+    test_base_s512_matches_reference_golden pins to the reference.  (reference: model/peneo_decoder.py:349-428,
+    modeling_layoutlmv3.py:365-404)"""
+    from seeded import layoutlmv3_config, peneo_config, seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
+    m = build_model(pcfg)
+    seeded_fill_(m.state_dict(), 11)
+    m = m.eval()
+    batch = to_cuda(synthetic_rfund_batch(8, 512, 128, pcfg["backbone_config"]["vocab_size"], seed=1008))
+    l32, l16, stats = _grad_agreement(m, batch)
+    assert abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
+    gmax = max(v[2] for v in stats.values())
+    bad = {n: v[:2] for n, v in stats.items() if v[2] > 1e-6 * gmax and (v[0] < 0.995 or abs(v[1] - 1) > 0.02)}
+    assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:12]
+    # and the bf16 step is repeatable: a second backward gives the same dz-derived gradients up to atomic ordering
+    l16b, _, _ = _grad_agreement(m, batch, ref_dtype=torch.bfloat16)
+    assert abs(l16b - l16) < 1e-6 * abs(l16)
+
+
+def test_large_full_depth_bf16_path_matches_fp32_path():
+    """BASELINE config 4 at full depth: LayoutLMv3-large (24 layers, H = 1024, 16 heads), S = 1024, N = 1023, D = 512, B = 2.
+    The CPU oracle is too slow at this depth (its one-layer slice is test_full_width_shapes_match_the_oracle); here the bf16
+    path is held to the fp32 path of the same model."""
+    from seeded import layoutlmv3_config, peneo_config, seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("large"))
+    m = build_model(pcfg)
+    seeded_fill_(m.state_dict(), 12)
+    m = m.eval()
+    batch = to_cuda(synthetic_rfund_batch(2, 1024, 256, pcfg["backbone_config"]["vocab_size"], seed=2004))
+    l32, l16, stats = _grad_agreement(m, batch)
+    assert abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
+    gmax = max(v[2] for v in stats.values())
+    bad = {n: v[:2] for n, v in stats.items() if v[2] > 1e-6 * gmax and (v[0] < 0.99 or abs(v[1] - 1) > 0.03)}
+    assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:12]
+
+
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
+def test_train_mode_masks_are_the_same_function_in_both_precisions(name):
+    """Train mode (every dropout site active, incl. the classifier dropout inside the pair kernels): all masks are pure
+    functions of (seed, element index), so the fp32 path (chunked decoder backward, stand-alone dz kernel, two-kernel
+    attention backward) and the bf16 path (fused kernels) of ONE model see the same masks when the seed counters are
+    reset -- losses and gradients must then agree to bf16 accuracy, and differ clearly from the eval-mode ones."""
+    from peneo_amd.model.engine import DropoutSeeds
+    fx = load_golden(name)
+    b = to_cuda(fx["batch"])
+    m = build_model(fx["config"], fx["state_dict"]).train()
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m.set_compute_dtype(dt)
+        DropoutSeeds._step, m._step = 1000, 1000
+        for p in m.parameters():
+            p.grad = None
+        out = m(**b)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[dt] = (float(out["loss"]), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    l32, l16 = res[torch.float32][0], res[torch.bfloat16][0]
+    assert abs(l16 - l32) < 3e-2 * abs(l32), (l16, l32)
+    assert abs(l32 - float(fx["outputs"]["loss"])) > 1e-3 * abs(l32)          # dropout really was on
+    bad = []
+    for n, g in res[torch.float32][1].items():
+        a, r = res[torch.bfloat16][1][n].double().flatten(), g.double().flatten()
+        if float(r.norm()) < 1e-7:
+            continue
+        cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300))
+        if cos < 0.97:
+            bad.append((n, cos))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
+def test_deferred_joins_do_not_change_the_gradients(name):
+    """The side-stream joins deferred by one stage (engine.defer_join) against immediate joins: only the PLACE of a stream
+    wait differs, so every gradient that is bit-reproducible run to run must be bit-identical between the two settings
+    (a clone of a bias gradient racing the side stream's column sums would show here), the rest equal to fp32 rounding."""
+    import peneo_amd.model.engine as E
+    fx = load_golden(name)
+    b = to_cuda(fx["batch"])
+    m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        m(**b)["loss"].backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    a1, a2 = run(), run()
+    stable = {n for n in a1 if torch.equal(a1[n], a2[n])}
+    assert len(stable) > len(a1) // 2
+    E.DEFER_ALLOWED[0] = False
+    try:
+        c = run()
+    finally:
+        E.DEFER_ALLOWED[0] = True
+    for n in a1:
+        if n in stable:
+            assert torch.equal(c[n], a1[n]), n
+        else:
+            assert maxdiff(c[n], a1[n]) <= 1e-3 * float(a1[n].abs().max()) + 1e-9, n
+
+
 def test_fused_adamw_training_steps_reduce_the_loss():
     """Three optimizer steps on one batch with the reference's parameter groups: the C-ABI update must invalidate the
     working-precision weight copies (loss changes and goes down)."""
@@ -259,13 +385,13 @@ def test_fused_adamw_training_steps_reduce_the_loss():
     assert losses[1] < losses[0] and losses[3] < losses[1], losses
 
 
-@pytest.mark.parametrize("env", [{"PENEO_ENC_SPLIT": "2"}, {"PENEO_WGRAD_STREAM": "0"}, {"PENEO_BWD_CHUNK_PAIRS": "300", "PENEO_DEC_STREAMS": "3"},
-                                 {"PENEO_DZ_FUSED": "0"}, {"PENEO_DZ_X_SIDE": "1", "PENEO_DZ_DW_MAIN": "0", "PENEO_BWD_CHUNK_PAIRS": "300"},
-                                 {"PENEO_DZF_PIPE": "0", "PENEO_DZ_X_SIDE": "1", "PENEO_DZ_WRITES_X": "0"}, {"PENEO_DZ_WRITES_X": "1"}, {"PENEO_WGRAD_GROUP": "1"}, {"PENEO_ENC_GROUPS": "1,1"}])
+@pytest.mark.parametrize("env", [{"PENEO_WGRAD_STREAM": "0"}, {"PENEO_BWD_FUSED": "0", "PENEO_BWD_CHUNK_PAIRS": "300"},
+                                 {"PENEO_BWD_FUSED": "0", "PENEO_DZ_FUSED": "0"}, {"PENEO_DEFER_JOIN": "0", "PENEO_DW1_HOLD": "0"},
+                                 {"PENEO_DW1_SIDE": "0"}, {"PENEO_LN_PARTIALS": "1", "PENEO_WGRAD_LATE": "0"}])
 def test_optional_execution_modes_keep_the_gradients(env):
-    """Stream / chunking options (document-group streams through the encoder, weight gradients on the main stream, small
-    decoder-backward chunks on three streams) are read at import time: run the bf16 gradient check of the tiny golden in a
-    subprocess per setting."""
+    """The remaining stream / chunking options (weight gradients on the main stream, the chunked decoder backward with and
+    without the fused dz kernel, immediate joins, dW1 on the main stream) are read at construction time: run the bf16
+    gradient check of the tiny golden in a subprocess per setting."""
     import os, subprocess, sys
     code = """
 import sys, torch
@@ -293,12 +419,13 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("chunks", ["1", "2"])
+@pytest.mark.parametrize("chunks", ["1", "many"])
 def test_flat_grad_data_parallel_over_rccl_world_of_one(chunks):
     """The data-parallel wrapper on the real backend (RCCL) with a single rank: gradients pass through the bf16 wire buffer
-    and the all-reduce unchanged up to bf16 rounding, on two consecutive steps.  chunks = 2: the early all-reduce of the
-    upper half must not lose the gradients that arrive last (rel-pos tables, patch embedding, the embedding LayerNorms are
-    registered after encoder.layer.* but get their gradients from the last backward stage)."""
+    and the all-reduce unchanged up to bf16 rounding, on three consecutive steps.  chunks = many (the default mode, with
+    a chunk size that cuts the tiny model into several): step 1 learns the arrival order, steps 2 and 3 put chunks on the
+    wire DURING the backward; the layout must end with the embedding stage and the held dW1 weights, and no gradient that
+    arrives late (rel-pos tables, patch embedding, embedding LayerNorms; dW1 completes at the end of the backward) may be lost."""
     import os, subprocess, sys
     code = """
 import os, sys, torch
@@ -323,27 +450,102 @@ def grads(net):
 ref = grads(m)
 net = wrap_data_parallel(m, device_ids=[0])
 assert isinstance(net, FlatGradDataParallel) and net.flat.dtype == torch.bfloat16
-if os.environ.get("PENEO_DP_CHUNKS") == "2":
-    names = [n for n, p in m.named_parameters() if p.requires_grad]
-    assert net._split is not None and any("rel_pos" in n or "patch_embed" in n for n in names[net._split:])
-for step in range(2):
+for step in range(3):
     got = grads(net)
     assert set(got) == set(ref)
     for n in ref:
         err = float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12))
         assert err < 1e-2, (step, n, err)
         assert float(ref[n].abs().max()) == 0 or float(got[n].abs().max()) > 0, n
-assert net.sync_calls == 2, net.sync_calls        # armed from the PEneoOutput fields, once per backward
+assert net.sync_calls == 3, net.sync_calls        # armed from the PEneoOutput fields, once per backward
+if os.environ.get("PENEO_DP_CHUNKS") != "1":
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    order = [names[i] for i in net.order]
+    assert len(net.chunks) >= 3, [len(c[0]) for c in net.chunks]
+    assert net.early_calls == 2 * (len(net.chunks) - 1), (net.early_calls, len(net.chunks))
+    first_layer = min(i for i, n in enumerate(order) if ".encoder.layer." in n)
+    last_layer = max(i for i, n in enumerate(order) if ".encoder.layer." in n)
+    dec_early = [i for i, n in enumerate(order) if "peneo_decoder" in n and not n.endswith("_fc.0.weight")]
+    late = [i for i, n in enumerate(order) if n.endswith("_fc.0.weight")]
+    emb = [i for i, n in enumerate(order) if "embeddings" in n or "rel_pos" in n or "patch_embed" in n]
+    assert max(dec_early) < first_layer and min(emb) > last_layer and min(late) > max(emb), order
+    lay = [int(n.split(".encoder.layer.")[1].split(".")[0]) for n in order if ".encoder.layer." in n]
+    assert lay == sorted(lay, reverse=True), lay            # layers in the order the backward visits them
 with net.no_sync():
     got = grads(net)
-assert net.sync_calls == 2
+assert net.sync_calls == 3
 assert all(float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12)) < 5e-4 for n in ref)   # no wire round trip (fp32 atomics reorder sums)
 dist.destroy_process_group()
 print("ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PENEO_DP_CHUNKS=chunks), capture_output=True,
-                       text=True, timeout=300)
+    env = dict(os.environ, PENEO_DP_CHUNKS="1") if chunks == "1" else dict(os.environ, PENEO_DP_CHUNK_MB="0.03")
+    env.pop("PENEO_DP_CHUNKS", None) if chunks != "1" else None
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_data_parallel_two_processes_on_one_gpu_match_a_single_process(tmp_path):
+    """Two FRESH child processes (gloo, both on GPU 0) run the real tiny PEneoModel (bf16 HIP path) behind the flat
+    data-parallel wrapper on their shards of a 4-document batch for three steps; the averaged gradients every rank ends up
+    with must equal the mean of the two shards' gradients computed by ONE process without any wrapper
+    (reference: torchrun + DDP, README.md:206-218)."""
+    import os, subprocess, sys
+    root, here = os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))
+    child = """
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_golden
+from peneo_amd.model import PEneoConfig, PEneoModel
+from peneo_amd.parallel import init_distributed, shard_documents, wrap_data_parallel
+from peneo_amd.data import synthetic_rfund_batch
+rank, local, world = init_distributed()
+torch.cuda.set_device(local)
+fx = load_golden("lmv3_tiny")
+m = PEneoModel(PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"}))
+m.load_state_dict(fx["state_dict"], strict=True)
+m = m.cuda().set_compute_dtype(torch.bfloat16).eval()
+full = synthetic_rfund_batch(4, 40, 8, fx["config"]["backbone_config"]["vocab_size"], seed=11, ragged=True)
+def shard(r, w):
+    idx = list(shard_documents(4, r, w))
+    return {k: v[idx].cuda() for k, v in full.items()}
+if world == 1:                                   # the single-process reference: mean of the shards' gradients
+    acc = {}
+    for r in range(2):
+        for p in m.parameters(): p.grad = None
+        m(**shard(r, 2))["loss"].backward()
+        for n, p in m.named_parameters():
+            acc[n] = acc.get(n, 0) + p.grad.float() / 2
+    torch.save({n: g.cpu() for n, g in acc.items()}, sys.argv[1])
+else:
+    net = wrap_data_parallel(m, device_ids=[local])
+    for step in range(3):
+        for p in m.parameters(): p.grad = None
+        net(**shard(rank, world))["loss"].backward()
+    torch.cuda.synchronize()
+    torch.save({"grads": {n: p.grad.float().cpu() for n, p in m.named_parameters()}, "chunks": len(net.chunks),
+                "early": net.early_calls}, sys.argv[1] + str(rank))
+    torch.distributed.destroy_process_group()
+print("ok")
+""" % (root, here)
+    script = tmp_path / "child.py"
+    script.write_text(child)
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", PENEO_DIST_BACKEND="gloo", PENEO_DEVICE="0",
+                GPU_MAX_HW_QUEUES="8", PENEO_DP_CHUNK_MB="0.05")
+    ref_file, out = str(tmp_path / "ref.pt"), str(tmp_path / "rank")
+    r = subprocess.run([sys.executable, str(script), ref_file], env=dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    procs = [subprocess.Popen([sys.executable, str(script), out], env=dict(base, WORLD_SIZE="2", RANK=str(k), LOCAL_RANK=str(k)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    ref = torch.load(ref_file)
+    for k in range(2):
+        got = torch.load(out + str(k))
+        assert got["chunks"] >= 2 and got["early"] >= 2, (got["chunks"], got["early"])
+        for n, g in ref.items():
+            err = float((got["grads"][n] - g).abs().max() / g.abs().max().clamp_min(1e-12))
+            assert err < 5e-3, (k, n, err)      # fp32 wire on gloo: only the side-stream / atomic summation order differs
 
 
 def test_fused_adamw_resumes_from_state_dict_and_from_torch_adamw():

@@ -33,9 +33,9 @@ def test_struct_layouts_match_the_header_sizes():
     from peneo_amd import hip
     # spot checks of the by-value / by-pointer structs shared with C (natural alignment on x86-64)
     assert ctypes.sizeof(hip.GemmEpilogue) == 104
-    assert ctypes.sizeof(hip.PairHeadsDesc) == 8 + 4 * 8 + 3 * 8
+    assert ctypes.sizeof(hip.PairHeadsDesc) == 8 + 4 * 8 + 3 * 8 + 8
     assert ctypes.sizeof(hip.PairLoss) == 8 * 8 * 2 + 8 + 8 * 8
-    assert ctypes.sizeof(hip.PairDzArgs) == 8 + 4 * 8 + 8 * 8 * 2 + 8
+    assert ctypes.sizeof(hip.PairDzArgs) == 8 + 4 * 8 + 8 * 8 * 2 + 8 + 16 + 8
 
 
 def test_no_cpu_fallback():
@@ -106,6 +106,53 @@ def test_model_save_and_from_pretrained_roundtrip(tmp_path):
     assert all(torch.equal(a[k], b[k]) for k in a)
     # decoder parameters keep the prefix the reference's optimizer groups key on (pipeline/trainer.py:280-284)
     assert sum(1 for n, _ in back.named_parameters() if "peneo_decoder" in n) == 26
+
+
+def test_backbone_from_checkpoint_path(tmp_path, caplog):
+    """``PEneoModel(config, backbone_name_or_path=dir)`` (reference model/modeling_peneo.py:58-79): backbone weights come
+    from the checkpoint directory (HF layout, keys prefixed ``layoutlmv3.``), ``config.backbone_config`` is filled from
+    its config.json when absent, the decoder is freshly initialised, and a path that cannot be read raises OSError (the
+    reference's hub fallback needs the network) instead of training from random weights."""
+    import json
+    from safetensors.torch import save_file
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    fx = load_golden("lmv3_tiny")
+    full = {k: v for k, v in fx["config"].items() if k != "model_type"}
+    bb = {k[len("backbone."):]: v for k, v in fx["state_dict"].items() if k.startswith("backbone.")}
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_file({"layoutlmv3." + k: v.contiguous() for k, v in bb.items() if v.dtype.is_floating_point}, str(ck / "model.safetensors"))
+    json.dump(dict(full["backbone_config"], model_type="layoutlmv3", architectures=["LayoutLMv3Model"]), open(ck / "config.json", "w"))
+    for given in (None, full["backbone_config"]):
+        cfg = PEneoConfig(**dict(full, backbone_config=given))
+        m = PEneoModel(cfg, backbone_name_or_path=str(ck))
+        sd = m.backbone.state_dict()
+        assert all(torch.equal(sd[k], v) for k, v in bb.items() if v.dtype.is_floating_point)
+        assert cfg.backbone_config["hidden_size"] == full["backbone_config"]["hidden_size"]
+        w = m.peneo_decoder.line_extraction_fc[0].weight
+        assert 0.01 < float(w.std()) < 0.03 and float(m.peneo_decoder.line_extraction_fc[0].bias.abs().max()) == 0.0
+    for bad in (str(tmp_path / "nowhere"), "auto"):
+        with pytest.raises(OSError):
+            PEneoModel(PEneoConfig(**full), backbone_name_or_path=bad)
+
+
+def test_init_weights_rule():
+    """Reference rule (modeling_layoutlmv3.py:260-274 via model/modeling_peneo.py:105-106): Linear / Embedding N(0, 0.02),
+    biases and the padding row zero, LayerNorm (1, 0)."""
+    from peneo_amd.model import PEneoConfig, PEneoModel
+    fx = load_golden("lmv3_tiny")
+    torch.manual_seed(1)
+    m = PEneoModel(PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"}))
+    e = m.backbone.embeddings
+    assert float(e.word_embeddings.weight[e.word_embeddings.padding_idx].abs().max()) == 0.0
+    assert abs(float(e.word_embeddings.weight.std()) - 0.02) < 0.003
+    lyr = m.backbone.encoder.layer[0]
+    assert abs(float(lyr.intermediate.dense.weight.std()) - 0.02) < 0.003 and float(lyr.intermediate.dense.bias.abs().max()) == 0.0
+    ln = lyr.output.LayerNorm
+    assert torch.equal(ln.weight, torch.ones_like(ln.weight)) and torch.equal(ln.bias, torch.zeros_like(ln.bias))
+    for name in ("line_extraction_fc", "ent_linking_h2h_fc"):
+        fc = getattr(m.peneo_decoder, name)
+        assert abs(float(fc[0].weight.std()) - 0.02) < 0.004 and float(fc[3].bias.abs().max()) == 0.0
 
 
 def test_tagging_scheme_matches_oracle():
