@@ -99,11 +99,6 @@ template <int KS> constexpr int pb_chunk_count(int j) { int n = 0; for (int f = 
 template <int KS> constexpr int pb_chunk_first(int j) { for (int f = 0; f < KS; ++f) if (f * 8 / KS == j) return f; return KS; }
 constexpr int PB_MAXC = 3;   // fragments per chunk (KS = 24)
 
-// v_writelane_b32: lane LANE of `v` receives the wave-uniform `s` (no builtin that compiles in the host pass)
-template <int LANE> __device__ __forceinline__ void pb_writelane(uint32_t& v, uint32_t s) {
-  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(s)), "n"(LANE));
-}
-
 #ifndef PB_DBG
 #define PB_DBG 0      // tools/ab_pb_dbg.sh: 65536 = packed-fp32 dz arithmetic in the wave-specialised kernel (reproduces the corruption)
 #endif
@@ -375,7 +370,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       // K12 dropout: this lane's hidden unit, one keep bit per pair of the group (written by the consumer waves one iteration
       // ago); shifted so that register r0's pair (rowc + 4 half) sits at the compile-time position rowc
       uint32_t mws = 0xffffffffu;
-      if constexpr (DOE && DROP) mws = sMask[((s & 1) * 4 + grp) * 32 + r32] >> (4 * half);
+      if constexpr (DOE && DROP) mws = sMask[((s & 1) * 4 + grp) * 32 + 2 * (r32 & 15) + (r32 >> 4)] >> (4 * half);
       const f2 b1 = f2{cw.w, cw.w};
       // dy[pair, hid] = sum_c g[pair, c] W2[c, hid] on the matrix cores: B operand = this lane's column of W2 (k = class:
       // lanes 0-31 hold (w0, w1, w2, 0 ...), lanes 32-63 the zero half), same accumulator layout as z
@@ -514,23 +509,23 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       if constexpr (DROP) {
         // keep bits of slab s + 1 for the producers' E(s + 1): lane = (pair r32 of the group, hidden units 16 half .. + 15) =
         // four word pairs of the forward's hash; a compare yields the 64-lane ballot = [pairs of unit k | pairs of unit 16 + k],
-        // i.e. the producers' words (bit = pair) for free; lane L keeps word L and stores it
+        // i.e. the producers' words (bit = pair) for free
         if (s + 1 < nslab) {
-          uint32_t mine = 0u;
-          auto quad = [&](auto qc) {
-            constexpr int q = decltype(qc)::value;
+          // word pair u = (unit u | unit 16 + u) of the slab, written by lane 0 straight from the ballot's scalar registers
+          // (v_writelane of a compare result needs wait states the compiler does not see inside inline asm: measured wrong
+          // words for a few units)
+          uint2* mw = reinterpret_cast<uint2*>(sMask + (((s + 1) & 1) * 4 + grp) * 32);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
             uint32_t w0, w1;
             pair_drop_words(drop_key, drop_base + (uint32_t)((s + 1) * 8 + q), w0, w1);
             const unsigned long long k0 = __ballot((w0 & 0xffffu) >= p.drop_thr16), k1 = __ballot((w0 >> 16) >= p.drop_thr16);
             const unsigned long long k2 = __ballot((w1 & 0xffffu) >= p.drop_thr16), k3 = __ballot((w1 >> 16) >= p.drop_thr16);
-            pb_writelane<4 * q + 0>(mine, (uint32_t)k0); pb_writelane<16 + 4 * q + 0>(mine, (uint32_t)(k0 >> 32));
-            pb_writelane<4 * q + 1>(mine, (uint32_t)k1); pb_writelane<16 + 4 * q + 1>(mine, (uint32_t)(k1 >> 32));
-            pb_writelane<4 * q + 2>(mine, (uint32_t)k2); pb_writelane<16 + 4 * q + 2>(mine, (uint32_t)(k2 >> 32));
-            pb_writelane<4 * q + 3>(mine, (uint32_t)k3); pb_writelane<16 + 4 * q + 3>(mine, (uint32_t)(k3 >> 32));
-          };
-          quad(std::integral_constant<int, 0>{}); quad(std::integral_constant<int, 1>{});
-          quad(std::integral_constant<int, 2>{}); quad(std::integral_constant<int, 3>{});
-          if (lane < 32) sMask[(((s + 1) & 1) * 4 + grp) * 32 + lane] = mine;
+            if (lane == 0) {
+              mw[4 * q + 0] = make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)); mw[4 * q + 1] = make_uint2((uint32_t)k1, (uint32_t)(k1 >> 32));
+              mw[4 * q + 2] = make_uint2((uint32_t)k2, (uint32_t)(k2 >> 32)); mw[4 * q + 3] = make_uint2((uint32_t)k3, (uint32_t)(k3 >> 32));
+            }
+          }
         }
       }
       if (s < 1) dma_iter(s);

@@ -647,7 +647,7 @@ def test_pair_heads_fwd_classifier_dropout(ops, dtype, N, D):
     plain, _, _ = ops.pair_heads_fwd(ab, wp, torch.cat(b1), torch.cat(b2), classes)
     for h in range(5):
         assert rel_err(logits[h], ref[h]) < tol(dtype), (h, rel_err(logits[h], ref[h]))
-        assert rel_err(plain[h], ref[h]) > 20 * tol(dtype)              # the mask really changes the result
+        assert rel_err(plain[h], ref[h]) > 0.1              # the mask really changes the result
     again, _, _ = ops.pair_heads_fwd(ab, wp, torch.cat(b1), torch.cat(b2), classes, drop_p=p_drop, drop_seed=seed)
     other, _, _ = ops.pair_heads_fwd(ab, wp, torch.cat(b1), torch.cat(b2), classes, drop_p=p_drop, drop_seed=seed + 1)
     assert all(torch.equal(a_, b_) for a_, b_ in zip(logits, again)) and not torch.equal(logits[1], other[1])
