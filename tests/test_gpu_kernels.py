@@ -569,6 +569,49 @@ def test_head_concat_split(ops, dtype, nh, da, db):
     assert float(a2[:, nh * da:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("mode", [256, 384, 128])
+@pytest.mark.parametrize("bk", [True, False])
+def test_gemm_big_tiles_match_fp32_matmul(ops, mode, bk):
+    """gemm_big.hip (one 8-wave workgroup per CU; 256 x 256 / 384 x 192 / 256 x 128 tiles) forced for a ragged problem
+    (M, N not multiples of any tile; 5 and 13 k-tiles: ring wrap-around and the short-loop prologue), both B layouts, with
+    every fused epilogue option, against an fp32 matmul of the same bf16 operands and against the 128 x 128 kernel."""
+    import ctypes
+    from peneo_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    g = torch.Generator().manual_seed(mode + bk)
+    dt = torch.bfloat16
+    try:
+        for (M, N, K) in [(2101, 1032, 320), (2800, 776, 832), (3000, 2304, 128)]:
+            a = torch.randn(M, K, generator=g).to(DEV).to(dt)
+            b = (torch.randn(N, K, generator=g) if bk else torch.randn(K, N, generator=g)).to(DEV).to(dt)
+            bias = torch.randn(N, generator=g).to(DEV)
+            res = torch.randn(M, N, generator=g).to(DEV).to(dt)
+            src = torch.randn(M, N, generator=g).to(DEV).to(dt)
+            z = a.float() @ (b.float().t() if bk else b.float()) / math.sqrt(K) * math.sqrt(K)
+            outs = {}
+            for m_ in (mode, 0):
+                lib.peneo_gemm_set_big_mode(m_)
+                pre = torch.empty(M, N, device=DEV, dtype=dt)
+                o1 = ops.gemm(a, b, b_kmajor=bk, bias=bias, act=1, preact=pre)                       # bias + GELU + pre-activation
+                o2 = ops.gemm(a, b, b_kmajor=bk, bias=bias, residual=res, drop_p=0.1, drop_seed=77)   # bias + dropout + residual
+                o3 = ops.gemm(a, b, b_kmajor=bk, grad_src=src, grad_act=2)                            # x SiLU'(src)
+                o4 = ops.gemm(a, b, b_kmajor=bk, out_dtype=torch.float32)
+                outs[m_] = (pre, o1, o2, o3, o4)
+            pre, o1, o2, o3, o4 = outs[mode]
+            assert rel_err(pre, z + bias) < 2e-2 and rel_err(o1, F.gelu(z + bias)) < 2e-2
+            sg = torch.sigmoid(src.float())
+            assert rel_err(o3, z * (sg * (1 + src.float() * (1 - sg)))) < 2e-2
+            assert rel_err(o4, z) < 2e-3
+            kept = (o2.float() - res.float()).abs() > 0
+            assert 0.85 < float(kept.float().mean()) < 0.95
+            # same dropout mask function and same arithmetic as the 128 x 128 kernel: only the summation order differs
+            for x, y in zip(outs[mode], outs[0]):
+                assert rel_err(x, y) < 1e-2
+            assert torch.equal((outs[0][2].float() - res.float()) != 0, kept)
+    finally:
+        lib.peneo_gemm_set_big_mode(1)
+
+
 # ---------------------------------------------------------------------------------------------- pair heads
 def _pair_ref(ab, w1, b1, w2, b2):
     B, N, D2 = ab.shape

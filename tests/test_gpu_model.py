@@ -338,8 +338,8 @@ def test_train_mode_masks_are_the_same_function_in_both_precisions(name):
 @pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
 def test_deferred_joins_do_not_change_the_gradients(name):
     """The side-stream joins deferred by one stage (engine.defer_join) against immediate joins: only the PLACE of a stream
-    wait differs, so every gradient that is bit-reproducible run to run must be bit-identical between the two settings
-    (a clone of a bias gradient racing the side stream's column sums would show here), the rest equal to fp32 rounding."""
+    wait differs, so all gradients must agree to fp32 summation-order noise and most of them bit for bit (a clone of a bias
+    gradient racing the side stream's column sums would show here)."""
     import peneo_amd.model.engine as E
     fx = load_golden(name)
     b = to_cuda(fx["batch"])
@@ -352,19 +352,19 @@ def test_deferred_joins_do_not_change_the_gradients(name):
         torch.cuda.synchronize()
         return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
 
-    a1, a2 = run(), run()
-    stable = {n for n in a1 if torch.equal(a1[n], a2[n])}
-    assert len(stable) > len(a1) // 2
+    a1 = run()
     E.DEFER_ALLOWED[0] = False
     try:
         c = run()
     finally:
         E.DEFER_ALLOWED[0] = True
+    exact = 0
     for n in a1:
-        if n in stable:
-            assert torch.equal(c[n], a1[n]), n
-        else:
-            assert maxdiff(c[n], a1[n]) <= 1e-3 * float(a1[n].abs().max()) + 1e-9, n
+        # fp32 atomics (LayerNorm / embedding / column-sum reductions) reorder sums from launch to launch: last-bit noise.
+        # A gradient cloned while the side stream is still adding to it would miss whole contributions (errors >> 1e-3)
+        assert maxdiff(c[n], a1[n]) <= 2e-5 * float(a1[n].abs().max()) + 1e-9, n
+        exact += int(torch.equal(c[n], a1[n]))
+    assert exact > len(a1) // 2
 
 
 def test_fused_adamw_training_steps_reduce_the_loss():
