@@ -52,13 +52,18 @@ def pmc_traffic_bytes(kernel_key: str, docs_per_gpu: int):
     return None
 
 
-def build_model(size: str, dtype, backbone: str = "layoutlmv3"):
+def build_model(size: str, dtype, backbone: str = "layoutlmv3", vocab: int = 0):
+    """vocab = 250002: the XLM-R-vocabulary registry entries (layoutlmv3-base-chinese / lilt-infoxlm-base,
+    model/backbone_mapping.py:277-288,325-336): same encoder, a 768 MB fp32 word table."""
     from seeded import layoutlmv3_config, lilt_config, peneo_config
     from peneo_amd.model import PEneoConfig, PEneoModel
+    xlmr = vocab == 250002
     if backbone == "lilt":
-        pcfg = peneo_config("lilt-roberta-en-base", lilt_config(size))
+        pcfg = peneo_config("lilt-infoxlm-base" if xlmr else "lilt-roberta-en-base", lilt_config(size))
     else:
-        pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config(size))
+        pcfg = peneo_config("layoutlmv3-base-chinese" if xlmr else "layoutlmv3-base", layoutlmv3_config(size))
+    if vocab:
+        pcfg["backbone_config"]["vocab_size"] = vocab
     model = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"}))
     return model, pcfg
 
@@ -115,6 +120,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backbone", default="layoutlmv3", choices=["layoutlmv3", "lilt"],
                     help="lilt = BASELINE config 5 (side measurement; the headline metric is layoutlmv3 base)")
+    ap.add_argument("--vocab", type=int, default=0, help="250002 = the XLM-R-vocabulary backbones (side measurement: word-table "
+                    "gather / scatter kernels against the HBM roofline)")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the ragged side line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-forward", action="store_true", help="time eval forward only (reported as a side metric)")
     args = ap.parse_args()
@@ -132,7 +140,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     torch.manual_seed(1234)
-    model, pcfg = build_model(args.size, dtype, args.backbone)
+    model, pcfg = build_model(args.size, dtype, args.backbone, args.vocab)
     model = model.to(dev).set_compute_dtype(dtype).train()
     model.backbone.check_inputs = False
     net = wrap_data_parallel(model, device_ids=[local_rank]) if world > 1 else model
@@ -171,8 +179,38 @@ def main():
     elapsed = max_over_ranks(elapsed, dev)
     ph = ops.TIMER.durations_ms("pair_heads_fwd")
     pb = ops.TIMER.durations_ms("pair_bwd_fused")     # fused pair-space backward + its partial-row reduction (one C call)
+    eb = ops.TIMER.durations_ms("embed_bwd")          # word / position / box table scatter (fp32 atomics)
     ops.TIMER.reset(False)
     loss_val = float(loss.detach())
+
+    # side line: ragged documents (300..510 tokens), batch cut to its longest document rounded up to a multiple
+    # of 8 like the reference's collator (data/collator.py:110-116): N varies from batch to batch (masked tails everywhere)
+    ragged = None
+    if not args.no_ragged and world == 1:
+        rb = []
+        for s_ in range(4):
+            b_ = synthetic_rfund_batch(B, args.seq_len, args.lines, vocab, seed=7000 + s_, ragged=True, pad_to_longest=True)
+            if args.backbone == "lilt":
+                b_.pop("image", None)
+            rb.append({k: v.to(dev) for k, v in b_.items()})
+
+        def rstep(i):
+            for p in model.parameters():
+                p.grad = None
+            out = net(**rb[i % 4])
+            out["loss"].backward()
+        for i in range(2):
+            rstep(i)
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        nr = max(4, args.steps // 2)
+        for i in range(nr):
+            rstep(i)
+        torch.cuda.synchronize()
+        r_ms = (time.perf_counter() - tr) * 1e3 / nr
+        ragged = {"docs_per_s": round(B * 1e3 / r_ms, 1), "ms_per_step": round(r_ms, 3),
+                  "padded_lengths": [int(b_["input_ids"].shape[1]) for b_ in rb],
+                  "mean_tokens": round(float(sum(float(b_["attention_mask"].sum()) for b_ in rb) / (4 * B)), 1)}
 
     # side metric: eval forward only (the "encoder + pair-head forward" roofline target of BASELINE.md §5)
     model.eval()
@@ -249,6 +287,11 @@ def main():
             "forward_only": {"ms_per_batch": round(fwd_ms, 3), "docs_per_s": round(B * 1e3 / fwd_ms, 1),
                              "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
                              "frac_of_mfma_peak": round(FWD_GFLOP_PER_DOC * B / fwd_ms / PEAK_BF16_TFLOPS, 4)},
+            "ragged": ragged,
+            "embed_bwd": ({"avg_launch_ms": round(sum(eb) / len(eb), 4), "launches": len(eb), "vocab": vocab,
+                           # algorithmic bytes: every token reads its d_x row (H * 2 B) and adds H fp32 values into 6 tables
+                           "GBps_algorithmic": round(B * args.seq_len * pcfg["backbone_config"]["hidden_size"] * (2 + 2 * 4 * 2)
+                                                     / (sum(eb) / len(eb) * 1e-3) / 1e9, 1), "peak_GBps": 8000.0} if eb else None),
             "optimizer_step_ms": round(opt_ms, 3),
             "train_tflops_algorithmic": round(3 * FWD_GFLOP_PER_DOC * docs / elapsed / 1e3, 1),
         }

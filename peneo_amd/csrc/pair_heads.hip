@@ -846,6 +846,9 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
   int pi, pj;
   pair_decode(p.pbase + (pair_ok ? lp : p.npairs - 1), N, pi, pj);
   const int nslab = ncol / 32, spb = D / 32;
+  const uint32_t drop_thr = pair_drop_thr16_dev(p.a.drop_p);
+  const uint32_t drop_key = pair_drop_key(p.a.drop_seed, p.a.drop_doc);
+  const float drop_scale = drop_thr ? 65536.f / (65536.f - (float)drop_thr) : 1.f;
 
   for (int n = tid; n < ncol; n += PH_WAVES * 64) {
     const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
@@ -1008,9 +1011,20 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
         else {
           const f2 dy = __builtin_elementwise_fma(g2, w2, __builtin_elementwise_fma(g1, w1, g0 * w0));
           dz = dy * (sg * __builtin_elementwise_fma(zz, one2 - sg, one2));
+          if (drop_thr) {
+            // the forward's classifier dropout, one hash per element (this chunked kernel is the path of the widths the
+            // batch kernel peneo_pair_bwd_fused does not cover: D = 512)
+            const int64_t gp0 = p.a.drop_pair0 + lp0 + row0;
+            const f2 kk = f2{pair_drop_keep(drop_key, gp0, es * 32 + (lane & 31), ncol / 4, drop_thr) ? drop_scale : 0.f,
+                             pair_drop_keep(drop_key, gp0 + 1, es * 32 + (lane & 31), ncol / 4, drop_thr) ? drop_scale : 0.f};
+            dz = dz * kk;
+            const f2 ym = y * kk;
+            s0 = __builtin_elementwise_fma(g0, ym, s0); s1 = __builtin_elementwise_fma(g1, ym, s1); s2 = __builtin_elementwise_fma(g2, ym, s2);
+          } else {
           s0 = __builtin_elementwise_fma(g0, y, s0);
           s1 = __builtin_elementwise_fma(g1, y, s1);
           s2 = __builtin_elementwise_fma(g2, y, s2);
+          }
           sb = sb + dz;
         }
         const float give = odd ? dz.x : dz.y;
@@ -1234,7 +1248,7 @@ extern "C" int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, 
     PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3,
                   "peneo_pair_dz_fused: head %d arguments invalid (classes must be 1..3)", h);
   PENEO_REQUIRE((reinterpret_cast<uintptr_t>(ab_doc) & 15) == 0, "peneo_pair_dz_fused: ab must be 16-byte aligned");
-  PENEO_REQUIRE(args->drop_p == 0.f, "peneo_pair_dz_fused: the classifier dropout is implemented by peneo_pair_bwd_fused and peneo_pair_dz");
+  PENEO_REQUIRE(args->drop_p >= 0.f && args->drop_p < 1.f, "peneo_pair_dz_fused: drop_p must be in [0, 1)");
   DzFusedParams p;
   p.abd = reinterpret_cast<const bf16_t*>(ab_doc); p.N = N; p.D = D;
   p.pbase = pair_row_start(i0, N); p.npairs = pair_row_start(i1, N) - p.pbase;

@@ -80,18 +80,24 @@ def _one_doc(rng: np.random.Generator, seq_len: int, n_lines: int, vocab: int, r
 
 def synthetic_rfund_batch(batch_size: int, seq_len: int = 512, n_lines: int = 128, vocab_size: int = 50265,
                           seed: int = 0, ragged: bool = False, with_image: bool = True, add_sep: bool = True,
-                          pad_id: int = 1, image_size: int = 224) -> Dict[str, torch.Tensor]:
-    """Batch with the keys ``DataCollatorForPEneo`` emits (data/collator.py:205-230)."""
+                          pad_id: int = 1, image_size: int = 224, pad_to_longest: bool = False) -> Dict[str, torch.Tensor]:
+    """Batch with the keys ``DataCollatorForPEneo`` emits (data/collator.py:205-230).  ``pad_to_longest`` (with ``ragged``):
+    the batch is cut to its longest document rounded up to a multiple of 8, as the reference's collator pads
+    (``padding="longest"``, ``pad_to_multiple_of=8``, data/collator.py:110-116); the label maps follow that length."""
     rng = np.random.default_rng(seed)
-    n = seq_len - 1
-    ids, masks, boxes, tags = [], [], [], [[] for _ in range(5)]
+    ids, masks, boxes, all_spots = [], [], [], []
     for _ in range(batch_size):
         i, m, b, spots = _one_doc(rng, seq_len, n_lines, vocab_size, ragged, add_sep, pad_id)
         ids.append(i)
         masks.append(m)
         boxes.append(b)
-        for t, sp in zip(tags, spots):
-            t.append(spots_to_shaking_tag(sp, n))
+        all_spots.append(spots)
+    L = seq_len
+    if pad_to_longest:
+        L = min(seq_len, -(-max(int(m.sum()) for m in masks) // 8) * 8)
+        ids, masks, boxes = [i[:L] for i in ids], [m[:L] for m in masks], [b[:L] for b in boxes]
+    n = L - 1
+    tags = [[spots_to_shaking_tag(sp[h], n) for sp in all_spots] for h in range(5)]
     batch = {
         "input_ids": torch.from_numpy(np.stack(ids)),
         "attention_mask": torch.from_numpy(np.stack(masks)),

@@ -172,7 +172,8 @@ class _DecoderStage(torch.autograd.Function):
         if dec.decoder_shrink:
             w0, b0, w3, b3 = next(it), next(it), next(it), next(it)
         wc_w, wc_b = next(it), next(it)
-        heads = [(next(it), next(it), next(it), next(it)) for _ in HEAD_NAMES]
+        kcls = dec.num_cls_layers
+        heads = [tuple(next(it) for _ in range(2 * kcls)) for _ in HEAD_NAMES]
         D = wc_w.shape[0]
         seeds = DropoutSeeds(dec.training, dec.dropout_p, 0.0)
         dev = seq.device
@@ -191,13 +192,23 @@ class _DecoderStage(torch.autograd.Function):
         Wab = dec.stacked_combine_weight(wc_w, dt)
         bab = wc.get(("dec.bab",), [wc_b], lambda: torch.cat([torch.zeros_like(wc_b.detach()), wc_b.detach()]))
         ab = ops.gemm(h, Wab, bias=bab).view(B, N, 2 * D)
+        cws = [dec.le_loss.weight] + [dec.link_loss.weight] * 4 if tags is not None else None
+        if kcls != 2:
+            # classifier depths other than the shipped 2 (reference :253-271): materialising per-document path
+            logits, outs, extra = _generic_heads_forward(dec, ab, heads, tags, cws, seeds, need_grad, want_logits)
+            saved.update(extra)
+            saved.update(ab=ab, B=B, N=N, D=D, seq=seq)
+            ctx.dec, ctx.saved, ctx.params = dec, saved, params
+            ctx.has_loss = tags is not None
+            ctx.mark_non_differentiable(*[lg for lg in logits if lg is not None])
+            ctx.set_materialize_grads(False)
+            return tuple(outs) + tuple(logits)
         w1s, b1s = [hd[0] for hd in heads], [hd[1] for hd in heads]
         w2s, b2s = [hd[2] for hd in heads], [hd[3] for hd in heads]
         wp = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
                                                                              [w.detach() for w in w2s]))
         b1cat = wc.get(("dec.b1",), b1s, lambda: torch.cat([b.detach() for b in b1s]))
         b2cat = wc.get(("dec.b2",), b2s, lambda: torch.cat([b.detach() for b in b2s]))
-        cws = [dec.le_loss.weight] + [dec.link_loss.weight] * 4 if tags is not None else None
         # the Dropout between the two layers of every classifier (reference :261) acts on the [B, P, 5D] hidden inside the
         # kernel; the backward regenerates the mask from (p, seed)
         saved["k12_drop"] = (seeds.p_hidden, seeds.seed(903))
@@ -250,7 +261,8 @@ class _DecoderStage(torch.autograd.Function):
         if dec.decoder_shrink:
             w0, b0, w3, b3 = next(it), next(it), next(it), next(it)
         wc_w, wc_b = next(it), next(it)
-        heads = [(next(it), next(it), next(it), next(it)) for _ in HEAD_NAMES]
+        kcls = dec.num_cls_layers
+        heads = [tuple(next(it) for _ in range(2 * kcls)) for _ in HEAD_NAMES]
         B, N, D = sv["B"], sv["N"], sv["D"]
         ab, seeds = sv["ab"], sv["seeds"]
         dt, dev = ab.dtype, ab.device
@@ -264,6 +276,9 @@ class _DecoderStage(torch.autograd.Function):
             extra = torch.stack([d.to(torch.float32).reshape(()) if d is not None else torch.zeros((), device=dev)
                                  for d in d_heads])
             scale = scale + extra * sv["inv_den"]
+        if kcls != 2:
+            d_ab, head_grads = _generic_heads_backward(dec, sv, heads, scale)
+            return _DecoderStage._front_backward(ctx, dec, sv, params, d_ab, head_grads)
         w1s, b1s = [hd[0] for hd in heads], [hd[1] for hd in heads]
         w2s, b2s = [hd[2] for hd in heads], [hd[3] for hd in heads]
         W1cat = wc.cat_rows("dec.w1cat", w1s, dt)                      # [nh*D, D]
@@ -322,9 +337,9 @@ class _DecoderStage(torch.autograd.Function):
         prebuf = [torch.empty((maxp, D), dtype=dt, device=dev) for _ in range(2)]   # a_i + b_j: SiLU' source of the dx GEMM
         zbuf = [torch.empty((maxp, nh * D), dtype=dt, device=dev) for _ in range(2)]
         dxbuf = torch.empty((maxp, D), dtype=dt, device=dev)
-        # with the classifier dropout active the chunked path runs z = x W1^T + b1 as a plain GEMM and the stand-alone
-        # peneo_pair_dz kernel (the one chunked form that regenerates the mask)
-        fused_dz = (dec.fused_dz and dt == torch.bfloat16 and D % 32 == 0 and drop_p == 0.0
+        # (with the classifier dropout active the un-fused form runs z = x W1^T + b1 as a plain GEMM and the stand-alone
+        # peneo_pair_dz kernel: the GEMM's pair-dz epilogue does not regenerate the mask)
+        fused_dz = (dec.fused_dz and dt == torch.bfloat16 and D % 32 == 0
                     and D // 16 in (2, 4, 6, 8, 12, 16, 24, 32))
         if fused_dz:
             wp = wc.get(("dec.pack", dt), w1s + w2s, lambda: ops.pair_heads_pack(dt, [w.detach() for w in w1s],
@@ -378,20 +393,31 @@ class _DecoderStage(torch.autograd.Function):
 
     @staticmethod
     def _finish_backward(ctx, dec, sv, params, scale, dW1cat, dz_ws, d_ab, heads, w1s, b1s, w2s, b2s):
-        """Second half of the backward: parameter gradients of the heads from the accumulated sums, then back through the
-        [a | b] projection and the shrink MLP."""
+        """Second half of the two-layer backward: parameter gradients of the heads from the accumulated sums."""
+        D = sv["D"]
+        nh = len(HEAD_NAMES)
+        dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
+        db2cat = sv["dls"]
+        head_grads = []
+        off = 0
+        for h in range(nh):
+            c = HEAD_CLASSES[h]
+            head_grads += [dW1cat[h * D:(h + 1) * D], db1cat[h * D:(h + 1) * D], dw2[h], db2cat[off:off + c] * scale[h]]
+            off += c
+        return _DecoderStage._front_backward(ctx, dec, sv, params, d_ab, head_grads, w1s)
+
+    @staticmethod
+    def _front_backward(ctx, dec, sv, params, d_ab, head_grads, w1s=()):
+        """Back through the [a | b] projection and the shrink MLP; `head_grads`: the heads' parameter gradients in
+        stage_params() order."""
         wc = dec.weight_cache
         B, N, D = sv["B"], sv["N"], sv["D"]
         ab, seeds = sv["ab"], sv["seeds"]
         dt, dev = ab.dtype, ab.device
-        nh = len(HEAD_NAMES)
         it = iter(params)
         if dec.decoder_shrink:
             w0, b0, w3, b3 = next(it), next(it), next(it), next(it)
         wc_w, wc_b = next(it), next(it)
-        dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
-        db2cat = sv["dls"]
-        # back through the [a | b] projection and the shrink MLP
         d_ab2 = ops.cast(d_ab.view(B * N, 2 * D), dt) if dt != torch.float32 else d_ab.view(B * N, 2 * D)
         s2 = sv["s2"]
         Wab = dec.stacked_combine_weight(wc_w, dt)
@@ -414,11 +440,7 @@ class _DecoderStage(torch.autograd.Function):
         else:
             d_seq = ops.gemm(d_ab2, Wab, b_kmajor=False)
         grads += [d_wc, d_bc]
-        off = 0
-        for h in range(nh):
-            c = HEAD_CLASSES[h]
-            grads += [dW1cat[h * D:(h + 1) * D], db1cat[h * D:(h + 1) * D], dw2[h], db2cat[off:off + c] * scale[h]]
-            off += c
+        grads += list(head_grads)
         grads = tuple(g if p.requires_grad else None for g, p in zip(grads, params))
         side_work = getattr(ctx, "side_work", None)
         if side_work is not None:
@@ -431,6 +453,94 @@ class _DecoderStage(torch.autograd.Function):
             else:
                 torch.cuda.current_stream().wait_stream(side)
         return (None, d_seq, None, None, None, None, None) + grads
+
+
+def _generic_heads_forward(dec, ab, heads, tags, cws, seeds, need_grad, want_logits):
+    """Classifier heads of any depth over the materialised pair activations, one document at a time: x = SiLU(a_i + b_j)
+    [P, D] (peneo_pair_x_fwd), per head (Linear + SiLU + Dropout) x (k - 1) as GEMMs with fused epilogues, the D -> C layer as
+    a GEMM into fp32 logits, class-weighted CE by peneo_weighted_ce (reference model/peneo_decoder.py:253-271,315-336).
+    Nothing but the un-normalised dlogits is kept for the backward (it recomputes the activations document by document)."""
+    B, N, D2 = ab.shape
+    D = D2 // 2
+    dt, dev = ab.dtype, ab.device
+    wc = dec.weight_cache
+    nh, k = len(HEAD_NAMES), dec.num_cls_layers
+    P = N * (N + 1) // 2
+    logits = [torch.empty((B, P, c), dtype=torch.float32, device=dev) for c in HEAD_CLASSES]
+    num = torch.zeros(nh, dtype=torch.float32, device=dev)
+    den = torch.zeros(nh, dtype=torch.float32, device=dev)
+    dlog = [torch.empty((B, P, c), dtype=torch.float32, device=dev) for c in HEAD_CLASSES] if (need_grad and tags is not None) else None
+    x = torch.empty((P, D), dtype=dt, device=dev)
+    for b in range(B):
+        ops.pair_x_fwd(ab[b], 0, N, x)
+        for h in range(nh):
+            cur = x
+            for l in range(k - 1):
+                W = wc.cast(f"dec.h{h}.{l}", heads[h][2 * l], dt)
+                cur = ops.gemm(cur, W, bias=heads[h][2 * l + 1], act=ACT_SILU, drop_p=seeds.p_hidden,
+                               drop_seed=seeds.seed(1000 + ((b * nh + h) * 8 + l)))
+            Wl = wc.cast(f"dec.h{h}.{k - 1}", heads[h][2 * (k - 1)], dt)
+            ops.gemm(cur, Wl, bias=heads[h][2 * (k - 1) + 1], out=logits[h][b])
+            if tags is not None:
+                n_, d_, dl_ = ops.weighted_ce(logits[h][b], tags[h][b], cws[h], want_dlogits=dlog is not None)
+                num[h] += n_[0]
+                den[h] += d_[0]
+                if dlog is not None:
+                    dlog[h][b].copy_(dl_)
+    outs = [None] * 6
+    extra = {}
+    if tags is not None:
+        ratio = dec.loss_ratio_tensor(dev)
+        losses = num / den
+        outs = [(losses * ratio).sum()] + [losses[i] for i in range(nh)]
+        extra = dict(scale=ratio / den, inv_den=1.0 / den, dlog=dlog)
+    return logits, outs, extra
+
+
+def _generic_heads_backward(dec, sv, heads, scale):
+    """Backward of _generic_heads_forward: per document and head the hidden activations are recomputed, then
+    dlogits -> (dW, db) of every layer and dx, summed over the heads; d_ab = pair_x_bwd(dx).  -> (d_ab, head gradients in
+    stage_params() order)."""
+    ab, seeds = sv["ab"], sv["seeds"]
+    B, N, D2 = ab.shape
+    D = D2 // 2
+    dt, dev = ab.dtype, ab.device
+    wc = dec.weight_cache
+    nh, k = len(HEAD_NAMES), dec.num_cls_layers
+    P = N * (N + 1) // 2
+    dlog = sv["dlog"]
+    gW = [[torch.zeros(heads[h][2 * l].shape, dtype=torch.float32, device=dev) for l in range(k)] for h in range(nh)]
+    gb = [[torch.zeros(heads[h][2 * l + 1].shape, dtype=torch.float32, device=dev) for l in range(k)] for h in range(nh)]
+    d_ab = torch.zeros((B, N, D2), dtype=torch.float32, device=dev)
+    x = torch.empty((P, D), dtype=dt, device=dev)
+    dx32 = torch.empty((P, D), dtype=torch.float32, device=dev)
+    for b in range(B):
+        ops.pair_x_fwd(ab[b], 0, N, x)
+        dx32.zero_()
+        for h in range(nh):
+            Ws = [wc.cast(f"dec.h{h}.{l}", heads[h][2 * l], dt) for l in range(k)]
+            acts, pres = [x], []
+            for l in range(k - 1):
+                z = torch.empty((P, D), dtype=dt, device=dev)
+                acts.append(ops.gemm(acts[-1], Ws[l], bias=heads[h][2 * l + 1], act=ACT_SILU, preact=z, drop_p=seeds.p_hidden,
+                                     drop_seed=seeds.seed(1000 + ((b * nh + h) * 8 + l))))
+                pres.append(z)
+            g = (dlog[h][b] * scale[h]).to(dt)                                   # [P, C]: d loss / d logits of this document
+            ops.gemm(g, acts[k - 1], a_kmajor=False, b_kmajor=False, out=gW[h][k - 1], accumulate=True)
+            ops.colsum(g, out=gb[h][k - 1], accumulate=True)
+            for l in range(k - 2, -1, -1):
+                up = g if l == k - 2 else dz
+                dz = ops.gemm(up, Ws[l + 1], b_kmajor=False, grad_src=pres[l], grad_act=ACT_SILU, drop_p=seeds.p_hidden,
+                              drop_seed=seeds.seed(1000 + ((b * nh + h) * 8 + l)))
+                ops.gemm(dz, acts[l], a_kmajor=False, b_kmajor=False, out=gW[h][l], accumulate=True)
+                ops.colsum(dz, out=gb[h][l], accumulate=True)
+            ops.gemm(g if k == 1 else dz, Ws[0], b_kmajor=False, out=dx32, accumulate=True)
+        ops.pair_x_bwd(ab[b], 0, N, ops.cast(dx32, dt) if dt != torch.float32 else dx32, d_ab[b])
+    head_grads = []
+    for h in range(nh):
+        for l in range(k):
+            head_grads += [gW[h][l], gb[h][l]]
+    return d_ab, head_grads
 
 
 class PEneoDecoder(nn.Module):
@@ -446,9 +556,9 @@ class PEneoDecoder(nn.Module):
         self.decoder_shrink = config.peneo_decoder_shrink
         hidden = config.backbone_config["hidden_size"]
         self.dropout_p = config.backbone_config["hidden_dropout_prob"]
-        if config.peneo_classifier_num_layers != 2:
-            raise NotImplementedError("the fused pair-heads kernel implements the shipped 2-layer classifier "
-                                      "(peneo_classifier_num_layers == 2, tools/generate_peneo_weights.py:66)")
+        self.num_cls_layers = int(config.peneo_classifier_num_layers)
+        if self.num_cls_layers < 1:
+            raise ValueError("peneo_classifier_num_layers must be >= 1")
         if self.decoder_shrink:
             D = hidden // 2
             self.shrink_projection = nn.Sequential(
@@ -463,7 +573,15 @@ class PEneoDecoder(nn.Module):
         self.inference_mode = config.inference_mode
 
         def build_classifier(out_size: int) -> nn.Module:
-            return nn.Sequential(nn.Linear(D, D), nn.SiLU(), nn.Dropout(self.dropout_p), nn.Linear(D, out_size))
+            """Reference :231-271: one Linear for a single layer, else (Linear, SiLU, Dropout) x (k - 1) + Linear; the shipped
+            k = 2 runs in the fused pair kernels, every other depth in the materialising per-document path below."""
+            if self.num_cls_layers == 1:
+                return nn.Linear(D, out_size)
+            mods = []
+            for _ in range(self.num_cls_layers - 1):
+                mods += [nn.Linear(D, D), nn.SiLU(), nn.Dropout(self.dropout_p)]
+            mods.append(nn.Linear(D, out_size))
+            return nn.Sequential(*mods)
 
         self.line_extraction_fc = build_classifier(2)
         self.ent_linking_h2h_fc = build_classifier(3)
@@ -513,9 +631,13 @@ class PEneoDecoder(nn.Module):
                    self.shrink_projection[3].weight, self.shrink_projection[3].bias]
         ps += [self.handshaking_kernel.combine_fc.weight, self.handshaking_kernel.combine_fc.bias]
         for name in HEAD_NAMES:
-            fc = getattr(self, name + "_fc")
-            ps += [fc[0].weight, fc[0].bias, fc[3].weight, fc[3].bias]
+            for lin in self.head_linears(name):
+                ps += [lin.weight, lin.bias]
         return ps
+
+    def head_linears(self, name: str) -> List[nn.Linear]:
+        fc = getattr(self, name + "_fc")
+        return [fc] if isinstance(fc, nn.Linear) else [m for m in fc if isinstance(m, nn.Linear)]
 
     def forward(self, sequence_output: torch.Tensor, orig_bbox: torch.Tensor = None, line_extraction_shaking_tag=None,
                 ent_linking_head_rel_shaking_tag=None, ent_linking_tail_rel_shaking_tag=None,

@@ -311,9 +311,10 @@ def embed_bwd(d_out: torch.Tensor, B: int, S: int, H: int, *, input_ids=None, po
     m2 = g_x.shape[0] if g_x is not None else 0
     rows, rpb, bs = _rowmap(d_out, H)
     assert rows == B * S
-    check(lib().peneo_embed_text_bwd(dtype_code(d_out.dtype), ptr(d_out), rpb, bs, ptr(input_ids), ptr(pos_ids), ptr(bbox),
-                                     C.byref(g), cs, ss, m2, B, S, H, int(clip_hw), pad_id, stream()),
-          "peneo_embed_text_bwd")
+    with kernel_timer("embed_bwd"):
+        check(lib().peneo_embed_text_bwd(dtype_code(d_out.dtype), ptr(d_out), rpb, bs, ptr(input_ids), ptr(pos_ids), ptr(bbox),
+                                         C.byref(g), cs, ss, m2, B, S, H, int(clip_hw), pad_id, stream()),
+              "peneo_embed_text_bwd")
 
 
 def im2col_patch16(image: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

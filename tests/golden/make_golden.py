@@ -238,11 +238,20 @@ def make_decode(ref, seed: int = 21):
     print(f"[decode] -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
+def make_cls_depths(ref):
+    """peneo_classifier_num_layers = 1 and 3 (model/peneo_decoder.py:253-271) on the tiny LayoutLMv3 shape, S = 24."""
+    for k, seed in ((1, 5), (3, 6)):
+        pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("tiny"))
+        pcfg["peneo_classifier_num_layers"] = k
+        make_tiny(ref, f"lmv3_tiny_cls{k}", pcfg, 24, 5, True, True, seed)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base", action="store_true")
     ap.add_argument("--only-ohem", action="store_true", help="regenerate tests/golden/ohem.pt only")
     ap.add_argument("--only-decode", action="store_true", help="regenerate tests/golden/decode.pt only")
+    ap.add_argument("--only-cls", action="store_true", help="classifier depths 1 and 3 (lmv3_tiny_cls1.pt / _cls3.pt) only")
     args = ap.parse_args()
     ref = import_reference()
     torch.set_num_threads(8)
@@ -252,11 +261,15 @@ def main():
     if args.only_decode:
         make_decode(ref)
         return
+    if args.only_cls:
+        make_cls_depths(ref)
+        return
     make_tiny(ref, "lmv3_tiny", peneo_config("layoutlmv3-base", layoutlmv3_config("tiny")), 40, 8, True, True, 1)
     make_tiny(ref, "lmv3_tiny_s24", peneo_config("layoutlmv3-base", layoutlmv3_config("tiny")), 24, 5, True, True, 2)
     make_tiny(ref, "lilt_tiny", peneo_config("lilt-roberta-en-base", lilt_config("tiny")), 33, 6, False, False, 3)
     make_ohem(ref)
     make_decode(ref)
+    make_cls_depths(ref)
     if args.base:
         make_base(ref)
 

@@ -26,7 +26,7 @@ def maxdiff(a, b):
     return float((a.float().cpu() - b.float().cpu()).abs().max())
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"])
 def test_fp32_forward_matches_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"]).eval()
@@ -44,7 +44,7 @@ def test_fp32_forward_matches_reference(name):
     assert torch.equal(out["orig_bbox"].cpu(), ref["orig_bbox"])
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"])
 def test_fp32_gradients_match_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"]).eval()   # eval: dropout off, like the fixture
@@ -62,7 +62,7 @@ def test_fp32_gradients_match_reference(name):
     assert checked == len(fx["grads"])
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"])
 def test_bf16_forward_close_to_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()
@@ -76,8 +76,9 @@ def test_bf16_forward_close_to_reference(name):
     assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-2 * float(ref["loss"])
 
 
-def test_bf16_gradients_close_to_reference():
-    fx = load_golden("lmv3_tiny")
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"])
+def test_bf16_gradients_close_to_reference(name):
+    fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()
     out = m(**to_cuda(fx["batch"]))
     out["loss"].backward()
@@ -193,7 +194,7 @@ def test_base_s512_matches_reference_golden():
         assert maxdiff(p.grad, g) <= 2e-3 * float(g.abs().max()) + 1e-7, n
 
 
-@pytest.mark.parametrize("which", ["lmv3_large_s1024", "lilt_base_s512"])
+@pytest.mark.parametrize("which", ["lmv3_large_s1024", "lilt_base_s512", "lmv3_chinese_s512", "lilt_infoxlm_s512"])
 def test_full_width_shapes_match_the_oracle(which):
     """BASELINE config 4 / 5 widths (H = 1024, 16 heads, S = 1024, N = 1023, D = 512; LiLT H = 768 + 192, head dim 64 + 16)
     with ONE encoder layer so that the CPU oracle finishes in seconds: fp32 logits / loss parity on seeded weights,
@@ -205,6 +206,17 @@ def test_full_width_shapes_match_the_oracle(which):
         bcfg = dict(layoutlmv3_config("large"), num_hidden_layers=1)
         pcfg = peneo_config("layoutlmv3-base", bcfg)
         batch = synthetic_rfund_batch(1, 1024, 256, bcfg["vocab_size"], seed=3)
+    elif which == "lmv3_chinese_s512":
+        # the XLM-R-vocabulary registry entry (model/backbone_mapping.py:325-336): vocab 250 002 = a 768 MB fp32 word table,
+        # token ids drawn from the whole vocabulary, S = 512, one encoder layer
+        bcfg = dict(layoutlmv3_config("base"), num_hidden_layers=1, vocab_size=250002)
+        pcfg = peneo_config("layoutlmv3-base-chinese", bcfg)
+        batch = synthetic_rfund_batch(2, 512, 128, bcfg["vocab_size"], seed=5, ragged=True)
+    elif which == "lilt_infoxlm_s512":
+        bcfg = dict(lilt_config("base"), num_hidden_layers=1, vocab_size=250002)    # model/backbone_mapping.py:277-288
+        pcfg = peneo_config("lilt-infoxlm-base", bcfg)
+        batch = synthetic_rfund_batch(2, 512, 128, bcfg["vocab_size"], seed=6, ragged=True, add_sep=False)
+        batch.pop("image", None)
     else:
         bcfg = dict(lilt_config("base"), num_hidden_layers=1)
         pcfg = peneo_config("lilt-roberta-en-base", bcfg)
@@ -239,6 +251,15 @@ def test_full_width_shapes_match_the_oracle(which):
     for n, p in m.named_parameters():
         if p.requires_grad and p.grad is not None:
             assert torch.isfinite(p.grad).all(), n
+    if "250002" in str(bcfg["vocab_size"]):
+        # the word-table gradient (scatter of 1024 token rows into 250 002): rows of tokens that occur, and only those, are hit
+        g = m.backbone.embeddings.word_embeddings.weight.grad
+        used = torch.zeros(bcfg["vocab_size"], dtype=torch.bool)
+        ids = batch["input_ids"][batch["attention_mask"].bool()]
+        used[ids] = True
+        used[bcfg["pad_token_id"]] = False
+        hit = (g.abs().sum(1) > 0).cpu()
+        assert int(ids.max()) > 200000 and torch.equal(hit, used)
 
 
 def _grad_agreement(m, batch, ref_dtype=torch.float32):

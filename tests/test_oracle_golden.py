@@ -6,7 +6,7 @@ from conftest import load_golden
 from oracle import peneo_oracle as O
 
 HEADS = O.HEAD_NAMES
-TINY = ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny"]
+TINY = ["lmv3_tiny", "lmv3_tiny_s24", "lilt_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"]
 
 
 def _req_grad(sd):
