@@ -1091,8 +1091,10 @@ static int launch_pair_dz_fused_v(const DzFusedParams& p, hipStream_t st) {
 }
 template <int KS>
 static int launch_pair_dz_fused(const DzFusedParams& p, hipStream_t st) {
-  static const bool pipe = [] { const char* e = getenv("PENEO_DZF_PIPE"); return e ? atoi(e) != 0 : true; }();
-  return pipe ? launch_pair_dz_fused_v<KS, true>(p, st) : launch_pair_dz_fused_v<KS, false>(p, st);
+  // software-pipelined form (MFMAs of slab s + 1 between the arithmetic steps of slab s) except at D = 512, where it spills
+  // (measured on config 4: 60.6 against 56.9 docs/s)
+  if constexpr (KS >= 32) return launch_pair_dz_fused_v<KS, false>(p, st);
+  else return launch_pair_dz_fused_v<KS, true>(p, st);
 }
 
 // label maps from sparse spots (b, i, j, tag): the dense [B, P] int64 maps the collator builds on the host
