@@ -154,29 +154,34 @@ __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint64_t idx, uint32
 __device__ __forceinline__ uint32_t dropout_base(uint32_t seed, uint64_t idx) { return mix32(seed ^ (uint32_t)(idx >> 32) * 0x9e3779b9u); }
 __device__ __forceinline__ bool dropout_keep_b(uint32_t base, uint32_t lo, uint32_t thresh) { return mix32(lo ^ base) >= thresh; }
 // ---- K12 dropout: the Dropout between the two layers of every pair classifier (model/peneo_decoder.py:261), acting on the
-// [B, P, nh*D] hidden that never exists in memory.  keep(b, p, n) = 16-bit field (n & 3) of the word pair
-// (w0, w1) = f(key(seed, b), p * ncol/4 + n/4) >= p_drop * 2^16: one two-round 24-bit-multiply mixer (full-rate
-// v_mul_u32_u24, as the attention mask) and one more round for the second word serve FOUR neighbouring hidden units of a
-// pair.  The forward kernel holds exactly such groups per lane (accumulator rows 8g + 4 half + 0..3 of a pair); backward
-// kernels regenerate the same bits (tools/check_dropout_hash.py: rates, field / neighbour correlations at the noise floor).
+// [B, P, nh*D] hidden that never exists in memory.  The hidden units of one pair are walked in slabs of 32 (the kernels'
+// weight slabs); a slab splits into two halves of 16 units, half h = units 8g + 4h + e (g = 0..3, e = 0..3): what ONE lane
+// of the forward kernel holds (accumulator rows 8g + 4 half + e of its pair).  Each (document, pair, slab, half) owns a
+// chain of 16 fields: a two-round 24-bit-multiply mixer (full-rate v_mul_u32_u24, as the attention mask) of the counter
+// seeds it, then one v_mad_u32_u24 per field:
+//     st_0 = mix24(((p * nslab + slab) * 2 + h) ^ key(seed, b));  st_{i+1} = (st_i[23:0] * 0xC2B2AF + 0x9E3779) mod 2^32
+//     keep(unit 8 (i >> 2) + 4 h + (i & 3)) = (st_{i+1} >> 16) >= p_drop * 2^16
+// i.e. 1.5 integer operations per element instead of a hash each (the mask generation was 27 % of the forward kernel).
+// Backward kernels regenerate the same bits.  tools/check_dropout_hash.py: keep rate, neighbour / slab / pair correlations
+// and count statistics at the noise floor.
 __device__ __forceinline__ uint32_t pair_drop_key(uint32_t seed, int b) { return mix32(seed ^ ((uint32_t)(b + 1) * 0x9e3779b9u)); }
-__device__ __forceinline__ void pair_drop_words(uint32_t key, uint32_t group, uint32_t& w0, uint32_t& w1) {
-  uint32_t x = group ^ key;
+__device__ __forceinline__ uint32_t pair_drop_seed(uint32_t key, uint32_t counter /* (p * nslab + slab) * 2 + half */) {
+  uint32_t x = counter ^ key;
   x ^= x >> 16; x = __umul24(x, 0x9E3779u); x ^= x >> 13; x = __umul24(x, 0x85EBCBu); x ^= x >> 16;
-  w0 = x;
-  w1 = __umul24(x ^ (x >> 11), 0xC2B2AFu) ^ (x >> 9);
+  return x;
 }
+__device__ __forceinline__ uint32_t pair_drop_step(uint32_t st) { return __umul24(st, 0xC2B2AFu) + 0x9E3779u; }
+__device__ __forceinline__ uint32_t pair_drop_thr16_dev(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
 // threshold and the matching scale: p is realised as thr16 / 2^16 (0.1 -> 6554 / 65536) and the kept values are scaled by
 // 2^16 / (2^16 - thr16), so the mask is unbiased for the probability it really uses
-__device__ __forceinline__ uint32_t pair_drop_thr16_dev(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
 inline uint32_t pair_drop_thr16_host(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
 inline float pair_drop_scale_host(float p) { const uint32_t t = pair_drop_thr16_host(p); return t ? 65536.f / (65536.f - (float)t) : 1.f; }
-// one element (the chunked / fp32 kernels, where speed does not matter): n = column in [0, ncol)
-__device__ __forceinline__ bool pair_drop_keep(uint32_t key, int64_t pair, int n, int ncol4, uint32_t thr16) {
-  uint32_t w0, w1;
-  pair_drop_words(key, (uint32_t)(pair * ncol4 + (n >> 2)), w0, w1);
-  const uint32_t w = (n & 2) ? w1 : w0;
-  return ((n & 1) ? (w >> 16) : (w & 0xffffu)) >= thr16;
+// one element (the chunked / fp32 kernels, where speed does not matter): n = column in [0, nslab * 32)
+__device__ __forceinline__ bool pair_drop_keep(uint32_t key, int64_t pair, int n, int nslab, uint32_t thr16) {
+  const int slab = n >> 5, w = n & 31, half = (w >> 2) & 1, i = 4 * (w >> 3) + (w & 3);
+  uint32_t st = pair_drop_seed(key, (uint32_t)((pair * nslab + slab) * 2 + half));
+  for (int k = 0; k <= i; ++k) st = pair_drop_step(st);
+  return (st >> 16) >= thr16;
 }
 
 // 8 consecutive elements starting at idx0 (handles the rare run that crosses a 2^32 boundary)

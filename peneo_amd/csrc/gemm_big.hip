@@ -294,7 +294,7 @@ int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
     double best = c256;
     if (c384 < best) { best = c384; pick = 384; }
     if (c128 < best) { best = c128; pick = 128; }
-    if (best > 0.95 * small_cost(p.M, p.N)) return 0;
+    if (best > 0.98 * small_cost(p.M, p.N)) return 0;
   }
   if (b_kmajor) {
     if (pick == 384) return launch_big<Big384<true>>(p, st);

@@ -166,11 +166,14 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   const int grp = wave & 3;                                  // pair group: rows 2 grp, 2 grp + 1 of the block
   const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
   char* sA = smem;                                                          // [4][HALF_BYTES] weight ring: slab s in slot s & 3
-  float4* sCol = reinterpret_cast<float4*>(smem + 4 * HALF_BYTES);          // [ncol]
-  float4* sG = sCol + ncol;                                                 // [4][32]
+  uint2* sW2p = reinterpret_cast<uint2*>(smem + 4 * HALF_BYTES);            // [ncol]: the column's W2 rows as bf16 (w0, w1 | w2, 0)
+  float* sB1 = reinterpret_cast<float*>(sW2p + ncol);                       // [ncol]: first-layer bias
+  float4* sG = reinterpret_cast<float4*>(sB1 + ncol);                       // [4][32]
   float4* sPart = sG + 4 * 32;                                              // [2][4][32]
   char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
-  uint32_t* sMask = reinterpret_cast<uint32_t*>(sT + 2 * 4 * 2048);         // [2][4][32]: keep bits of a slab, word = hidden unit, bit = pair of the group
+  // classifier-dropout masks of a slab as f16 addends (0 = keep, -30000 = drop) for the pre-activation: [2][4 groups][32 units]
+  // [2 halves][16 registers]: a producer lane (unit, half) reads its 16 register values with two ds_read_b128
+  _Float16* sMask = reinterpret_cast<_Float16*>(sT + 2 * 4 * 2048);
 
   int ti = 0;
   {
@@ -192,8 +195,9 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   for (int n = tid; n < ncol; n += PW_WAVES * 64) {
     const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
     const float ds = DROP ? p.drop_scale : 1.f;     // dy = g W2 / (1 - p): the scale of the kept units rides on the W2 rows
-    sCol[n] = make_float4(ds * p.a.w2[h][k], Cn > 1 ? ds * p.a.w2[h][(int64_t)D + k] : 0.f, Cn > 2 ? ds * p.a.w2[h][(int64_t)2 * D + k] : 0.f,
-                          p.b1[n]);
+    sW2p[n] = make_uint2(pack_bf16x2(ds * p.a.w2[h][k], Cn > 1 ? ds * p.a.w2[h][(int64_t)D + k] : 0.f),
+                         pack_bf16x2(Cn > 2 ? ds * p.a.w2[h][(int64_t)2 * D + k] : 0.f, 0.f));
+    sB1[n] = p.b1[n];
   }
 
   // weight stream: piece q of an iteration (q < KS: z fragments, else du fragments); wave w carries pieces w, w + 8, ...
@@ -365,13 +369,18 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         for (int r = 0; r < 16; ++r) zw[r] = 0.f;
         asm volatile("" : "+v"(zw));   // opaque zero: a literal 0 as srcC lets the compiler overlap the chain's destination with its B operand
       }
-      float4 cw = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (DOE) cw = sCol[s * 32 + r32];
-      // K12 dropout: this lane's hidden unit, one keep bit per pair of the group (written by the consumer waves one iteration
-      // ago); shifted so that register r0's pair (rowc + 4 half) sits at the compile-time position rowc
-      uint32_t mws = 0xffffffffu;
-      if constexpr (DOE && DROP) mws = sMask[((s & 1) * 4 + grp) * 32 + 2 * (r32 & 15) + (r32 >> 4)] >> (4 * half);
-      const f2 b1 = f2{cw.w, cw.w};
+      uint2 cw2 = make_uint2(0u, 0u);
+      float cb1 = 0.f;
+      if constexpr (DOE) { cw2 = sW2p[s * 32 + r32]; cb1 = sB1[s * 32 + r32]; }
+      // K12 dropout: 16 f16 addends (0 / -30000) for this lane's (unit, half) = its 16 accumulator registers, written by the
+      // consumer waves one iteration ago.  Adding -30000 to the pre-activation zeroes y = z sigmoid(z) AND SiLU'(z) (so dz):
+      // one v_fma_mix_f32 per element masks both
+      pb_u32x4 mk0 = pb_u32x4{0u, 0u, 0u, 0u}, mk1 = mk0;
+      if constexpr (DOE && DROP) {
+        const pb_u32x4* mp = reinterpret_cast<const pb_u32x4*>(sMask + ((((s & 1) * 4 + grp) * 32 + r32) * 2 + half) * 16);
+        mk0 = mp[0]; mk1 = mp[1];
+      }
+      const f2 b1 = f2{cb1, cb1};
       // dy[pair, hid] = sum_c g[pair, c] W2[c, hid] on the matrix cores: B operand = this lane's column of W2 (k = class:
       // lanes 0-31 hold (w0, w1, w2, 0 ...), lanes 32-63 the zero half), same accumulator layout as z
       f32x16_t dy;
@@ -405,20 +414,22 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         if constexpr (DOE) {
           constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
           const int row0 = rowc + 4 * half;
-          const f2 zz = f2{zr[r0], zr[r0 + 1]} + b1;
+          f2 zz = f2{zr[r0], zr[r0 + 1]} + b1;
+          if constexpr (DROP) {
+            // registers r0, r0 + 1 = halves (lo, hi) of dword r0 / 2 of the 16 f16 addends
+            const uint32_t mw = (J < 4) ? (J == 0 ? mk0.x : J == 1 ? mk0.y : J == 2 ? mk0.z : mk0.w)
+                                        : (J == 4 ? mk1.x : J == 5 ? mk1.y : J == 6 ? mk1.z : mk1.w);
+            asm volatile("v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mix_f32 %1, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                         : "+v"(zz.x), "+v"(zz.y) : "v"(mw));
+          }
           const f2 t = zz * nl2e;
           const f2 den = f2{__builtin_amdgcn_exp2f(t.x) + 1.f, __builtin_amdgcn_exp2f(t.y) + 1.f};
           const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
           const f2 y = zz * sg;
           // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
-          f2 dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
-          if constexpr (DROP) {
-            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)mws, rowc, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)mws, rowc + 1, 1);
-            yv[r0] = __uint_as_float(__float_as_uint(y.x) & m0); yv[r0 + 1] = __uint_as_float(__float_as_uint(y.y) & m1);
-            dzv = f2{__uint_as_float(__float_as_uint(dzv.x) & m0), __uint_as_float(__float_as_uint(dzv.y) & m1)};
-          } else {
-            yv[r0] = y.x; yv[r0 + 1] = y.y;
-          }
+          const f2 dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
+          yv[r0] = y.x; yv[r0 + 1] = y.y;
           sbx += dzv.x; sby += dzv.y;
           const float give = odd ? dzv.x : dzv.y;
           const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
@@ -435,8 +446,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       issue(std::integral_constant<int, 0>{}, fa);
       pre();                          // (may stage the next head's dlogits: gA / gT change here)
       if constexpr (DOE) {
-        const float m = half ? 0.f : 1.f;
-        const pb_u32x4 w2f = pb_u32x4{pack_bf16x2(cw.x * m, cw.y * m), pack_bf16x2(cw.z * m, 0.f), 0u, 0u};
+        const pb_u32x4 w2f = pb_u32x4{half ? 0u : cw2.x, half ? 0u : cw2.y, 0u, 0u};
         pb_mma(gA, w2f, dy);
       }
       landed(fa);
@@ -503,28 +513,22 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
     T* dz_row = p.dz + row * ncol + 8 * half;
     __syncthreads();                                          // matches the producers' barrier
     const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
-    const uint32_t drop_base = (uint32_t)(mypair * (ncol / 4)) + 4u * (uint32_t)half;
+    const uint32_t drop_base = (uint32_t)(mypair * nslab * 2) + (uint32_t)half;
+    // this lane's pair as the producers see it: accumulator register r of the lanes of half hp, R = (r & 3) + 8 (r >> 2) + 4 hp
+    const int mreg = (r32 & 3) + 4 * (r32 >> 3), mhp = (r32 >> 2) & 1;
     for (int s = -1; s <= nslab; ++s) {
       top();
       if constexpr (DROP) {
-        // keep bits of slab s + 1 for the producers' E(s + 1): lane = (pair r32 of the group, hidden units 16 half .. + 15) =
-        // four word pairs of the forward's hash; a compare yields the 64-lane ballot = [pairs of unit k | pairs of unit 16 + k],
-        // i.e. the producers' words (bit = pair) for free
+        // addends of slab s + 1 for the producers' E(s + 1): lane = (pair r32 of the group, half) walks the forward's chain of
+        // 16 fields = units 8g + 4 half + e and stores one f16 per unit at [unit][half of the pair's register][register]
         if (s + 1 < nslab) {
-          // word pair u = (unit u | unit 16 + u) of the slab, written by lane 0 straight from the ballot's scalar registers
-          // (v_writelane of a compare result needs wait states the compiler does not see inside inline asm: measured wrong
-          // words for a few units)
-          uint2* mw = reinterpret_cast<uint2*>(sMask + (((s + 1) & 1) * 4 + grp) * 32);
+          _Float16* mrow = sMask + ((((s + 1) & 1) * 4 + grp) * 32 * 2 + mhp) * 16 + mreg;
+          uint32_t st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(s + 1));
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            uint32_t w0, w1;
-            pair_drop_words(drop_key, drop_base + (uint32_t)((s + 1) * 8 + q), w0, w1);
-            const unsigned long long k0 = __ballot((w0 & 0xffffu) >= p.drop_thr16), k1 = __ballot((w0 >> 16) >= p.drop_thr16);
-            const unsigned long long k2 = __ballot((w1 & 0xffffu) >= p.drop_thr16), k3 = __ballot((w1 >> 16) >= p.drop_thr16);
-            if (lane == 0) {
-              mw[4 * q + 0] = make_uint2((uint32_t)k0, (uint32_t)(k0 >> 32)); mw[4 * q + 1] = make_uint2((uint32_t)k1, (uint32_t)(k1 >> 32));
-              mw[4 * q + 2] = make_uint2((uint32_t)k2, (uint32_t)(k2 >> 32)); mw[4 * q + 3] = make_uint2((uint32_t)k3, (uint32_t)(k3 >> 32));
-            }
+          for (int i = 0; i < 16; ++i) {
+            st = pair_drop_step(st);
+            const int unit = 8 * (i >> 2) + 4 * half + (i & 3);
+            mrow[unit * 32] = (st >> 16) >= p.drop_thr16 ? (_Float16)0.f : (_Float16)(-30000.f);
           }
         }
       }
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
 template <int KS, bool DROP>
 static int launch_pair_bwd_ws(const PairBwdParams& p, hipStream_t st) {
   const int ncol = p.a.num_heads * p.D;
-  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 16 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)2 * 4 * 32 * 4;
+  const size_t sh = (size_t)4 * KS * 1024 + (size_t)ncol * 12 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)2 * 4 * 32 * 32 * 2;
   if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (sh > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_ws_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
     w2p0 = pack_frag8<T>(zero); w2p1 = w2p0;
   }
   const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
-  const uint32_t drop_base = (uint32_t)(mypair * (p.num_heads * D / 4)) + (uint32_t)half;
+  const uint32_t drop_base = (uint32_t)(mypair * nslab * 2) + (uint32_t)half;
   auto second_layer = [&](const f32x16_t& zz, int bias_slab, const Frag<T>& wa_, const Frag<T>& wb_) {
     float y[16];
 #pragma unroll
@@ -353,16 +353,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
       }
     }
     if constexpr (DROP) {
-      // K12 dropout (peneo_decoder.py:261): rows 8g + 4 half + 0..3 of the slab = one aligned group of four hidden units of
-      // this lane's pair = the four 16-bit fields of one word pair; the 1 / (1 - p) factor is applied to the logits
+      // K12 dropout (peneo_decoder.py:261): this lane's 16 hidden units of the slab (rows 8g + 4 half + e, y[4g + e]) are the
+      // 16 fields of ONE chain (common.h); the 1 / (1 - p) factor is applied to the logits
+      uint32_t st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)bias_slab);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint32_t w0, w1;
-        pair_drop_words(drop_key, drop_base + (uint32_t)(bias_slab * 8 + 2 * g), w0, w1);
-        y[4 * g + 0] = (w0 & 0xffffu) >= p.drop_thr16 ? y[4 * g + 0] : 0.f;
-        y[4 * g + 1] = (w0 >> 16) >= p.drop_thr16 ? y[4 * g + 1] : 0.f;
-        y[4 * g + 2] = (w1 & 0xffffu) >= p.drop_thr16 ? y[4 * g + 2] : 0.f;
-        y[4 * g + 3] = (w1 >> 16) >= p.drop_thr16 ? y[4 * g + 3] : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        st = pair_drop_step(st);
+        y[i] = (st >> 16) >= p.drop_thr16 ? y[i] : 0.f;
       }
     }
     Frag<T> y0 = pack_frag8<T>(y), y1 = pack_frag8<T>(y + 8);
@@ -630,7 +627,7 @@ __global__ __launch_bounds__(256) void pair_dz_kernel(T* z, int64_t npairs, DzPa
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float sg = sigmoid_f(zv[e]);
-            const float keep = (!thr16 || pair_drop_keep(dkey, a.drop_pair0 + r, col + e, ncol / 4, thr16)) ? dscale : 0.f;
+            const float keep = (!thr16 || pair_drop_keep(dkey, a.drop_pair0 + r, col + e, ncol / 32, thr16)) ? dscale : 0.f;
             const float y = zv[e] * sg * keep;
             const float dy = fmaf(g[u][2], w2[2][e], fmaf(g[u][1], w2[1][e], g[u][0] * w2[0][e]));
             const float dz = dy * keep * (sg * fmaf(zv[e], 1.f - sg, 1.f));
@@ -1015,8 +1012,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
             // the forward's classifier dropout, one hash per element (this chunked kernel is the path of the widths the
             // batch kernel peneo_pair_bwd_fused does not cover: D = 512)
             const int64_t gp0 = p.a.drop_pair0 + lp0 + row0;
-            const f2 kk = f2{pair_drop_keep(drop_key, gp0, es * 32 + (lane & 31), ncol / 4, drop_thr) ? drop_scale : 0.f,
-                             pair_drop_keep(drop_key, gp0 + 1, es * 32 + (lane & 31), ncol / 4, drop_thr) ? drop_scale : 0.f};
+            const f2 kk = f2{pair_drop_keep(drop_key, gp0, es * 32 + (lane & 31), ncol / 32, drop_thr) ? drop_scale : 0.f,
+                             pair_drop_keep(drop_key, gp0 + 1, es * 32 + (lane & 31), ncol / 32, drop_thr) ? drop_scale : 0.f};
             dz = dz * kk;
             const f2 ym = y * kk;
             s0 = __builtin_elementwise_fma(g0, ym, s0); s1 = __builtin_elementwise_fma(g1, ym, s1); s2 = __builtin_elementwise_fma(g2, ym, s2);
@@ -1165,7 +1162,7 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
   PENEO_REQUIRE(p.total_classes <= NCP, "peneo_pair_heads_fwd: more than %d classes in total", NCP);
   p.wp = desc->w_packed; p.b1 = desc->b1; p.b2 = desc->b2;
   PENEO_REQUIRE(desc->drop_p >= 0.f && desc->drop_p < 1.f, "peneo_pair_heads_fwd: drop_p must be in [0, 1)");
-  PENEO_REQUIRE((int64_t)p.P * (desc->num_heads * desc->D / 4) < ((int64_t)1 << 32), "peneo_pair_heads_fwd: pair space too large for the dropout counter");
+  PENEO_REQUIRE((int64_t)p.P * (desc->num_heads * desc->D / 16) < ((int64_t)1 << 32), "peneo_pair_heads_fwd: pair space too large for the dropout counter");
   p.drop_thr16 = pair_drop_thr16_host(desc->drop_p); p.drop_seed = desc->drop_seed;
   p.drop_scale = p.drop_thr16 ? 65536.f / (65536.f - (float)p.drop_thr16) : 1.f;
   for (int h = 0; h < desc->num_heads; ++h) {

@@ -1,5 +1,5 @@
 """Host restatement (numpy, 64-bit arithmetic masked to 32 bits) of the counter-based mask of the classifier dropout
-(peneo_amd/csrc/common.h: pair_drop_key / pair_drop_words): keep(b, p, n) for document b, packed pair index p, hidden
+(peneo_amd/csrc/common.h: pair_drop_key / pair_drop_seed / pair_drop_step): keep(b, p, n) for document b, packed pair index p, hidden
 column n of the [B, P, nh * D] classifier hidden (model/peneo_decoder.py:261).  Test infrastructure."""
 import numpy as np
 import torch
@@ -32,12 +32,18 @@ def k12_keep(seed: int, b: int, p0: int, p1: int, ncol: int, p: float) -> torch.
     thr = k12_threshold(p)
     if thr == 0:
         return torch.ones((p1 - p0, ncol), dtype=torch.bool)
+    nslab = ncol // 32
     key = _mix32(np.array([(seed ^ (((b + 1) * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF], dtype=np.uint64))[0]
-    pp = np.arange(p0, p1, dtype=np.uint64)[:, None]
-    g = np.arange(ncol // 4, dtype=np.uint64)[None, :]
-    x = ((pp * _u(ncol // 4) + g) & _M) ^ key
+    pp = np.arange(p0, p1, dtype=np.uint64)[:, None, None]
+    sl = np.arange(nslab, dtype=np.uint64)[None, :, None]
+    hh = np.arange(2, dtype=np.uint64)[None, None, :]
+    x = ((((pp * _u(nslab) + sl) * _u(2) + hh)) & _M) ^ key
     x ^= x >> _u(16); x = _mul24(x, 0x9E3779); x ^= x >> _u(13); x = _mul24(x, 0x85EBCB); x ^= x >> _u(16)
-    w0 = x
-    w1 = _mul24(w0 ^ (w0 >> _u(11)), 0xC2B2AF) ^ (w0 >> _u(9))
-    f = np.stack([w0 & _u(0xFFFF), w0 >> _u(16), w1 & _u(0xFFFF), w1 >> _u(16)], -1).reshape(p1 - p0, ncol)
-    return torch.from_numpy(f >= thr)
+    out = np.zeros((p1 - p0, nslab, 32), dtype=bool)
+    st = x
+    for i in range(16):
+        st = (_mul24(st, 0xC2B2AF) + _u(0x9E3779)) & _M
+        g, e = i >> 2, i & 3
+        for h in range(2):
+            out[:, :, 8 * g + 4 * h + e] = (st[:, :, h] >> _u(16)) >= thr
+    return torch.from_numpy(out.reshape(p1 - p0, ncol))

@@ -45,5 +45,33 @@ def main(p=0.1, T=709, rows=2000, seed=12345):
               f"per key {keep.sum(0).std():.2f} (binomial {np.sqrt(rows * p * (1 - p)):.2f});  noise floor of a correlation ~ {1 / np.sqrt(k.size):.4f}")
 
 
+def k12(p=0.1, P=3000, nslab=60, seed=12345):
+    """The classifier-dropout mask (common.h: pair_drop_seed / pair_drop_step): one mix24 seed per (pair, slab, half), 16
+    fields by a 24-bit multiply-add chain.  Keep rate, correlations along the chain (lag 1..3), across halves (lag 4),
+    groups (lag 8), slabs (lag 32) and pairs, joint probabilities of neighbours, count statistics."""
+    key = int(mix32(np.array([(seed ^ 0x9E3779B9) & 0xFFFFFFFF], dtype=np.uint64))[0])
+    pp = np.arange(P, dtype=np.uint64)[:, None, None]; sl = np.arange(nslab, dtype=np.uint64)[None, :, None]
+    hh = np.arange(2, dtype=np.uint64)[None, None, :]
+    st = mix24((((pp * u(nslab) + sl) * u(2) + hh) & M) ^ u(key))
+    f = np.zeros((P, nslab, 32), dtype=np.uint64)
+    for i in range(16):
+        st = (((st & u(0xFFFFFF)) * u(0xC2B2AF)) + u(0x9E3779)) & M
+        for h in range(2):
+            f[:, :, 8 * (i >> 2) + 4 * h + (i & 3)] = st[:, :, h] >> u(16)
+    f = f.reshape(P, nslab * 32)
+    th = round(p * 65536)
+    keep = f >= th
+    k = keep.astype(float) - keep.mean()
+    c = lambda a, b: float((a * b).mean() / k.var())
+    print(f"K12 chain: keep {keep.mean():.5f}, want {1 - th / 65536:.5f}")
+    print("   corr along units: " + " ".join(f"lag{l} {c(k[:, :-l], k[:, l:]):+.5f}" for l in (1, 2, 3, 4, 8, 16, 32)) +
+          f";  next pair {c(k[:-1], k[1:]):+.5f};  noise floor ~ {1 / np.sqrt(k.size):.5f}")
+    print(f"   P(keep, keep) {float((keep[:, :-1] & keep[:, 1:]).mean()):.5f} (independent {keep.mean() ** 2:.5f}), "
+          f"P(drop, drop) {float((~keep[:, :-1] & ~keep[:, 1:]).mean()):.5f} ({(1 - keep.mean()) ** 2:.5f})")
+    print(f"   keep-count std per pair {keep.sum(1).std():.2f} (binomial {np.sqrt(nslab * 32 * p * (1 - p)):.2f}), per unit "
+          f"{keep.sum(0).std():.2f} ({np.sqrt(P * p * (1 - p)):.2f})")
+
+
 if __name__ == "__main__":
     main()
+    k12()
