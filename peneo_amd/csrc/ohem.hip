@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void ohem_ce_kernel(const float* logits, const
     for (int c = 1; c < C; ++c) mx = fmaxf(mx, l[c]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(l[c] - mx);      // full-precision exp / log: the ORDER of the losses is the result
-    const float w = cw ? cw[tag] : 1.f;
-    const float v = w * (logf(se) - (l[tag] - mx));          // -log_softmax(l)[tag], grouped like torch's log_softmax
+    // ignore_index (-100, custom_loss.py:236-243: F.cross_entropy(..., ignore_index) gives such a pair zero loss while the
+    // `target != 0` test still files it under the positives) and any other label outside [0, C) (memory safety): zero loss
+    const bool valid = tag >= 0 && tag < C;
+    const float w = !valid ? 0.f : (cw ? cw[tag] : 1.f);
+    const float v = valid ? w * (logf(se) - (l[tag] - mx)) : 0.f;   // -log_softmax(l)[tag], grouped like torch's log_softmax
     const uint32_t pos = tag != 0;
     ce[p] = v;
     flag[p] = pos;

@@ -171,7 +171,8 @@ __device__ __forceinline__ void pair_epilogue(const PairFwdParams& p, const f32x
           float lt = 0.f;
 #pragma unroll
           for (int c = 0; c < 4; ++c) lt = (c == tag) ? l[c] : lt;
-          const float w = p.cw[h] ? p.cw[h][tag] : 1.f;
+          // labels outside [0, C) (the reference's ignore_index = -100 among them) carry zero weight: no loss, no gradient
+          const float w = (tag < 0 || tag >= C) ? 0.f : (p.cw[h] ? p.cw[h][tag] : 1.f);
           num[h] = w * (lse - lt);
           den[h] = w;
           const float inv = 1.f / se;
@@ -707,8 +708,9 @@ __global__ void weighted_ce_kernel(const float* logits, const int64_t* tags, con
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += __expf(l[c] - mx);
     const float lse = mx + __logf(se);
-    const float w = cw ? cw[tag] : 1.f;
-    n += w * (lse - l[tag]);
+    const bool valid = tag >= 0 && tag < C;                 // ignore_index / garbage labels: zero weight
+    const float w = !valid ? 0.f : (cw ? cw[tag] : 1.f);
+    n += valid ? w * (lse - l[tag]) : 0.f;
     d += w;
     if (dlogits)
       for (int c = 0; c < C; ++c) dlogits[r * C + c] = w * (__expf(l[c] - lse) - (c == tag ? 1.f : 0.f));

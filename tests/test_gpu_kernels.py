@@ -896,6 +896,14 @@ def test_weighted_ce_and_spots(ops):
     ls = F.cross_entropy(lr, tags, weight=cw, reduction="sum")
     ls.backward()
     assert abs(float(num) - float(ls)) / float(ls) < 1e-5 and rel_err(dl.cpu(), lr.grad) < 1e-5
+    # ignore_index (-100) rows carry no loss, no weight and no gradient, like F.cross_entropy(ignore_index=-100)
+    tags_i = tags.clone(); tags_i[::7] = -100
+    num_i, den_i, dl_i = ops.weighted_ce(logits.to(DEV), tags_i.to(DEV), cw.to(DEV), want_dlogits=True)
+    lr2 = logits.clone().requires_grad_(True)
+    ls2 = F.cross_entropy(lr2, tags_i, weight=cw, reduction="sum", ignore_index=-100)
+    ls2.backward()
+    assert abs(float(num_i) - float(ls2)) / float(ls2) < 1e-5 and rel_err(dl_i.cpu(), lr2.grad) < 1e-5
+    assert abs(float(den_i) - float(cw[tags_i[tags_i >= 0]].sum())) < 1e-3
     spots, scores = ops.spots_compact(logits.to(DEV), N, max_spots=16)  # forces the regrow path
     ref = O.spots_from_logits(logits)
     assert [tuple(r) for r in spots.cpu().tolist()] == [(i, j, t) for i, j, t, _ in ref]

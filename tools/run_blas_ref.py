@@ -32,3 +32,6 @@ for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
     bench(f"fwd [{R},{K}]x[{N},{K}]^T torch", lambda: torch.mm(a, w.t()), f2)
     bench(f"wgrad -> [{N},{K}] peneo", lambda: ops.gemm(dy, a, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32), f2)
     bench(f"wgrad -> [{N},{K}] torch", lambda: torch.mm(dy.t(), a), f2)
+    # dgrad of the same layer: dx [R, K] = dy [R, N] . W [N, K]  (B mn-major)
+    bench(f"dgrad [{R},{N}]x[{N},{K}] peneo", lambda: ops.gemm(dy, w, b_kmajor=False), f2)
+    bench(f"dgrad [{R},{N}]x[{N},{K}] torch", lambda: torch.mm(dy, w), f2)
