@@ -176,6 +176,18 @@ __device__ __forceinline__ uint32_t pair_drop_thr16_dev(float p) { return p > 0.
 // 2^16 / (2^16 - thr16), so the mask is unbiased for the probability it really uses
 inline uint32_t pair_drop_thr16_host(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
 inline float pair_drop_scale_host(float p) { const uint32_t t = pair_drop_thr16_host(p); return t ? 65536.f / (65536.f - (float)t) : 1.f; }
+// Kernels whose lane owns ONE hidden unit (chain position i) and walks many pairs jump to that position: the 24-bit state
+// after i steps is affine in the seed, st_i[23:0] = (A^i st_0 + C_i) mod 2^24, so an element costs the seed + two multiply-adds.
+struct PairDropJump { uint32_t a, c; };
+__device__ __forceinline__ PairDropJump pair_drop_jump(int i /* chain position 0..15 */) {
+  uint32_t a = 1u, c = 0u;
+  for (int k = 0; k < i; ++k) { a = (a * 0xC2B2AFu) & 0xFFFFFFu; c = (c * 0xC2B2AFu + 0x9E3779u) & 0xFFFFFFu; }
+  return PairDropJump{a, c};
+}
+__device__ __forceinline__ bool pair_drop_keep_at(uint32_t seedword, PairDropJump j, uint32_t thr16) {
+  const uint32_t si = __umul24(seedword, j.a) + j.c;            // low 24 bits = state after i steps
+  return (pair_drop_step(si) >> 16) >= thr16;
+}
 // one element (the chunked / fp32 kernels, where speed does not matter): n = column in [0, nslab * 32)
 __device__ __forceinline__ bool pair_drop_keep(uint32_t key, int64_t pair, int n, int nslab, uint32_t thr16) {
   const int slab = n >> 5, w = n & 31, half = (w >> 2) & 1, i = 4 * (w >> 3) + (w & 3);

@@ -272,6 +272,11 @@ static int g_big_mode = -1;   // PENEO_GEMM_BIG: 0 = off, 1 = auto (default), 25
 int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   if (g_big_mode < 0) { const char* e = getenv("PENEO_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
   if (g_big_mode == 0) return 0;
+  // mn-major B = the dgrad GEMMs of the backward: in the step they run beside the weight-gradient stream, and a workgroup that
+  // needs a CU's whole LDS cannot share it (measured: d_zi on 384 x 192 tiles 50 us alone, 166 us in the step; the step is
+  // 0.2 ms FASTER with the 128 x 128 kernel there).  PENEO_GEMM_BIG_NN=1 for stand-alone measurements.
+  static const bool nn_ok = getenv("PENEO_GEMM_BIG_NN") && atoi(getenv("PENEO_GEMM_BIG_NN")) != 0;
+  if (!b_kmajor && !nn_ok && g_big_mode == 1) return 0;
   if (p.split_k > 1 || p.dz_on || p.K % 64 != 0 || p.K < 128 || p.N % 8 != 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) return 0;
   if ((p.lda * 2) % 16 != 0 || (p.ldb * 2) % 16 != 0) return 0;
@@ -294,7 +299,8 @@ int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
     double best = c256;
     if (c384 < best) { best = c384; pick = 384; }
     if (c128 < best) { best = c128; pick = 128; }
-    if (best > 0.98 * small_cost(p.M, p.N)) return 0;
+    static const double margin = getenv("PENEO_GEMM_BIG_MARGIN") ? atof(getenv("PENEO_GEMM_BIG_MARGIN")) : 0.95;
+    if (best > margin * small_cost(p.M, p.N)) return 0;
   }
   if (b_kmajor) {
     if (pick == 384) return launch_big<Big384<true>>(p, st);

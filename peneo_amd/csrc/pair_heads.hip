@@ -848,6 +848,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
   const uint32_t drop_thr = pair_drop_thr16_dev(p.a.drop_p);
   const uint32_t drop_key = pair_drop_key(p.a.drop_seed, p.a.drop_doc);
   const float drop_scale = drop_thr ? 65536.f / (65536.f - (float)drop_thr) : 1.f;
+  const uint32_t drop_half = ((lane & 31) >> 2) & 1;                                  // unit w = lane & 31 of every slab:
+  const PairDropJump drop_jump = pair_drop_jump(4 * ((lane & 31) >> 3) + (lane & 3));  // half (w >> 2) & 1, position 4 (w >> 3) + (w & 3)
 
   for (int n = tid; n < ncol; n += PH_WAVES * 64) {
     const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
@@ -1013,9 +1015,10 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
           if (drop_thr) {
             // the forward's classifier dropout, one hash per element (this chunked kernel is the path of the widths the
             // batch kernel peneo_pair_bwd_fused does not cover: D = 512)
-            const int64_t gp0 = p.a.drop_pair0 + lp0 + row0;
-            const f2 kk = f2{pair_drop_keep(drop_key, gp0, es * 32 + (lane & 31), ncol / 32, drop_thr) ? drop_scale : 0.f,
-                             pair_drop_keep(drop_key, gp0 + 1, es * 32 + (lane & 31), ncol / 32, drop_thr) ? drop_scale : 0.f};
+            // the forward's classifier dropout: this lane's unit sits at a fixed chain position, its pairs vary
+            const uint32_t cnt0 = (uint32_t)(((p.a.drop_pair0 + lp0 + row0) * nslab + es) * 2) + drop_half;
+            const f2 kk = f2{pair_drop_keep_at(pair_drop_seed(drop_key, cnt0), drop_jump, drop_thr) ? drop_scale : 0.f,
+                             pair_drop_keep_at(pair_drop_seed(drop_key, cnt0 + 2u * (uint32_t)nslab), drop_jump, drop_thr) ? drop_scale : 0.f};
             dz = dz * kk;
             const f2 ym = y * kk;
             s0 = __builtin_elementwise_fma(g0, ym, s0); s1 = __builtin_elementwise_fma(g1, ym, s1); s2 = __builtin_elementwise_fma(g2, ym, s2);

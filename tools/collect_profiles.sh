@@ -11,6 +11,7 @@ bash tools/pmc_traffic.sh pair_bwd_ws_kernel tools/run_pair_bwd_once.py > $OUT/p
 bash tools/pmc_traffic.sh pair_heads_fwd tools/run_pair.py > $OUT/pmc_pair_fwd.txt 2>&1
 python tools/run_pair_bwd.py > $OUT/pair_bwd_kernel.txt 2>&1
 python bench.py --backbone lilt --no-cpu-baseline > $OUT/lilt_line.json 2>/dev/null
+python bench.py --vocab 250002 --no-cpu-baseline --no-ragged > $OUT/xlmr_vocab_line.json 2>/dev/null
 python bench.py --size large --seq-len 1024 --lines 256 --docs-per-gpu 2 --no-cpu-baseline > $OUT/large_line.json 2>/dev/null
 python bench.py --dtype fp32 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fp32_line.json 2>/dev/null
 python tools/run_phases.py > $OUT/phases.txt 2>&1
