@@ -19,7 +19,7 @@ dz = torch.empty(B * rows, nh * D, device=dev, dtype=dt)
 x = torch.empty(B * rows, D, device=dev, dtype=dt)
 d_ab = torch.zeros(B, N, 2 * D, device=dev)
 ws = ops.pair_dz_workspace(nh, D, dev, slots=256)
-args = ops.pair_dz_args(D, classes, dl, w2, scale)
+args = ops.pair_dz_args(D, classes, dl, w2, scale, drop_p=0.1, drop_seed=1234)   # train step: the forward's classifier dropout regenerated
 for _ in range(3):
     ops.pair_bwd_fused(ab, wp2, b1, args, dz, x, d_ab, ws)
 torch.cuda.synchronize()
