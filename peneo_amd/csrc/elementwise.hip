@@ -251,8 +251,37 @@ __global__ __launch_bounds__(256) void adamw_kernel(const peneo_adamw_tensor* ta
   }
 }
 
+// Many fp32 -> bf16 casts in ONE launch (the working-precision copies of a model's weights after an optimizer step): block =
+// one CAST_MULTI_CHUNK-element chunk of one tensor, table and chunk maps as for adamw_kernel
+constexpr int CAST_MULTI_CHUNK = 16384;
+__global__ __launch_bounds__(256) void cast_multi_kernel(const peneo_cast_item* tab, const int32_t* chunk_item, const int32_t* chunk_index) {
+  const peneo_cast_item t = tab[chunk_item[blockIdx.x]];
+  const int64_t base = (int64_t)chunk_index[blockIdx.x] * CAST_MULTI_CHUNK;
+  const int64_t end = min(t.numel, base + CAST_MULTI_CHUNK);
+  bf16_t* dst = reinterpret_cast<bf16_t*>(t.dst);
+  const bool vec = ((reinterpret_cast<uintptr_t>(t.src) | reinterpret_cast<uintptr_t>(t.dst)) & 15) == 0;
+  for (int64_t i = base + threadIdx.x * 8; i < end; i += 256 * 8) {
+    if (vec && i + 8 <= end) {
+      float f[8];
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(t.src + i);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(t.src + i + 4);
+      *reinterpret_cast<uint4*>(dst + i) = pack16<bf16_t>(f);
+    } else {
+      for (int64_t e = i; e < min(end, i + 8); ++e) dst[e] = f32_to_bf16(t.src[e]);
+    }
+  }
+}
+
 }  // namespace peneo
 using namespace peneo;
+
+extern "C" int peneo_cast_multi_chunk_elems(void) { return CAST_MULTI_CHUNK; }
+extern "C" int peneo_cast_multi(const peneo_cast_item* table_dev, const int32_t* chunk_item_dev, const int32_t* chunk_index_dev,
+                                int n_chunks, peneo_stream_t stream) {
+  PENEO_REQUIRE(table_dev && chunk_item_dev && chunk_index_dev && n_chunks > 0, "peneo_cast_multi: bad arguments");
+  hipLaunchKernelGGL(cast_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, chunk_item_dev, chunk_index_dev);
+  return check_launch("peneo_cast_multi");
+}
 
 extern "C" int peneo_adamw_chunk_elems(void) { return ADAMW_CHUNK; }
 

@@ -40,6 +40,10 @@ class GemmProblem(C.Structure):
                 ("accumulate", _i)]
 
 
+class CastItem(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("numel", _i64)]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("numel", _i64), ("lr", _f),
                 ("weight_decay", _f), ("step_offset", _i), ("reserved", _i)]
@@ -79,6 +83,8 @@ SIGNATURES = {
     "peneo_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _i64, _vp, _i64, _i, C.POINTER(GemmEpilogue), _i, _vp,
                         _sz, _vp]),
     "peneo_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    "peneo_cast_multi_chunk_elems": (_i, []),
+    "peneo_cast_multi": (_i, [_vp, _vp, _vp, _i, _vp]),
     "peneo_copy2d": (_i, [_i, _vp, _i64, _vp, _i64, _i64, _i64, _f, _u32, _vp]),
     "peneo_copy_rows": (_i, [_i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _f, _u32, _vp]),
     "peneo_head_concat": (_i, [_i, _vp, _i64, _i, _f, _vp, _i64, _i, _f, _vp, _i64, _i64, _i, _vp]),

@@ -155,6 +155,35 @@ def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = No
     return out
 
 
+class CastPlan:
+    """Device tables of a fixed set of (fp32 source, bf16 destination) pairs for ``peneo_cast_multi``: built once, launched
+    whenever the sources have changed."""
+
+    def __init__(self, pairs: Sequence[Tuple[torch.Tensor, torch.Tensor]]):
+        import numpy as np
+        chunk = int(lib().peneo_cast_multi_chunk_elems())
+        items = (hip.CastItem * len(pairs))()
+        ci, cx = [], []
+        for k, (src, dst) in enumerate(pairs):
+            assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.is_contiguous() and dst.is_contiguous()
+            assert src.numel() == dst.numel()
+            items[k].src, items[k].dst, items[k].numel = src.data_ptr(), dst.data_ptr(), src.numel()
+            n = (src.numel() + chunk - 1) // chunk
+            ci += [k] * n
+            cx += list(range(n))
+        dev = pairs[0][0].device
+        raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(dev)
+        self.chunk_item = torch.tensor(ci, dtype=torch.int32, device=dev)
+        self.chunk_index = torch.tensor(cx, dtype=torch.int32, device=dev)
+        self.n_chunks = len(ci)
+        self.keep = list(pairs)                     # the tensors whose addresses the table holds
+
+    def run(self) -> None:
+        check(lib().peneo_cast_multi(ptr(self.table), ptr(self.chunk_item), ptr(self.chunk_index), self.n_chunks, stream()),
+              "peneo_cast_multi")
+
+
 def copy2d(src: torch.Tensor, out: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     assert src.dim() == 2 and src.stride(1) == 1
     if out is None:

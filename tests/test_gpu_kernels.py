@@ -612,6 +612,25 @@ def test_gemm_big_tiles_match_fp32_matmul(ops, mode, bk):
         lib.peneo_gemm_set_big_mode(1)
 
 
+def test_cast_multi_equals_single_casts(ops):
+    """peneo_cast_multi (all weight copies of a step in one launch) == peneo_cast tensor by tensor, ragged sizes included."""
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in (768 * 768, 16384, 16385, 7, 3072 * 768 + 24, 1)]
+    whole = torch.zeros(sum(t.numel() for t in srcs) + 64, dtype=torch.bfloat16, device=DEV)
+    dsts, off = [], 0
+    for t in srcs:
+        dsts.append(whole[off:off + t.numel()])
+        off += (t.numel() + 7) // 8 * 8
+    plan = ops.CastPlan(list(zip(srcs, dsts)))
+    plan.run()
+    for t, d in zip(srcs, dsts):
+        assert torch.equal(d, t.to(torch.bfloat16))
+    assert float(whole[off:].abs().max()) == 0
+    srcs[2].mul_(3.0)
+    plan.run()                                               # same tables, new values
+    assert torch.equal(dsts[2], srcs[2].to(torch.bfloat16))
+
+
 # ---------------------------------------------------------------------------------------------- pair heads
 def _pair_ref(ab, w1, b1, w2, b2):
     B, N, D2 = ab.shape

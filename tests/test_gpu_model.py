@@ -388,6 +388,30 @@ def test_deferred_joins_do_not_change_the_gradients(name):
     assert exact > len(a1) // 2
 
 
+def test_working_weights_follow_the_parameters():
+    """The bf16 working copies (one multi-tensor cast for the encoder layers, lazy casts / packs elsewhere) are rebuilt when a
+    parameter changes, through `.data` writes + epoch bump (FusedAdamW) as well as through versioned in-place ops (torch
+    optimizers), and reused otherwise: outputs must equal those of a freshly built model with the same weights."""
+    from peneo_amd.model.engine import bump_param_epoch
+    fx = load_golden("lmv3_tiny")
+    b = to_cuda(fx["batch"])
+    m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()
+    with torch.no_grad():
+        l0 = float(m(**b)["loss"])
+        assert float(m(**b)["loss"]) == l0                              # cached copies
+        w = m.backbone.encoder.layer[1].intermediate.dense.weight
+        w.mul_(1.5)                                                    # versioned in-place update
+        l1 = float(m(**b)["loss"])
+        w.data.mul_(1.0 / 1.5); w.data.mul_(1.25)                      # unversioned writes + the optimizer's epoch bump
+        m.peneo_decoder.ent_linking_h2h_fc[0].weight.data.mul_(0.5)
+        bump_param_epoch()
+        l2 = float(m(**b)["loss"])
+    ref = build_model(fx["config"], {k: v.clone() for k, v in m.state_dict().items()}, torch.bfloat16).eval()
+    with torch.no_grad():
+        l2_ref = float(ref(**b)["loss"])
+    assert l1 != l0 and l2 != l1 and l2 == l2_ref, (l0, l1, l2, l2_ref)
+
+
 def test_fused_adamw_training_steps_reduce_the_loss():
     """Three optimizer steps on one batch with the reference's parameter groups: the C-ABI update must invalidate the
     working-precision weight copies (loss changes and goes down)."""
