@@ -348,22 +348,27 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
     __syncthreads();
     FWD_PREFETCH(t + 1 < ntile ? t + 1 : t)   // unconditional: keeps the staging registers out of scratch
 
-    // S^T[key, q] for the 64 keys of this tile
+    // S^T[key, q] for the 64 keys of this tile; a 32-key block that lies entirely past T (T = 709: the second half of the
+    // twelfth tile) is all masked: its products, exponentials and P.V steps are skipped
+    const bool two = k0 + 32 < Tn;
     f32x16_t s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (kt == 0 || two) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        Frag<T> kf = FragReader<T, DP>::straight(sK, kt * 32 + (lane & 31), 16 * ks + 8 * half);
-        mma_step(kf, qf[ks], s[kt]);
+        for (int ks = 0; ks < KS; ++ks) {
+          Frag<T> kf = FragReader<T, DP>::straight(sK, kt * 32 + (lane & 31), 16 * ks + 8 * half);
+          mma_step(kf, qf[ks], s[kt]);
+        }
       }
     }
     // log2-domain scores, running max
     float mt = MASKED;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two) break;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int kl = kt * 32 + 8 * g + 4 * half;   // 4 consecutive keys: regs 4g .. 4g+3
@@ -376,12 +381,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
           mt = fmaxf(mt, v);
         }
       }
+    }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
     const float alpha = fast_exp2(m_run - m_new);
     float ls = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 1 && !two) break;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {                 // registers (r, r + 1) hold keys (2j, 2j + 1)
         float e0 = fast_exp2(s[kt][r] - m_new), e1 = fast_exp2(s[kt][r + 1] - m_new);
@@ -394,6 +401,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
         s[kt][r] = e0;
         s[kt][r + 1] = e1;
       }
+    }
     ls += __shfl_xor(ls, 32, 64);
     l_run = l_run * alpha + ls;
     m_run = m_new;
@@ -404,6 +412,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
     // O^T[d, q] += V^T[d, key] . P^T[key, q]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+      if (kk == 2 && !two) break;
       float pv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) pv[e] = s[kk >> 1][8 * (kk & 1) + e];
@@ -918,8 +927,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
     FUSED_PREFETCH(t + 1 < ntile ? t + 1 : t)
 
     float* Gt = G ? G + (int64_t)q0 * p.bias_ld + key0 : nullptr;   // uniform tile base; lanes add 32-bit offsets
+    // a query block that lies entirely past T (T = 709: the second half of the twelfth tile) contributes nothing: skipped
+    // (its dS^T columns are zero-filled below)
+    const int nqt = (q0 + 32 < Tn) ? 2 : 1;
 #pragma unroll 1
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < nqt; ++qt) {
       // S[q, key], dP[q, key]: A = Q / dO rows (q), B = K / V fragments (lane = key)
       f32x16_t s, dp;
 #pragma unroll
@@ -994,6 +1006,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
           mma_step(qtf, dsf, dk[t2]);
         }
       }
+    }
+    if (nqt == 1 && half == 0) {   // the skipped query block: its dS^T columns are zero (the padding columns of the slab stay 0)
+      const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sS + keyl * PS + 64 + 16 * i) = z4;
     }
     __syncthreads();   // dS^T tile complete
     if (p.ds_out) {    // this layer's dS^T rows (key-major, 128 B per key and step): the bias-table gradient is reduced from

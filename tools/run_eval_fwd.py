@@ -1,0 +1,17 @@
+"""Eval forward only (B = 8, bf16): the 'encoder + pair-head forward' target of BASELINE.md.  For rocprofv3 --kernel-trace."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from seeded import layoutlmv3_config, peneo_config
+from peneo_amd.model import PEneoConfig, PEneoModel
+from peneo_amd.data import synthetic_rfund_batch
+pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
+m = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"})).cuda().set_compute_dtype(torch.bfloat16).eval()
+m.backbone.check_inputs = False
+bs = [{k: v.cuda() for k, v in synthetic_rfund_batch(8, 512, 128, 50265, seed=s).items()} for s in range(3)]
+with torch.no_grad():
+    for i in range(3): m(**bs[i])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = int(os.environ.get("N", "10"))
+    for i in range(n): m(**bs[i % 3])
+    torch.cuda.synchronize()
+print(f"eval forward {(time.perf_counter() - t0) / n * 1e3:.3f} ms per 8 documents")
