@@ -249,6 +249,13 @@ int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t* bk1, const
  * [B, nh, DP, Tp] (DP = peneo_attn_padded_dim(d), Tp = peneo_attn_padded_len(T)) made by
  * peneo_head_transpose: vt for the forward; kt, qt and dot (= d_out transposed) for the backward.
  * `lse` [B, nh, T] fp32 is the per-row log-sum-exp in log2 units (an opaque forward->backward buffer).
+ *
+ * Dropout on the attention probabilities (modeling_layoutlmv3.py:396-399): the keep bits of one call are made by
+ * peneo_attn_drop_words - a pure function of (seed, word index), Bernoulli(1 - p) per bit with p realised to 2^-17 - into
+ * `words`, uint32 [B * nh][n_query_blocks][n_key_slots] (peneo_attn_drop_words_dims; 64-byte aligned), and handed to the
+ * forward and to the backward of that call (`drop_words`; NULL with drop_p = 0).  One dword holds the 32 queries of a
+ * block for one key; the key slots of a 32-key block are ordered as the forward kernel's accumulator registers see them,
+ * so the kernels read whole select masks instead of hashing per element (csrc/attention.hip, top).
  * ------------------------------------------------------------------------------------------ */
 int peneo_attn_padded_len(int T);
 int peneo_attn_padded_dim(int d);
@@ -258,8 +265,11 @@ int peneo_head_transpose(int dtype, const void* src, int64_t ld, int B, int nh, 
  * be NULL; fp32 needs vt, the per-head transposed copy from peneo_head_transpose (v is then ignored). */
 int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qk, const void* vt,
                    int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
-                   const float* key_bias, void* out, int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed,
+                   const float* key_bias, void* out, int64_t ld_out, float* lse, float drop_p, const uint32_t* drop_words,
                    peneo_stream_t stream);
+void peneo_attn_drop_words_dims(int T, int* n_query_blocks, int* n_key_slots);
+int64_t peneo_attn_drop_words_count(int B, int nh, int T);   /* = B * nh * n_query_blocks * n_key_slots */
+int peneo_attn_drop_words(uint32_t* words, int B, int nh, int T, float drop_p, uint32_t seed, peneo_stream_t stream);
 /* dq/dk/dv share the q/k/v layout (ld_dqkv).  g_bias (fp32 [B, nh, T, bias_ld], may be NULL) is
  * accumulated with dS so the bias-table gradient can be reduced once per step.
  * `delta` is a [B, nh, T] fp32 scratch.
@@ -276,7 +286,7 @@ int peneo_attn_bwd(int dtype, const void* q, const void* k, const void* v, int64
                    const void* out, const void* d_out, int64_t ld_out, const float* lse,
                    int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias,
                    void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta, float* dq_accum,
-                   void* ds_out, float drop_p, uint32_t drop_seed, peneo_stream_t stream);
+                   void* ds_out, float drop_p, const uint32_t* drop_words, peneo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K11 + K12 (+ K13) — handshaking + the pair-classifier heads + class-weighted CE, fused

@@ -29,30 +29,64 @@ constexpr float LOG2E = 1.4426950408889634f;
 // raw v_exp_f32: arguments here are <= 0 (or hugely negative for masked keys), results in [0, 1]; no denormal fix-up needed
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Attention-probability dropout.  keep(q row, key) compares 16 random bits with p * 2^16; ONE hash serves the two keys
-// (2j, 2j + 1) of a query row (low / high half), and the hash mixes with 24-bit multiplies (v_mul_u32_u24, full rate)
-// instead of mix32's two quarter-rate 32-bit multiplies.  With the softmax itself at ~50 VALU cycles per element and wave,
-// the former one-mix32-per-element mask (64 cycles) was the largest single cost of the forward and backward kernels; this
-// one is 24 (forward: both keys of a pair sit in one lane) to 32 (fused backward: lane = key, the pair's hash is
-// computed once per two rows and exchanged between the two lanes by DPP).  Row hashes stay mix32 (one per row).
-// Statistics against mix32 on 1.4 M elements (keep rate, bit balance, correlations along keys / rows / between the
-// halves): indistinguishable (tools/check_dropout_hash.py).  p is realised to 2^-17 (0.1 -> 6554 / 65536).
-__device__ __forceinline__ uint32_t attn_rowhash(uint32_t seed, int64_t rowid) {
-  return mix32(seed ^ ((uint32_t)rowid * 0x9e3779b9u) ^ ((uint32_t)(rowid >> 32) * 0x85ebca6bu));
+// Attention-probability dropout.  The keep bits of a call are made ONCE by peneo_attn_drop_words (one bit per (query, key),
+// Bernoulli(1 - p) from the counter-based chain of the classifier dropout, common.h) and every kernel here READS them:
+//
+//     words[((b * nh + h) * nqb + (q >> 5)) * Tk + attn_kslot(key)]   bit (q & 31)
+//     nqb = 4 * ceil(T / 128) query blocks, Tk = 128 * ceil(T / 128) key slots (peneo_attn_drop_words_dims)
+//
+// One dword = the 32 queries of a block for one key.  attn_kslot orders the 32 keys of a key block the way the forward's
+// accumulator registers see them (lane = query, register r of half-wave hf = key 8 (r / 4) + 4 hf + r % 4): slots 2r and
+// 2r + 1 hold the keys of register r for hf = 0 / 1, so the 64-bit word at slot 2r IS the 64-lane select mask of register r.
+// The forward reads it with a scalar load and masks with one v_cndmask on the SGPR pair - no hash, no compare, one VALU
+// instruction per element (the in-kernel hash it replaces was 8.5 of the kernel's 20 VALU slots per element).  The
+// single-pass backward (lane = key, registers = queries) loads its key's dword per 32-query block and takes register r's
+// bit with one v_bfe_i32 (0 / -1), used as an AND mask on P and on keep_scale.  1 / (1 - p) is applied once to the
+// accumulators (O, dV), not per element.
+__host__ __device__ __forceinline__ int attn_kslot(int key) {
+  return (key & ~31) | (((key >> 3) & 3) << 3) | ((key & 3) << 1) | ((key >> 2) & 1);
 }
-__device__ __forceinline__ uint32_t attn_mix24(uint32_t x) {
-  x ^= x >> 16; x = __umul24(x, 0x9E3779u); x ^= x >> 13; x = __umul24(x, 0x85EBCBu); x ^= x >> 16;
-  return x;
+__device__ __forceinline__ bool attn_word_keep(const uint32_t* words_bh, int Tk, int q, int key) {
+  return (words_bh[(int64_t)(q >> 5) * Tk + attn_kslot(key)] >> (q & 31)) & 1u;
 }
-__device__ __forceinline__ uint32_t attn_thresh16(float p) { return (uint32_t)fminf(rintf(p * 65536.0f), 65535.0f); }
-// the 32 bits shared by keys (key & ~1, key | 1) of the row
-__device__ __forceinline__ uint32_t attn_pairhash(uint32_t rowhash, int key) { return attn_mix24(rowhash ^ ((uint32_t)key >> 1)); }
-__device__ __forceinline__ bool attn_keep(uint32_t rowhash, int key, uint32_t thresh16) {
-  return __builtin_amdgcn_ubfe(attn_pairhash(rowhash, key), (key & 1) * 16, 16) >= thresh16;
+// x where the lane's bit of the 64-bit mask is set, else 0 (mask in an SGPR pair)
+__device__ __forceinline__ float mask_keep(float x, uint64_t m) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+  return r;
 }
-// value of the neighbouring lane (lane ^ 1)
-__device__ __forceinline__ uint32_t lane_swap1(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false);
+// the 64 dwords (32 register masks) of one forward tile -> SGPRs.  Issued by hand at the top of the tile, long before their
+// use: left to the compiler the scalar loads sit right in front of the first use with a full s_waitcnt each (SMEM returns
+// out of order, so every wait is lgkmcnt(0)), and the forward ran SLOWER than with the hash.
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+struct TileMasks { u32x16_t a, b, c, d; };
+__device__ __forceinline__ void tile_masks_load(TileMasks& m, const uint32_t* p) {
+  asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
+               : "=&s"(m.a), "=&s"(m.b), "=&s"(m.c), "=&s"(m.d) : "s"(p));
+}
+__device__ __forceinline__ void tile_masks_wait(TileMasks& m) {   // (the operands tie every later use to this wait)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.a), "+s"(m.b), "+s"(m.c), "+s"(m.d));
+}
+template <int I> __device__ __forceinline__ uint64_t tile_mask(const TileMasks& m) {   // register mask I = 16 kt + r
+  const u32x16_t& v = I < 8 ? m.a : I < 16 ? m.b : I < 24 ? m.c : m.d;
+  return (uint64_t)v[2 * (I & 7)] | ((uint64_t)v[2 * (I & 7) + 1] << 32);
+}
+__device__ __forceinline__ float and_mask(float x, int m) { return __uint_as_float(__float_as_uint(x) & (uint32_t)m); }
+// the running maximum of the online softmax only moves when a tile beats it by more than this (natural units): exponentials
+// stay below e^4 and the rescaling of the accumulators - one multiply per element - is skipped for almost every tile
+constexpr float RESCALE_TAU = 4.0f;
+
+__global__ __launch_bounds__(256) void attn_drop_words_kernel(uint32_t* words, int64_t n, uint32_t thr16, uint32_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    uint32_t st = mix32(seed ^ ((uint32_t)i * 0x9e3779b9u) ^ ((uint32_t)(i >> 32) * 0x85ebca6bu));
+    uint32_t w = 0;
+#pragma unroll
+    for (int bit = 0; bit < 32; ++bit) {
+      st = pair_drop_step(st);
+      w |= ((st >> 16) >= thr16 ? 1u : 0u) << bit;
+    }
+    words[i] = w;
+  }
 }
 
 // ---- LDS tiles: row-major [rows][COLS] of T, pitch = COLS*sizeof(T) + 16 bytes (odd number of 16-byte
@@ -217,7 +251,7 @@ struct AttnParams {
   int B, nh, T, d, Tp; float scale;
   const void* bias; int64_t bias_ld; const float* key_bias;       // bias [B, nh, T, bias_ld]; key_bias [B, Tp]
   void* out; int64_t ld_out; float* lse;
-  float drop_p; uint32_t seed;
+  float drop_p, keep_scale; const uint32_t* words; int nqb, Tk;   // dropout keep bits (peneo_attn_drop_words) or NULL
   const void* d_out; void* dq; void* dk; void* dv; int64_t ld_d; float* g_bias; float* delta;
   void* ds_out;   // single-pass backward only: bf16 dS^T [B, nh, T keys, Tp queries] of this layer (or NULL)
 };
@@ -306,9 +340,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
   const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int qrow = wave * 32 + (lane & 31);
-  const uint32_t thresh = attn_thresh16(p.drop_p);
-  const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  const float sc2 = p.scale * LOG2E;
+  const float keep_scale = DROP ? p.keep_scale : 1.0f;
+  const bool add_kb = kb != nullptr || bias == nullptr;   // with a bias tensor its padding columns already mask keys >= T
+  // this wave's 32-query block of keep words (uniform address -> scalar loads)
+  const uint32_t* wq = nullptr;
+  if (DROP) wq = p.words + (((int64_t)b * p.nh + h) * p.nqb + (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave))) * (int64_t)p.Tk;
   const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
   Frag<T> qf[KS];
@@ -321,7 +357,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = MASKED, l_run = 0.f;
-  const uint32_t my_rh = attn_rowhash(p.seed, ((int64_t)b * p.nh + h) * Tn + myq);
 
   TileRegs<T, AK, DP> rk;
   TileRegs<T, DP, AK> rv;
@@ -344,13 +379,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
     tile_store<T, AK, DP>(rk, sK, tid);
     if constexpr (VTR) tile_store<T, AK, DP>(rv2, sVt, tid); else tile_store<T, DP, AK>(rv, sVt, tid);
     if (bias) bias_store<T, AQ>(rb, sB, tid);
-    if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] * LOG2E : 0.f) : MASKED;
+    if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] : 0.f) : MASKED;
     __syncthreads();
     FWD_PREFETCH(t + 1 < ntile ? t + 1 : t)   // unconditional: keeps the staging registers out of scratch
 
     // S^T[key, q] for the 64 keys of this tile; a 32-key block that lies entirely past T (T = 709: the second half of the
     // twelfth tile) is all masked: its products, exponentials and P.V steps are skipped
     const bool two = k0 + 32 < Tn;
+    TileMasks tm;
+    if constexpr (DROP) tile_masks_load(tm, wq + 64 * t);
     f32x16_t s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -364,7 +401,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
         }
       }
     }
-    // log2-domain scores, running max
+    // scores (natural units) and the tile's row maximum
     float mt = MASKED;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -374,41 +411,53 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
         const int kl = kt * 32 + 8 * g + 4 * half;   // 4 consecutive keys: regs 4g .. 4g+3
         float bb[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias) bias_read4<T>(sB, qrow, kl, bb);
+        if (add_kb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bb[e] += sKb[kl + e];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = fmaf(s[kt][4 * g + e], sc2, fmaf(bb[e], LOG2E, sKb[kl + e]));
+          const float v = fmaf(s[kt][4 * g + e], p.scale, bb[e]);
           s[kt][4 * g + e] = v;
           mt = fmaxf(mt, v);
         }
       }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = fast_exp2(m_run - m_new);
-    float ls = 0.f;
+    const float m_new = (mt > m_run + RESCALE_TAU) ? mt : m_run;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {   // rare after the first tiles (wave-uniform branch)
+      const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kt == 1 && !two) break;
+      for (int t2 = 0; t2 < DT; ++t2)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {                 // registers (r, r + 1) hold keys (2j, 2j + 1)
-        float e0 = fast_exp2(s[kt][r] - m_new), e1 = fast_exp2(s[kt][r + 1] - m_new);
-        ls += e0 + e1;
-        if (DROP) {
-          const uint32_t h2 = attn_pairhash(my_rh, k0 + kt * 32 + acc_row(r, lane));
-          e0 = (h2 & 0xffffu) >= thresh ? e0 * keep_scale : 0.f;
-          e1 = (h2 >> 16) >= thresh ? e1 * keep_scale : 0.f;
-        }
-        s[kt][r] = e0;
-        s[kt][r + 1] = e1;
-      }
+        for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
     }
+    const float nm = -m_run * LOG2E;
+    if constexpr (DROP) tile_masks_wait(tm);
+    float ls = 0.f;
+    auto soft = [&](auto kt_c, auto r_c) {
+      constexpr int kt = decltype(kt_c)::value, r = decltype(r_c)::value;
+      float e = fast_exp2(fmaf(s[kt][r], LOG2E, nm));
+      ls += e;
+      if constexpr (DROP) e = mask_keep(e, tile_mask<16 * kt + r>(tm));
+      s[kt][r] = e;
+    };
+    auto soft16 = [&](auto kt_c) {
+      soft(kt_c, std::integral_constant<int, 0>{}); soft(kt_c, std::integral_constant<int, 1>{});
+      soft(kt_c, std::integral_constant<int, 2>{}); soft(kt_c, std::integral_constant<int, 3>{});
+      soft(kt_c, std::integral_constant<int, 4>{}); soft(kt_c, std::integral_constant<int, 5>{});
+      soft(kt_c, std::integral_constant<int, 6>{}); soft(kt_c, std::integral_constant<int, 7>{});
+      soft(kt_c, std::integral_constant<int, 8>{}); soft(kt_c, std::integral_constant<int, 9>{});
+      soft(kt_c, std::integral_constant<int, 10>{}); soft(kt_c, std::integral_constant<int, 11>{});
+      soft(kt_c, std::integral_constant<int, 12>{}); soft(kt_c, std::integral_constant<int, 13>{});
+      soft(kt_c, std::integral_constant<int, 14>{}); soft(kt_c, std::integral_constant<int, 15>{});
+    };
+    soft16(std::integral_constant<int, 0>{});
+    if (two) soft16(std::integral_constant<int, 1>{});
     ls += __shfl_xor(ls, 32, 64);
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
-#pragma unroll
-    for (int t2 = 0; t2 < DT; ++t2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
+    l_run += ls;
     // O^T[d, q] += V^T[d, key] . P^T[key, q]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -432,12 +481,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
   __syncthreads();
   float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
   const bool any = m_run > 0.5f * MASKED;
-  const float inv = (any && l_run > 0.f) ? 1.0f / l_run : 0.f;
+  const float inv = (any && l_run > 0.f) ? keep_scale / l_run : 0.f;
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = o[t][r] * inv;
-  if (half == 0 && myq < Tn && p.lse) p.lse[((int64_t)b * p.nh + h) * Tn + myq] = any ? m_run + log2f(l_run) : MASKED;  // log2 units
+  if (half == 0 && myq < Tn && p.lse) p.lse[((int64_t)b * p.nh + h) * Tn + myq] = any ? fmaf(m_run, LOG2E, log2f(l_run)) : MASKED;  // log2 units
   __syncthreads();
   T* O = reinterpret_cast<T*>(p.out) + (int64_t)b * Tn * p.ld_out + h * d;
   store_rows<T, DP>(myO, O, p.ld_out, q0 + wave * 32, Tn, d, lane);
@@ -523,9 +572,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const float* kb = p.key_bias ? p.key_bias + (int64_t)b * Tp : nullptr;
   const int myq = q0 + wave * 32 + (lane & 31);
   const int qrow = wave * 32 + (lane & 31);
-  const uint32_t thresh = attn_thresh16(p.drop_p);
-  const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float keep_scale = DROP ? p.keep_scale : 1.0f;
   const float sc2 = p.scale * LOG2E;
+  const uint32_t* wbh = DROP ? p.words + ((int64_t)b * p.nh + h) * p.nqb * (int64_t)p.Tk : nullptr;
   const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((reinterpret_cast<uintptr_t>(V) & 15) == 0) &&
                     ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
@@ -538,7 +587,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + myq;
   const float my_lse = myq < Tn ? p.lse[rowid] : 0.f;      // log2 units
   const float my_delta = myq < Tn ? p.delta[rowid] : 0.f;
-  const uint32_t my_rh = attn_rowhash(p.seed, rowid);
 
   f32x16_t dq[DT];
 #pragma unroll
@@ -592,14 +640,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         float bb[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias) bias_read4<T>(sB, qrow, kl, bb);
         float dsv[4];
-        uint32_t h2[2] = {0u, 0u};
-        if (DROP) { h2[0] = attn_pairhash(my_rh, k0 + kl); h2[1] = attn_pairhash(my_rh, k0 + kl + 2); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float v = fmaf(s[kt][4 * g + e], sc2, fmaf(bb[e], LOG2E, sKb[kl + e]));
           const float pr = (myq < Tn) ? fast_exp2(v - my_lse) : 0.f;
           float dpv = dp[kt][4 * g + e];
-          if (DROP) dpv = ((e & 1) ? h2[e >> 1] >> 16 : h2[e >> 1] & 0xffffu) >= thresh ? dpv * keep_scale : 0.f;
+          if (DROP) dpv = attn_word_keep(wbh, p.Tk, myq, k0 + kl + e) ? dpv * keep_scale : 0.f;
           dsv[e] = pr * (dpv - my_delta);
           s[kt][4 * g + e] = dsv[e];
         }
@@ -658,8 +704,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   char* sdOt = sQt + DP * Pitch<T, AK>::v;            // [DP][AK q]
   float* sLse = reinterpret_cast<float*>(sdOt + DP * Pitch<T, AK>::v);  // [AK]
   float* sDelta = sLse + AK;                          // [AK]
-  uint32_t* sRh = reinterpret_cast<uint32_t*>(sDelta + AK);   // [AK] dropout row hashes
-  char* sB = reinterpret_cast<char*>(sRh + AK);       // bias: [AK q][AQ keys] T
+  char* sB = reinterpret_cast<char*>(sDelta + AK);    // bias: [AK q][AQ keys] T
   constexpr int BP = AQ * (int)sizeof(T) + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * AQ;
@@ -673,9 +718,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const T* bias = p.bias ? reinterpret_cast<const T*>(p.bias) + ((int64_t)b * p.nh + h) * Tn * p.bias_ld : nullptr;
   const int mykey = key0 + wave * 32 + (lane & 31);
   const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] * LOG2E : 0.f) : MASKED;
-  const uint32_t thresh = attn_thresh16(p.drop_p);
-  const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float keep_scale = DROP ? p.keep_scale : 1.0f;
   const float sc2 = p.scale * LOG2E;
+  const uint32_t* wbh = DROP ? p.words + ((int64_t)b * p.nh + h) * p.nqb * (int64_t)p.Tk : nullptr;
   const bool q_al = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
   const bool do_al = ((reinterpret_cast<uintptr_t>(dO) & 15) == 0) && ((p.ld_out * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
@@ -726,7 +771,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
       sLse[tid] = qq < Tn ? p.lse[rowid] : 0.f;
       sDelta[tid] = qq < Tn ? p.delta[rowid] : 0.f;
-      sRh[tid] = attn_rowhash(p.seed, rowid);
     }
     if (bias) {
 #pragma unroll
@@ -767,7 +811,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         float dpv = dp[qt][r];
         float pdrop = pv;
         if (DROP) {
-          bool keep = attn_keep(sRh[ql], mykey, thresh);
+          const bool keep = attn_word_keep(wbh, p.Tk, qq, mykey);
           dpv = keep ? dpv * keep_scale : 0.f;
           pdrop = keep ? pv * keep_scale : 0.f;
         }
@@ -824,8 +868,8 @@ constexpr int FKEYS = 128; // keys per workgroup
 __device__ __forceinline__ uint4 fused_bias_load(const bf16_t* bias, int64_t ld, int q0, int Tn, int key0, int tid, int i) {
   const int v = tid + 256 * i;
   const int r = min(q0 + v / (FKEYS / 8), Tn - 1), c = (v % (FKEYS / 8)) * 8;
-  const int cc = min(key0 + c, (int)ld - 8);   // the window may pass the padded row end: those keys are masked anyway
-  return *reinterpret_cast<const uint4*>(bias + (int64_t)r * ld + cc);
+  if (key0 + c >= (int)ld) return make_uint4(0xF14AF14Au, 0xF14AF14Au, 0xF14AF14Au, 0xF14AF14Au);   // past the padded row end: bf16(-1e30)
+  return *reinterpret_cast<const uint4*>(bias + (int64_t)r * ld + key0 + c);
 }
 template <int PB>
 __device__ __forceinline__ void fused_bias_store(uint4 val, char* sB, int tid, int i) {
@@ -849,7 +893,6 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
   char* sB = sS + FKEYS * PS;                       // [FQ][FKEYS]  bias
   float* sLse = reinterpret_cast<float*>(sB + FQ * PB);   // [FQ]
   float* sDelta = sLse + FQ;                        // [FQ]
-  uint32_t* sRh = reinterpret_cast<uint32_t*>(sDelta + FQ);   // [FQ] dropout row hashes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * FKEYS;
   const int Tn = p.T, d = p.d, Tp = p.Tp;
@@ -863,10 +906,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
   const int64_t ldq = (int64_t)p.nh * d;
   const int keyl = wave * 32 + (lane & 31);
   const int mykey = key0 + keyl;
-  const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] * LOG2E : 0.f) : MASKED;
-  const uint32_t thresh = attn_thresh16(p.drop_p);
-  const float keep_scale = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  const float sc2 = p.scale * LOG2E;
+  const float my_kb = (mykey < Tn) ? (p.key_bias ? p.key_bias[(int64_t)b * Tp + mykey] : 0.f) : MASKED;   // natural units
+  const bool add_kb = HAS_BIAS && p.key_bias != nullptr;   // (with a bias tensor its padding columns mask keys >= T)
+  const float keep_scale = DROP ? p.keep_scale : 1.0f;
+  // this lane's key column of the keep words: one dword per 32-query block
+  const uint32_t* wl = DROP ? p.words + ((int64_t)b * p.nh + h) * p.nqb * (int64_t)p.Tk + attn_kslot(mykey) : nullptr;
+  const int trk = (lane & 15) >> 2, trc = wave * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);   // transpose-read address parts
   const bool q_al = ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((p.ld * 2) % 16 == 0) && (d == DP);
   const bool do_al = ((reinterpret_cast<uintptr_t>(dO) & 15) == 0) && ((p.ld_out * 2) % 16 == 0) && (d == DP);
 
@@ -891,6 +936,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
   TileRegs<T, FQ, DP> rq, rdo;
   static_assert(FQ * (FKEYS / 8) / 256 == 4, "bias tile = 4 vectors per thread");
   uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+  uint32_t rw0 = 0u, rw1 = 0u;   // keep words of the tile's two query blocks
   const int ntile = (Tn + FQ - 1) / FQ;
 #define FUSED_PREFETCH(t_)                                                               \
   {                                                                                      \
@@ -903,6 +949,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
       rb2 = fused_bias_load(bias, p.bias_ld, q0_, Tn, key0, tid, 2);                     \
       rb3 = fused_bias_load(bias, p.bias_ld, q0_, Tn, key0, tid, 3);                     \
     }                                                                                    \
+    if constexpr (DROP) {                                                                \
+      rw0 = wl[(int64_t)(2 * (t_)) * p.Tk];                                              \
+      rw1 = wl[(int64_t)(2 * (t_) + 1) * p.Tk];                                          \
+    }                                                                                    \
   }
   FUSED_PREFETCH(0)
   for (int t = 0; t < ntile; ++t) {
@@ -913,10 +963,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
     if (tid < FQ) {
       const int qq = q0 + tid;
       const int64_t rowid = ((int64_t)b * p.nh + h) * Tn + qq;
-      sLse[tid] = qq < Tn ? p.lse[rowid] : 0.f;
+      sLse[tid] = qq < Tn ? -p.lse[rowid] : MASKED;   // minus lse (log2 units); rows past T give P = exp2(-huge) = 0
       sDelta[tid] = qq < Tn ? p.delta[rowid] : 0.f;
-      if (DROP) sRh[tid] = attn_rowhash(p.seed, rowid);
     }
+    const uint32_t cw0 = rw0 >> (4 * half), cw1 = rw1 >> (4 * half);   // bit (8 (r / 4) + r % 4) = this lane's query of register r
     if constexpr (HAS_BIAS) {
       fused_bias_store<PB>(rb0, sB, tid, 0);
       fused_bias_store<PB>(rb1, sB, tid, 1);
@@ -944,51 +994,45 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
         mma_step(a2, vf[ks], dp);
       }
       f32x16_t pr;
+      const uint32_t cw = qt ? cw1 : cw0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int qb = qt * 32 + 8 * g + 4 * half;           // 4 consecutive query rows: r = 4g .. 4g+3
         const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb);
         const float4 d4 = *reinterpret_cast<const float4*>(sDelta + qb);
-        const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
-        uint4 h4 = make_uint4(0, 0, 0, 0);
-        if (DROP) h4 = *reinterpret_cast<const uint4*>(sRh + qb);
-        // the pair hash of (row qb + e, keys mykey & ~1 .. | 1): the even lane computes rows 0 and 2, the odd lane rows 1
-        // and 3, the neighbour's two arrive by DPP; each lane then takes its own 16 bits
-        uint32_t hv[4] = {0u, 0u, 0u, 0u};
-        if (DROP) {
-          const bool odd = lane & 1;
-          const uint32_t kp = (uint32_t)mykey >> 1;
-          const uint32_t ha = attn_mix24((odd ? h4.y : h4.x) ^ kp), hb = attn_mix24((odd ? h4.w : h4.z) ^ kp);
-          const uint32_t oa = lane_swap1(ha), ob = lane_swap1(hb);
-          const uint32_t sh = odd ? 16u : 0u;
-          hv[0] = __builtin_amdgcn_ubfe(odd ? oa : ha, sh, 16);
-          hv[1] = __builtin_amdgcn_ubfe(odd ? ha : oa, sh, 16);
-          hv[2] = __builtin_amdgcn_ubfe(odd ? ob : hb, sh, 16);
-          hv[3] = __builtin_amdgcn_ubfe(odd ? hb : ob, sh, 16);
+        const float nl4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
+        float bv4[4] = {my_kb, my_kb, my_kb, my_kb};
+        if constexpr (HAS_BIAS) {   // the four queries' bias of this lane's key: one transpose read of the [q][key] tile
+          typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
+          const uint2 u = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(sB + (qb + trk) * PB + trc * 2)));
+          bv4[0] = __uint_as_float(u.x << 16); bv4[1] = __uint_as_float(u.x & 0xffff0000u);
+          bv4[2] = __uint_as_float(u.y << 16); bv4[3] = __uint_as_float(u.y & 0xffff0000u);
+          if (add_kb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv4[e] += my_kb;
+          }
         }
         float ds4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e, ql = qb + e, qq = q0 + ql;
-          float bv = 0.f;
-          if constexpr (HAS_BIAS) bv = bf16_to_f32(*reinterpret_cast<const T*>(sB + ql * PB + keyl * 2));
-          const float v = fmaf(s[r], sc2, fmaf(bv, LOG2E, my_kb));
-          const float pv = (qq < Tn) ? fast_exp2(v - lse4[e]) : 0.f;
-          float dpv = dp[r];
-          float pdrop = pv;
+          const float v = fmaf(s[r], p.scale, bv4[e]);
+          const float pv = fast_exp2(fmaf(v, LOG2E, nl4[e]));
+          float pdrop = pv, ks = keep_scale;
           if (DROP) {
-            const bool keep = hv[e] >= thresh;
-            dpv = keep ? dpv * keep_scale : 0.f;
-            pdrop = keep ? pv * keep_scale : 0.f;
+            const int m = __builtin_amdgcn_sbfe((int)cw, 8 * g + e, 1);   // 0 / -1
+            pdrop = and_mask(pv, m);
+            ks = and_mask(keep_scale, m);
           }
-          pr[r] = pdrop;
-          const float dsv = pv * (dpv - del4[e]);
+          pr[r] = pdrop;                                    // (1 / (1 - p) goes onto dV once, at the end)
+          const float dsv = pv * fmaf(dp[r], ks, -del4[e]);
           s[r] = dsv;
           ds4[e] = dsv;
           if (G && qq < Tn && mykey < Tn) atomicAdd(Gt + ((uint32_t)ql * (uint32_t)p.bias_ld + (uint32_t)keyl), dsv);
         }
         // dS^T[key][q]: 4 consecutive queries of this key
         *reinterpret_cast<uint2*>(sS + keyl * PS + qb * 2) = make_uint2(pack_bf16x2(ds4[0], ds4[1]), pack_bf16x2(ds4[2], ds4[3]));
+        __builtin_amdgcn_sched_barrier(0);   // one group's loads and temporaries at a time (register pressure)
       }
       // dV^T[d, key] += dO^T[d, q] . P[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
 #pragma unroll
@@ -1060,7 +1104,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = which == 0 ? dk[t][r] * p.scale : dv[t][r];
+        myO[(lane & 31) * (DP + 1) + t * 32 + acc_row(r, lane)] = which == 0 ? dk[t][r] * p.scale : dv[t][r] * keep_scale;
     __syncthreads();
     store_rows<T, DP>(myO, which == 0 ? DK : DV, p.ld_d, key0 + wave * 32, Tn, d, lane);
     __syncthreads();
@@ -1092,22 +1136,22 @@ __global__ __launch_bounds__(256, 2) void attn_dq_from_ds_kernel(AttnParams p) {
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  TileRegs<T, AK, AQ> ra;
-  TileRegs<T, AK, DP> rk;
+  // the slab is read once from HBM: tiles are fetched TWO steps ahead into two register sets (one step ahead left a single
+  // 24 KB tile per workgroup in flight and the kernel at 1.6 TB/s: every step waited out the full memory latency)
+  TileRegs<T, AK, AQ> ra0, ra1;
+  TileRegs<T, AK, DP> rk0, rk1;
   const int ntile = (Tn + AK - 1) / AK;
-#define DQS_PREFETCH(t_)                                                              \
-  {                                                                                   \
-    const int k0_ = (t_) * AK;                                                        \
-    tile_load<T, AK, AQ>(ra, DS, Tp, k0_, Tn, q0, Tp, tid, a_full && k0_ + AK <= Tn); \
-    tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + AK <= Tn);    \
-  }
-  DQS_PREFETCH(0)
-  for (int t = 0; t < ntile; ++t) {
+  auto prefetch = [&](TileRegs<T, AK, AQ>& ra, TileRegs<T, AK, DP>& rk, int t_) {
+    const int k0_ = min(t_, ntile - 1) * AK;
+    tile_load<T, AK, AQ>(ra, DS, Tp, k0_, Tn, q0, Tp, tid, a_full && k0_ + AK <= Tn);
+    tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + AK <= Tn);
+  };
+  auto step = [&](TileRegs<T, AK, AQ>& ra, TileRegs<T, AK, DP>& rk, int t) {
     __syncthreads();
     tile_store<T, AK, AQ>(ra, sA, tid);
     tile_store<T, AK, DP>(rk, sK, tid);
     __syncthreads();
-    DQS_PREFETCH(t + 1 < ntile ? t + 1 : t)
+    prefetch(ra, rk, t + 2);
 #pragma unroll
     for (int kk = 0; kk < AK / 16; ++kk) {
       const int k0 = 16 * kk + 8 * half;
@@ -1118,8 +1162,13 @@ __global__ __launch_bounds__(256, 2) void attn_dq_from_ds_kernel(AttnParams p) {
         mma_step(af, bf, acc[t2]);
       }
     }
+  };
+  prefetch(ra0, rk0, 0);
+  prefetch(ra1, rk1, 1);
+  for (int t = 0; t < ntile; t += 2) {
+    step(ra0, rk0, t);
+    if (t + 1 < ntile) step(ra1, rk1, t + 1);
   }
-#undef DQS_PREFETCH
   __syncthreads();
   // acc: rows = q (register index), cols = dcol (lane) -> per-wave [32 q][DP] fp32 tile -> bf16 rows of dq
   float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
@@ -1326,18 +1375,45 @@ static int attn_common_check(const char* who, int dtype, int B, int nh, int T, i
   return PENEO_OK;
 }
 
+extern "C" void peneo_attn_drop_words_dims(int T, int* n_query_blocks, int* n_key_slots) {
+  const int t128 = (T + 127) / 128;
+  if (n_query_blocks) *n_query_blocks = 4 * t128;
+  if (n_key_slots) *n_key_slots = 128 * t128;
+}
+extern "C" int64_t peneo_attn_drop_words_count(int B, int nh, int T) {
+  int nqb = 0, tk = 0;
+  peneo_attn_drop_words_dims(T, &nqb, &tk);
+  return (int64_t)B * nh * nqb * tk;
+}
+extern "C" int peneo_attn_drop_words(uint32_t* words, int B, int nh, int T, float drop_p, uint32_t seed, peneo_stream_t stream) {
+  PENEO_REQUIRE(words && B > 0 && nh > 0 && T > 0, "peneo_attn_drop_words: bad arguments");
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_attn_drop_words: drop_p out of range");
+  const int64_t n = peneo_attn_drop_words_count(B, nh, T);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(attn_drop_words_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, words, n,
+                     pair_drop_thr16_host(drop_p), seed);
+  return check_launch("peneo_attn_drop_words");
+}
+static void set_drop(AttnParams& p, float drop_p, const uint32_t* words) {
+  p.drop_p = drop_p; p.keep_scale = pair_drop_scale_host(drop_p); p.words = words;
+  peneo_attn_drop_words_dims(p.T, &p.nqb, &p.Tk);
+}
+
 extern "C" int peneo_attn_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld_qk, const void* vt, int B, int nh, int T,
                               int d, float scale, const void* bias, int64_t bias_ld, const float* key_bias, void* out,
-                              int64_t ld_out, float* lse, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+                              int64_t ld_out, float* lse, float drop_p, const uint32_t* drop_words, peneo_stream_t stream) {
   int rc = attn_common_check("peneo_attn_fwd", dtype, B, nh, T, d, bias, bias_ld);
   if (rc) return rc;
   PENEO_REQUIRE(q && k && out && (vt || (v && dtype == PENEO_BF16)), "peneo_attn_fwd: null pointer (fp32 needs the transposed copy vt)");
   PENEO_REQUIRE(ld_qk >= (int64_t)nh * d && ld_out >= (int64_t)nh * d, "peneo_attn_fwd: leading dims too small");
   PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_attn_fwd: drop_p out of range");
+  PENEO_REQUIRE(drop_p == 0.f || (drop_words && (reinterpret_cast<uintptr_t>(drop_words) & 63) == 0),
+                "peneo_attn_fwd: drop_p > 0 needs the keep words of peneo_attn_drop_words (64-byte aligned)");
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.ld = ld_qk; p.vt = vt; p.B = B; p.nh = nh; p.T = T; p.d = d; p.Tp = peneo_attn_padded_len(T);
   p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias; p.out = out; p.ld_out = ld_out; p.lse = lse;
-  p.drop_p = drop_p; p.seed = drop_seed;
+  set_drop(p, drop_p, drop_words);
   return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, false, (hipStream_t)stream) : dispatch<float>(p, false, (hipStream_t)stream);
 }
 
@@ -1345,10 +1421,12 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
                               const void* qt, const void* dot, const void* out, const void* d_out, int64_t ld_out,
                               const float* lse, int B, int nh, int T, int d, float scale, const void* bias, int64_t bias_ld,
                               const float* key_bias, void* dq, void* dk, void* dv, int64_t ld_dqkv, float* g_bias, float* delta,
-                              float* dq_accum, void* ds_out, float drop_p, uint32_t drop_seed, peneo_stream_t stream) {
+                              float* dq_accum, void* ds_out, float drop_p, const uint32_t* drop_words, peneo_stream_t stream) {
   int rc = attn_common_check("peneo_attn_bwd", dtype, B, nh, T, d, bias, bias_ld);
   if (rc) return rc;
   PENEO_REQUIRE(q && k && v && out && d_out && lse && dq && dk && dv && delta, "peneo_attn_bwd: null pointer");
+  PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || drop_words),
+                "peneo_attn_bwd: drop_p > 0 needs the keep words the forward used (peneo_attn_drop_words)");
   // single-pass eligibility (bf16, accumulator given, dq rows writable as 16-byte vectors); otherwise the two-kernel path
   bool fused = dtype == PENEO_BF16 && (dq_accum != nullptr || ds_out != nullptr) && (((int64_t)nh * d) % 8 == 0) &&
                ((reinterpret_cast<uintptr_t>(dq) & 15) == 0) && ((ld_dqkv * 2) % 16 == 0);
@@ -1362,7 +1440,7 @@ extern "C" int peneo_attn_bwd(int dtype, const void* q, const void* k, const voi
   p.q = q; p.k = k; p.v = v; p.ld = ld_qkv; p.kt = kt; p.qt = qt; p.dot = dot; p.B = B; p.nh = nh; p.T = T; p.d = d;
   p.Tp = peneo_attn_padded_len(T); p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias;
   p.out = const_cast<void*>(out); p.ld_out = ld_out; p.lse = const_cast<float*>(lse);
-  p.drop_p = drop_p; p.seed = drop_seed; p.d_out = d_out; p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_dqkv;
+  set_drop(p, drop_p, drop_words); p.d_out = d_out; p.dq = dq; p.dk = dk; p.dv = dv; p.ld_d = ld_dqkv;
   p.g_bias = g_bias; p.delta = delta; p.ds_out = ds_out;
   return dtype == PENEO_BF16 ? dispatch<bf16_t>(p, true, (hipStream_t)stream, dq_accum)
                              : dispatch<float>(p, true, (hipStream_t)stream, nullptr);

@@ -110,9 +110,12 @@ SIGNATURES = {
     "peneo_attn_padded_len": (_i, [_i]),
     "peneo_attn_padded_dim": (_i, [_i]),
     "peneo_head_transpose": (_i, [_i, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
-    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _u32, _vp]),
+    "peneo_attn_fwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp, _vp, _i64, _vp, _f, _vp, _vp]),
+    "peneo_attn_drop_words_dims": (None, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "peneo_attn_drop_words_count": (_i64, [_i, _i, _i]),
+    "peneo_attn_drop_words": (_i, [_vp, _i, _i, _i, _f, _u32, _vp]),
     "peneo_attn_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp, _i64, _vp,
-                            _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _u32, _vp]),
+                            _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "peneo_pair_heads_packed_bytes": (_sz, [_i, _i, _i]),
     "peneo_pair_heads_pack": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "peneo_pair_heads_fwd": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp]),

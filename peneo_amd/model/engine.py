@@ -91,6 +91,37 @@ class DropoutSeeds:
             DropoutSeeds._step += 1
             step = DropoutSeeds._step
         self.base = (int(torch.initial_seed()) * 0x9E3779B1 + step * 0x85EBCA6B) & 0xFFFFFFFF
+        self._attn_words = None
+        self._attn_words_ready = None
+
+    def prepare_attn_words(self, n_layers: int, B: int, nh: int, T: int, device) -> None:
+        """Make the keep bits of the attention dropout of ALL encoder layers (ops.attn_drop_words, one launch, 7 MB per layer
+        at 8 documents) on a side stream: called by the embedding stage, whose small kernels leave the GPU mostly idle, so
+        the 0.1 ms of integer work is off the critical path; the first attention call waits for its event."""
+        if self.p_attn <= 0.0 or self._attn_words is not None:
+            return
+        from .. import ops
+        main = torch.cuda.current_stream(device)
+        side = side_stream(device, "rel")
+        side.wait_stream(main)      # (the buffer below is allocated on `main`: whatever used its memory before has been queued there)
+        with torch.cuda.stream(side):
+            self._attn_words = ops.attn_drop_words(B, nh, T, self.p_attn, self.seed(7), device, sets=n_layers)
+            self._attn_words_ready = torch.cuda.Event()
+            self._attn_words_ready.record(side)
+
+    def attn_words(self, layer: int, n_layers: int, B: int, nh: int, T: int, device):
+        """Keep bits of the attention dropout of encoder layer `layer`; they stay with the forward's seeds for the backward.
+        None when dropout is off."""
+        if self.p_attn <= 0.0:
+            return None
+        if self._attn_words is None or tuple(self._attn_words.shape[:2]) != (n_layers, B * nh):
+            from .. import ops
+            self._attn_words = ops.attn_drop_words(B, nh, T, self.p_attn, self.seed(7), device, sets=n_layers)
+            self._attn_words_ready = None
+        if self._attn_words_ready is not None:
+            torch.cuda.current_stream(device).wait_event(self._attn_words_ready)
+            self._attn_words_ready = None
+        return self._attn_words[layer]
 
     def seed(self, site: int) -> int:
         x = (self.base ^ (site * 0xC2B2AE35)) & 0xFFFFFFFF

@@ -141,6 +141,7 @@ class _EmbedStage(torch.autograd.Function):
                 raise ValueError(f"image gives {nv} visual tokens but pos_embed has {pos_embed.shape[1]}")
         T = S + nv
         st.dims = (B, S, T)
+        seeds.prepare_attn_words(cfg.num_hidden_layers, B, cfg.num_attention_heads, T, dev)
         if getattr(model, "check_inputs", True) and (int(bbox.min()) < 0 or int(bbox.max()) > 1023):
             raise IndexError("The :obj:`bbox` coordinate values should be within 0-1000 range.")
 
@@ -279,8 +280,8 @@ class _LayerStage(torch.autograd.Function):
 
         qkv = ops.gemm(x, Wqkv, bias=bqkv)
         q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-        att, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias,
-                                drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1))
+        att, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, drop_p=seeds.p_attn,
+                                drop_words=seeds.attn_words(idx, cfg.num_hidden_layers, B, nh, T, x.device))
         h1 = ops.gemm(att, Wo, bias=bo, residual=x, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2))
         a, m1, r1 = ops.layernorm_fwd(h1, g1, b1, cfg.layer_norm_eps)
         # the GELU pre-activation is only needed by the backward: inference (no input needs a gradient) skips its 35 MB store
@@ -402,8 +403,8 @@ class _LayerStage(torch.autograd.Function):
             on_side(run_held)          # the event sits behind the d_att GEMM: they start with the attention backward
         dwo2, dwi, dwo = r_o2[1], r_i[1], r_o[1]
         ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv,
-                     st.g_bias if ds_out is None else None, drop_p=seeds.p_attn, drop_seed=seeds.seed(site + 1),
-                     ds_out=ds_out)
+                     st.g_bias if ds_out is None else None, drop_p=seeds.p_attn,
+                     drop_words=seeds.attn_words(idx, cfg.num_hidden_layers, B, nh, T, q.device), ds_out=ds_out)
         _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
         def launch_rel():
             if ds_out is not None and idx == 0:

@@ -167,6 +167,7 @@ class _LiltEmbedStage(torch.autograd.Function):
         seeds = st.seeds
         if getattr(model, "check_inputs", True) and (int(bbox.min()) < 0 or int(bbox.max()) > cfg.max_2d_position_embeddings - 1):
             raise IndexError("The :obj:`bbox`coordinate values should be within 0-1000 range.")
+        seeds.prepare_attn_words(cfg.num_hidden_layers, B, cfg.num_attention_heads, S, dev)
         pid = ops.position_ids(input_ids, cfg.pad_token_id)
         x0 = torch.empty((B * S, H), dtype=dt, device=dev)
         ops.embed_fwd(dt, x0, B, S, H, input_ids=input_ids, pos_ids=pid, word=word, type0=type_w[0], pos=pos_w)
@@ -249,7 +250,7 @@ class _LiltLayerStage(torch.autograd.Function):
         ops.head_concat(qkv[:, H:], lqkv[:, Hl:], 2 * nh, cat[:, nh * dc:])      # k and v in one launch: 2 nh "heads"
         qc, kc, vc = cat[:, :nh * dc], cat[:, nh * dc:2 * nh * dc], cat[:, 2 * nh * dc:]
         attc, lse = ops.attn_fwd(qc, kc, vc, B, nh, S, dc, 1.0, None, st.key_bias, drop_p=seeds.p_attn,
-                                 drop_seed=seeds.seed(site))
+                                 drop_words=seeds.attn_words(idx, cfg.num_hidden_layers, B, nh, S, dev))
         att = torch.empty((R, H), dtype=dt, device=dev)
         latt = torch.empty((R, Hl), dtype=dt, device=dev)
         ops.head_split(attc, nh, att, latt)
@@ -300,7 +301,7 @@ class _LiltLayerStage(torch.autograd.Function):
         qc, kc, vc = cat[:, :nh * dc], cat[:, nh * dc:2 * nh * dc], cat[:, 2 * nh * dc:]
         dcat = torch.empty_like(cat)
         ops.attn_bwd(qc, kc, vc, attc, d_attc, lse, B, nh, S, dc, 1.0, None, st.key_bias, dcat, None, drop_p=seeds.p_attn,
-                     drop_seed=seeds.seed(site))
+                     drop_words=seeds.attn_words(idx, cfg.num_hidden_layers, B, nh, S, dcat.device))
         dqkv = torch.empty((R, 3 * H), dtype=dt, device=dev)
         dlqkv = torch.empty((R, 3 * Hl), dtype=dt, device=dev)
         ops.head_split(dcat[:, :nh * dc], nh, dqkv[:, :H], dlqkv[:, :Hl], 1.0 / math.sqrt(d), 1.0 / math.sqrt(dl))

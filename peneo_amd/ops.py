@@ -447,12 +447,27 @@ def head_transpose(x: torch.Tensor, B: int, nh: int, T: int, d: int) -> torch.Te
     return out
 
 
+def attn_drop_words(B: int, nh: int, T: int, drop_p: float, drop_seed: int, device=None, sets: int = 1) -> torch.Tensor:
+    """Keep bits of the attention dropout (peneo_attn_drop_words): int32 [sets, B * nh, query blocks, key slots], one launch for
+    `sets` independent calls of the same shape (e.g. all layers of a step); hand set i to attn_fwd / attn_bwd of call i."""
+    nqb, tk = C.c_int(0), C.c_int(0)
+    lib().peneo_attn_drop_words_dims(T, C.byref(nqb), C.byref(tk))
+    words = torch.empty((sets, B * nh, nqb.value, tk.value), dtype=torch.int32, device=device or torch.device("cuda"))
+    check(lib().peneo_attn_drop_words(ptr(words), sets * B, nh, T, drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_drop_words")
+    return words
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int, T: int, d: int, scale: float,
              bias: Optional[torch.Tensor], key_bias: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
-             vt: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
+             vt: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+             drop_words: Optional[torch.Tensor] = None):
     """q/k/v: 2-D views [B*T, nh*d] with a common row stride (e.g. slices of a fused QKV buffer).
     bias: [B, nh, T, Tp] from relpos_bias_fwd (masking folded in); key_bias: fp32 [B, Tp] additive (0 / -1e30).
-    out [B*T, nh*d] / lse [B, nh, T] may be given (e.g. row slices of larger buffers)."""
+    out [B*T, nh*d] / lse [B, nh, T] may be given (e.g. row slices of larger buffers).
+    Dropout: `drop_words` = one set of attn_drop_words (the backward of this call takes the same set); without it the words
+    are made here from (drop_p, drop_seed) - attn_bwd with the same pair regenerates the same bits."""
+    if drop_p > 0 and drop_words is None:
+        drop_words = attn_drop_words(B, nh, T, drop_p, drop_seed, q.device)
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
     if vt is None and q.dtype != torch.bfloat16:   # bf16 reads V in place (transpose reads); fp32 needs the transposed copy
         vt = head_transpose(v, B, nh, T, d)
@@ -463,19 +478,21 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, nh: int,
     assert out.shape == (B * T, nh * d) and out.stride(1) == 1 and lse.is_contiguous() and lse.shape == (B, nh, T)
     check(lib().peneo_attn_fwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), q.stride(0), ptr(vt), B, nh, T, d, scale, ptr(bias),
                                bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(out), out.stride(0), ptr(lse),
-                               drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_fwd")
+                               drop_p, ptr(drop_words) if drop_p > 0 else None, stream()), "peneo_attn_fwd")
     return out, lse
 
 
 def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: float, bias, key_bias,
              dqkv: torch.Tensor, g_bias: Optional[torch.Tensor], drop_p: float = 0.0, drop_seed: int = 0,
              single_pass: Optional[bool] = None, ds_out: Optional[torch.Tensor] = None,
-             dq_atomic: bool = False) -> torch.Tensor:
+             dq_atomic: bool = False, drop_words: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dqkv: [B*T, 3*nh*d] buffer receiving dq | dk | dv (same layout as the fused QKV activations).
     bf16 runs the single-pass kernel (fp32 dQ accumulator, no transposed copies); fp32 the dQ + dK/dV pair."""
     H = nh * d
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     delta = torch.empty((B, nh, T), dtype=torch.float32, device=q.device)
+    if drop_p > 0 and drop_words is None:
+        drop_words = attn_drop_words(B, nh, T, drop_p, drop_seed, q.device)
     assert out.stride(0) == d_out.stride(0)
     if single_pass is None:
         single_pass = (q.dtype == torch.bfloat16 and H % 8 == 0 and dqkv.stride(0) % 8 == 0
@@ -495,7 +512,7 @@ def attn_bwd(q, k, v, out, d_out, lse, B: int, nh: int, T: int, d: int, scale: f
                                ptr(out), ptr(d_out), out.stride(0), ptr(lse), B, nh, T, d, scale, ptr(bias),
                                bias.shape[-1] if bias is not None else 0, ptr(key_bias), ptr(dq), ptr(dk), ptr(dv),
                                dqkv.stride(0), ptr(g_bias), ptr(delta), ptr(dq_acc), ptr(ds_out), drop_p,
-                               drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_bwd")
+                               ptr(drop_words) if drop_p > 0 else None, stream()), "peneo_attn_bwd")
     return dqkv
 
 

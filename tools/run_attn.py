@@ -21,12 +21,16 @@ def bench(name, fn, flops, n=10):
     ms = e0.elapsed_time(e1) / n
     print(f"{name:32s} {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TF/s")
 fl = 4.0 * B * nh * T * T * d
-out, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_seed=5)
-bench("attn_fwd", lambda: ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_seed=5), fl)
+w = ops.attn_drop_words(B, nh, T, drop, 5)[0] if drop > 0 else None
+if drop > 0:
+    bench('drop words, 1 layer', lambda: ops.attn_drop_words(B, nh, T, drop, 5), fl)
+    bench('drop words, 12 layers', lambda: ops.attn_drop_words(B, nh, T, drop, 5, sets=12), fl)
+out, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_words=w)
+bench("attn_fwd", lambda: ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_words=w), fl)
 d_out = torch.randn(B * T, H, device="cuda").to(dt)
 dqkv = torch.empty_like(qkv)
 g = torch.zeros(bias.shape, dtype=torch.float32, device="cuda")
-bench("attn_bwd single pass (+G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, g, drop_p=drop, drop_seed=5), 2.5 * fl)
-bench("attn_bwd single pass, dQ atomics (no G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, None, drop_p=drop, drop_seed=5, dq_atomic=True), 2.5 * fl)
-bench("attn_bwd single pass (no G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, None, drop_p=drop, drop_seed=5), 2.5 * fl)
-bench("attn_bwd two kernels (+G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, g, drop_p=drop, drop_seed=5, single_pass=False), 2.5 * fl)
+bench("attn_bwd single pass (+G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, g, drop_p=drop, drop_words=w), 2.5 * fl)
+bench("attn_bwd single pass, dQ atomics (no G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, None, drop_p=drop, drop_words=w, dq_atomic=True), 2.5 * fl)
+bench("attn_bwd single pass (no G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, None, drop_p=drop, drop_words=w), 2.5 * fl)
+bench("attn_bwd two kernels (+G)", lambda: ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, g, drop_p=drop, drop_words=w, single_pass=False), 2.5 * fl)

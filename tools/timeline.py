@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline view of one training step from a rocprofv3 kernel trace (csv).
 
-    python tools/timeline.py <..._kernel_trace.csv> [step_index_from_end=2] [--list]
+    python tools/timeline.py <..._kernel_trace.csv> [step_index_from_end=2] [--list] [--gaps]
 
 Splits the trace into steps at every `pair_heads_fwd_kernel` launch of a train step (one per step), takes one steady-state
 step and prints: wall span, union busy time, idle time, per-queue busy time, and per kernel name the total duration, the
@@ -58,7 +58,12 @@ def main():
     exposed = defaultdict(float)
     last = t0
     nact = 0
+    gaps = []
+    prev_name = ""
     for t, d, n in ev:
+        if nact == 0 and t > last:
+            gaps.append((t - last, last - t0, prev_name, n))
+        prev_name = n
         if nact > 0:
             busy += t - last
             if nact == 1:
@@ -78,6 +83,11 @@ def main():
     print(f"{'total_us':>10} {'alone_us':>10} {'calls':>6}  name")
     for n in sorted(tot, key=lambda k: -tot[k])[:45]:
         print(f"{tot[n] / 1e3:10.1f} {exp2[n] / 1e3:10.1f} {cnt[n]:6d}  {n}")
+    if "--gaps" in sys.argv:
+        print("largest idle gaps (us, at offset us, after kernel -> before kernel):")
+        for g, off, p, n in sorted(gaps, reverse=True)[:25]:
+            print(f"{g / 1e3:8.1f} @{off / 1e3:9.1f}  {short(p)[:45]} -> {short(n)[:45]}")
+        print(f"gaps: {len(gaps)}, total {sum(g for g, *_ in gaps) / 1e3:.1f} us")
     if "--list" in sys.argv:
         for s, e, q, n in step:
             print(f"{(s - t0) / 1e3:10.1f} {(e - s) / 1e3:8.1f} q{q} {short(n)}")
