@@ -22,6 +22,9 @@
 
 namespace peneo {
 
+#ifndef FWD_OCC
+#define FWD_OCC 2
+#endif
 constexpr int AQ = 128;   // rows of the "n" side per workgroup (4 waves x 32)
 constexpr int AK = 64;    // rows of the streamed side per tile
 constexpr float MASKED = -1.0e30f;
@@ -38,8 +41,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // One dword = the 32 queries of a block for one key.  attn_kslot orders the 32 keys of a key block the way the forward's
 // accumulator registers see them (lane = query, register r of half-wave hf = key 8 (r / 4) + 4 hf + r % 4): slots 2r and
 // 2r + 1 hold the keys of register r for hf = 0 / 1, so the 64-bit word at slot 2r IS the 64-lane select mask of register r.
-// The forward reads it with a scalar load and masks with one v_cndmask on the SGPR pair - no hash, no compare, one VALU
-// instruction per element (the in-kernel hash it replaces was 8.5 of the kernel's 20 VALU slots per element).  The
+// The forward keeps a tile's 64 words one per lane (one coalesced 256-byte load per wave and tile, fetched a tile ahead),
+// moves register r's pair into SGPRs with two v_readlane and masks with one v_cndmask on that pair - no hash, no compare,
+// three VALU instructions per element (the in-kernel hash it replaces was 8.5 of the kernel's 20 VALU slots per element).  The
 // single-pass backward (lane = key, registers = queries) loads its key's dword per 32-query block and takes register r's
 // bit with one v_bfe_i32 (0 / -1), used as an AND mask on P and on keep_scale.  1 / (1 - p) is applied once to the
 // accumulators (O, dV), not per element.
@@ -55,21 +59,18 @@ __device__ __forceinline__ float mask_keep(float x, uint64_t m) {
   asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
   return r;
 }
-// the 64 dwords (32 register masks) of one forward tile -> SGPRs.  Issued by hand at the top of the tile, long before their
-// use: left to the compiler the scalar loads sit right in front of the first use with a full s_waitcnt each (SMEM returns
-// out of order, so every wait is lgkmcnt(0)), and the forward ran SLOWER than with the hash.
-typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
-struct TileMasks { u32x16_t a, b, c, d; };
-__device__ __forceinline__ void tile_masks_load(TileMasks& m, const uint32_t* p) {
-  asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0"
-               : "=&s"(m.a), "=&s"(m.b), "=&s"(m.c), "=&s"(m.d) : "s"(p));
-}
-__device__ __forceinline__ void tile_masks_wait(TileMasks& m) {   // (the operands tie every later use to this wait)
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(m.a), "+s"(m.b), "+s"(m.c), "+s"(m.d));
-}
-template <int I> __device__ __forceinline__ uint64_t tile_mask(const TileMasks& m) {   // register mask I = 16 kt + r
-  const u32x16_t& v = I < 8 ? m.a : I < 16 ? m.b : I < 24 ? m.c : m.d;
-  return (uint64_t)v[2 * (I & 7)] | ((uint64_t)v[2 * (I & 7) + 1] << 32);
+// register mask i of a forward tile from the wave's 64 keep words (lane L holds word L of the tile): two v_readlane into
+// an SGPR pair.  (Scalar loads of the words straight into SGPRs were tried first: left to the compiler they sit right in
+// front of the first use with a full s_waitcnt each - SMEM returns out of order - and the forward ran slower than with the
+// hash; issued by hand at the top of the tile, the register allocator spilled the destination SGPRs between the load and
+// the wait, i.e. before the data had arrived.)
+template <int I> __device__ __forceinline__ uint64_t lane_words_mask(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w, 2 * I), hi = (uint32_t)__builtin_amdgcn_readlane((int)w, 2 * I + 1);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+#else
+  return 0;
+#endif
 }
 __device__ __forceinline__ float and_mask(float x, int m) { return __uint_as_float(__float_as_uint(x) & (uint32_t)m); }
 // the running maximum of the online softmax only moves when a tile beats it by more than this (natural units): exponentials
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* src, int64
 // VTR (bf16): V comes as the row-major [keys][d] tile and the V^T operand is read with the hardware transpose read, so
 // no per-head transposed copy of V is made (peneo_attn_fwd then takes v instead of vt)
 template <typename T, int DP, bool DROP, bool VTR>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? FWD_OCC : 1) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DP / 16, DT = DP / 32;
   char* sK = smem;                                   // [AK][DP]
@@ -342,9 +343,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
   const int qrow = wave * 32 + (lane & 31);
   const float keep_scale = DROP ? p.keep_scale : 1.0f;
   const bool add_kb = kb != nullptr || bias == nullptr;   // with a bias tensor its padding columns already mask keys >= T
-  // this wave's 32-query block of keep words (uniform address -> scalar loads)
+  // this wave's 32-query block of keep words: lane L reads word L of each 64-key tile
   const uint32_t* wq = nullptr;
-  if (DROP) wq = p.words + (((int64_t)b * p.nh + h) * p.nqb + (blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave))) * (int64_t)p.Tk;
+  if (DROP) wq = p.words + (((int64_t)b * p.nh + h) * p.nqb + (blockIdx.x * 4 + wave)) * (int64_t)p.Tk + lane;
+  uint32_t rw = 0u;
   const bool k_al = ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
 
   Frag<T> qf[KS];
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
     if constexpr (VTR) tile_load<T, AK, DP>(rv2, Vt, p.ld, k0_, Tn, 0, d, tid, v_al && k0_ + AK <= Tn); \
     else tile_load<T, DP, AK>(rv, Vt, Tp, 0, DP, k0_, Tp, tid, true);                    \
     if (bias) bias_load<T, AQ>(rb, bias, p.bias_ld, q0, Tn, k0_, tid);                   \
+    if constexpr (DROP) rw = wq[k0_];                                                    \
   }
   FWD_PREFETCH(0)
   for (int t = 0; t < ntile; ++t) {
@@ -381,31 +384,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
     if (bias) bias_store<T, AQ>(rb, sB, tid);
     if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] : 0.f) : MASKED;
     __syncthreads();
+    const uint32_t cw = rw;                   // this tile's keep words (lane L: word L)
     FWD_PREFETCH(t + 1 < ntile ? t + 1 : t)   // unconditional: keeps the staging registers out of scratch
 
-    // S^T[key, q] for the 64 keys of this tile; a 32-key block that lies entirely past T (T = 709: the second half of the
-    // twelfth tile) is all masked: its products, exponentials and P.V steps are skipped
-    const bool two = k0 + 32 < Tn;
-    TileMasks tm;
-    if constexpr (DROP) tile_masks_load(tm, wq + 64 * t);
-    f32x16_t s[2];
+    // The tile's two 32-key blocks go through the online softmax one after the other (one 16-register score tile live at
+    // a time - the running maximum moves lazily, so the second pass costs a compare and a ballot).  A block that lies
+    // entirely past T (T = 709: the second half of the twelfth tile) is all masked and skipped.
+    auto block = [&](auto kt_c) {
+      constexpr int kt = decltype(kt_c)::value;
+      f32x16_t s;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      if (kt == 0 || two) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          Frag<T> kf = FragReader<T, DP>::straight(sK, kt * 32 + (lane & 31), 16 * ks + 8 * half);
-          mma_step(kf, qf[ks], s[kt]);
-        }
+      for (int ks = 0; ks < KS; ++ks) {       // S^T[key, q]
+        Frag<T> kf = FragReader<T, DP>::straight(sK, kt * 32 + (lane & 31), 16 * ks + 8 * half);
+        mma_step(kf, qf[ks], s);
       }
-    }
-    // scores (natural units) and the tile's row maximum
-    float mt = MASKED;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (kt == 1 && !two) break;
+      float mt = MASKED;                      // scores (natural units) and the block's row maximum
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int kl = kt * 32 + 8 * g + 4 * half;   // 4 consecutive keys: regs 4g .. 4g+3
@@ -417,63 +412,60 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? 2 : 1) void att
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(s[kt][4 * g + e], p.scale, bb[e]);
-          s[kt][4 * g + e] = v;
+          const float v = fmaf(s[4 * g + e], p.scale, bb[e]);
+          s[4 * g + e] = v;
           mt = fmaxf(mt, v);
         }
       }
-    }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = (mt > m_run + RESCALE_TAU) ? mt : m_run;
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {   // rare after the first tiles (wave-uniform branch)
-      const float alpha = fast_exp2((m_run - m_new) * LOG2E);
-      l_run *= alpha;
-      m_run = m_new;
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = (mt > m_run + RESCALE_TAU) ? mt : m_run;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {   // rare after the first tiles (wave-uniform branch)
+        const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+        l_run *= alpha;
+        m_run = m_new;
 #pragma unroll
-      for (int t2 = 0; t2 < DT; ++t2)
+        for (int t2 = 0; t2 < DT; ++t2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
-    }
-    const float nm = -m_run * LOG2E;
-    if constexpr (DROP) tile_masks_wait(tm);
-    float ls = 0.f;
-    auto soft = [&](auto kt_c, auto r_c) {
-      constexpr int kt = decltype(kt_c)::value, r = decltype(r_c)::value;
-      float e = fast_exp2(fmaf(s[kt][r], LOG2E, nm));
-      ls += e;
-      if constexpr (DROP) e = mask_keep(e, tile_mask<16 * kt + r>(tm));
-      s[kt][r] = e;
-    };
-    auto soft16 = [&](auto kt_c) {
-      soft(kt_c, std::integral_constant<int, 0>{}); soft(kt_c, std::integral_constant<int, 1>{});
-      soft(kt_c, std::integral_constant<int, 2>{}); soft(kt_c, std::integral_constant<int, 3>{});
-      soft(kt_c, std::integral_constant<int, 4>{}); soft(kt_c, std::integral_constant<int, 5>{});
-      soft(kt_c, std::integral_constant<int, 6>{}); soft(kt_c, std::integral_constant<int, 7>{});
-      soft(kt_c, std::integral_constant<int, 8>{}); soft(kt_c, std::integral_constant<int, 9>{});
-      soft(kt_c, std::integral_constant<int, 10>{}); soft(kt_c, std::integral_constant<int, 11>{});
-      soft(kt_c, std::integral_constant<int, 12>{}); soft(kt_c, std::integral_constant<int, 13>{});
-      soft(kt_c, std::integral_constant<int, 14>{}); soft(kt_c, std::integral_constant<int, 15>{});
-    };
-    soft16(std::integral_constant<int, 0>{});
-    if (two) soft16(std::integral_constant<int, 1>{});
-    ls += __shfl_xor(ls, 32, 64);
-    l_run += ls;
-    // O^T[d, q] += V^T[d, key] . P^T[key, q]
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk == 2 && !two) break;
-      float pv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = s[kk >> 1][8 * (kk & 1) + e];
-      Frag<T> pf = pack_frag8<T>(pv);
-#pragma unroll
-      for (int t2 = 0; t2 < DT; ++t2) {
-        Frag<T> vf;
-        if constexpr (VTR) vf = frag_tr<Pitch<T, DP>::v>(sVt, t2 * 32, 16 * kk + 4 * half, 16 * kk + 4 * half + 8, lane);
-        else vf = FragReader<T, AK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
-        mma_step(vf, pf, o[t2]);
+          for (int r = 0; r < 16; ++r) o[t2][r] *= alpha;
       }
-    }
+      const float nm = -m_run * LOG2E;
+      float ls = 0.f;
+      auto soft = [&](auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        float e = fast_exp2(fmaf(s[r], LOG2E, nm));
+        ls += e;
+        if constexpr (DROP) e = mask_keep(e, lane_words_mask<16 * kt + r>(cw));
+        s[r] = e;
+      };
+      soft(std::integral_constant<int, 0>{}); soft(std::integral_constant<int, 1>{});
+      soft(std::integral_constant<int, 2>{}); soft(std::integral_constant<int, 3>{});
+      soft(std::integral_constant<int, 4>{}); soft(std::integral_constant<int, 5>{});
+      soft(std::integral_constant<int, 6>{}); soft(std::integral_constant<int, 7>{});
+      soft(std::integral_constant<int, 8>{}); soft(std::integral_constant<int, 9>{});
+      soft(std::integral_constant<int, 10>{}); soft(std::integral_constant<int, 11>{});
+      soft(std::integral_constant<int, 12>{}); soft(std::integral_constant<int, 13>{});
+      soft(std::integral_constant<int, 14>{}); soft(std::integral_constant<int, 15>{});
+      ls += __shfl_xor(ls, 32, 64);
+      l_run += ls;
+      // O^T[d, q] += V^T[d, key] . P^T[key, q]
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int kk = 2 * kt + kh;
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = s[8 * kh + e];
+        Frag<T> pf = pack_frag8<T>(pv);
+#pragma unroll
+        for (int t2 = 0; t2 < DT; ++t2) {
+          Frag<T> vf;
+          if constexpr (VTR) vf = frag_tr<Pitch<T, DP>::v>(sVt, t2 * 32, 16 * kk + 4 * half, 16 * kk + 4 * half + 8, lane);
+          else vf = FragReader<T, AK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+          mma_step(vf, pf, o[t2]);
+        }
+      }
+    };
+    block(std::integral_constant<int, 0>{});
+    if (k0 + 32 < Tn) block(std::integral_constant<int, 1>{});
   }
 #undef FWD_PREFETCH
 
