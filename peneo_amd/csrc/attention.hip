@@ -22,9 +22,6 @@
 
 namespace peneo {
 
-#ifndef FWD_OCC
-#define FWD_OCC 2
-#endif
 constexpr int AQ = 128;   // rows of the "n" side per workgroup (4 waves x 32)
 constexpr int AK = 64;    // rows of the streamed side per tile
 constexpr float MASKED = -1.0e30f;
@@ -53,10 +50,12 @@ __host__ __device__ __forceinline__ int attn_kslot(int key) {
 __device__ __forceinline__ bool attn_word_keep(const uint32_t* words_bh, int Tk, int q, int key) {
   return (words_bh[(int64_t)(q >> 5) * Tk + attn_kslot(key)] >> (q & 31)) & 1u;
 }
-// x where the lane's bit of the 64-bit mask is set, else 0 (mask in an SGPR pair)
+// x where the lane's bit of the 64-bit mask is set, else 0 (mask in an SGPR pair).  s_nop 1: the pair comes from v_readlane,
+// and gfx950 wants two wait states between a VALU write of an SGPR and a VALU read of it; the compiler pads that hazard for
+// instructions it can see, not inside inline asm (the fp32 kernel's schedule put the two back to back: wrong masks)
 __device__ __forceinline__ float mask_keep(float x, uint64_t m) {
   float r;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(m));
   return r;
 }
 // register mask i of a forward tile from the wave's 64 keep words (lane L holds word L of the tile): two v_readlane into
@@ -64,9 +63,9 @@ __device__ __forceinline__ float mask_keep(float x, uint64_t m) {
 // front of the first use with a full s_waitcnt each - SMEM returns out of order - and the forward ran slower than with the
 // hash; issued by hand at the top of the tile, the register allocator spilled the destination SGPRs between the load and
 // the wait, i.e. before the data had arrived.)
-template <int I> __device__ __forceinline__ uint64_t lane_words_mask(uint32_t w) {
+__device__ __forceinline__ uint64_t lane_words_mask(uint32_t w, int word /* even, wave-uniform */) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w, 2 * I), hi = (uint32_t)__builtin_amdgcn_readlane((int)w, 2 * I + 1);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)w, word), hi = (uint32_t)__builtin_amdgcn_readlane((int)w, word + 1);
   return (uint64_t)lo | ((uint64_t)hi << 32);
 #else
   return 0;
@@ -198,17 +197,17 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, ROWS, COLS>& t, cha
 }
 
 // bias tile [AQ q][AK keys]: pitch chosen for conflict-light 4-key reads by 32 consecutive rows
-template <typename T> struct BiasPitch { static constexpr int v = AK * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16); };
-template <typename T, int ROWS> struct BiasRegs {
+template <typename T, int KW = AK> struct BiasPitch { static constexpr int v = KW * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16); };
+template <typename T, int ROWS, int KW = AK> struct BiasRegs {
   static constexpr int VEC = Elem<T>::kVec;
-  static constexpr int VPR = AK / VEC;
+  static constexpr int VPR = KW / VEC;
   static constexpr int NV = ROWS * VPR / 256;
   uint4 v[NV];
 };
 // rows are clamped to rmax-1 (their results are discarded), the key range is always inside the padded row
-template <typename T, int ROWS>
-__device__ __forceinline__ void bias_load(BiasRegs<T, ROWS>& t, const T* src, int64_t ld, int r0, int rmax, int c0, int tid) {
-  using BR = BiasRegs<T, ROWS>;
+template <typename T, int ROWS, int KW = AK>
+__device__ __forceinline__ void bias_load(BiasRegs<T, ROWS, KW>& t, const T* src, int64_t ld, int r0, int rmax, int c0, int tid) {
+  using BR = BiasRegs<T, ROWS, KW>;
 #pragma unroll
   for (int i = 0; i < BR::NV; ++i) {
     const int v = tid + 256 * i;
@@ -216,14 +215,14 @@ __device__ __forceinline__ void bias_load(BiasRegs<T, ROWS>& t, const T* src, in
     t.v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c0 + c);
   }
 }
-template <typename T, int ROWS>
-__device__ __forceinline__ void bias_store(const BiasRegs<T, ROWS>& t, char* tile, int tid) {
-  using BR = BiasRegs<T, ROWS>;
+template <typename T, int ROWS, int KW = AK>
+__device__ __forceinline__ void bias_store(const BiasRegs<T, ROWS, KW>& t, char* tile, int tid) {
+  using BR = BiasRegs<T, ROWS, KW>;
 #pragma unroll
   for (int i = 0; i < BR::NV; ++i) {
     const int v = tid + 256 * i;
     const int r = v / BR::VPR, c = (v % BR::VPR) * BR::VEC;
-    char* d = tile + r * BiasPitch<T>::v + c * (int)sizeof(T);
+    char* d = tile + r * BiasPitch<T, KW>::v + c * (int)sizeof(T);
     if (sizeof(T) == 2) {
       *reinterpret_cast<uint2*>(d) = make_uint2(t.v[i].x, t.v[i].y);
       *reinterpret_cast<uint2*>(d + 8) = make_uint2(t.v[i].z, t.v[i].w);
@@ -233,9 +232,9 @@ __device__ __forceinline__ void bias_store(const BiasRegs<T, ROWS>& t, char* til
   }
 }
 // 4 consecutive bias values (fp32) at (row, col) of the staged tile, col multiple of 4
-template <typename T>
+template <typename T, int KW = AK>
 __device__ __forceinline__ void bias_read4(const char* tile, int row, int col, float* out) {
-  const char* p = tile + row * BiasPitch<T>::v + col * (int)sizeof(T);
+  const char* p = tile + row * BiasPitch<T, KW>::v + col * (int)sizeof(T);
   if (sizeof(T) == 2) {
     uint2 u = *reinterpret_cast<const uint2*>(p);
     out[0] = __uint_as_float(u.x << 16); out[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -321,15 +320,19 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* src, int64
 // ================================================================================================
 // VTR (bf16): V comes as the row-major [keys][d] tile and the V^T operand is read with the hardware transpose read, so
 // no per-head transposed copy of V is made (peneo_attn_fwd then takes v instead of vt)
-template <typename T, int DP, bool DROP, bool VTR>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? FWD_OCC : 1) void attn_fwd_kernel(AttnParams p) {
+// FK = keys per tile, 64 or (VTR only) 32.  With 32 the staging registers of the next tile halve (K, V, bias: 32 -> 16) and
+// the kernel fits 168 registers = three workgroups per CU: the 576 workgroups of 8 documents are resident at once instead of
+// 512 + a second round of 64 (the 12 key-tile loop of a wave is the unit of time, so a second round costs half a first one).
+template <typename T, int DP, bool DROP, bool VTR, int FK>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? (FK == 32 ? 3 : 2) : 1) void attn_fwd_kernel(AttnParams p) {
+  static_assert(FK == AK || (FK == 32 && VTR), "32-key tiles: row-major V only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = DP / 16, DT = DP / 32;
-  char* sK = smem;                                   // [AK][DP]
-  char* sVt = sK + AK * Pitch<T, DP>::v;             // [DP][AK]
-  constexpr int VT_BYTES = (DP * Pitch<T, AK>::v > AK * Pitch<T, DP>::v) ? DP * Pitch<T, AK>::v : AK * Pitch<T, DP>::v;
-  char* sB = sVt + VT_BYTES;                         // [AQ][AK] bias (after V^T [DP][AK] or, VTR, V [AK][DP])
-  float* sKb = reinterpret_cast<float*>(sB + AQ * BiasPitch<T>::v);  // [AK] additive key bias (log2 units)
+  char* sK = smem;                                   // [FK][DP]
+  char* sVt = sK + FK * Pitch<T, DP>::v;             // [DP][FK]
+  constexpr int VT_BYTES = (DP * Pitch<T, FK>::v > FK * Pitch<T, DP>::v) ? DP * Pitch<T, FK>::v : FK * Pitch<T, DP>::v;
+  char* sB = sVt + VT_BYTES;                         // [AQ][FK] bias (after V^T [DP][FK] or, VTR, V [FK][DP])
+  float* sKb = reinterpret_cast<float*>(sB + AQ * BiasPitch<T, FK>::v);  // [FK] additive key bias
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AQ;
   const int Tn = p.T, d = p.d, Tp = p.Tp;
@@ -360,31 +363,32 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? FWD_OCC : 1) vo
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = MASKED, l_run = 0.f;
 
-  TileRegs<T, AK, DP> rk;
-  TileRegs<T, DP, AK> rv;
-  TileRegs<T, AK, DP> rv2;
-  BiasRegs<T, AQ> rb;
+  TileRegs<T, FK, DP> rk;
+  TileRegs<T, DP, FK> rv;
+  TileRegs<T, FK, DP> rv2;
+  BiasRegs<T, AQ, FK> rb;
   const bool v_al = VTR && ((reinterpret_cast<uintptr_t>(Vt) & 15) == 0) && ((p.ld * (int64_t)sizeof(T)) % 16 == 0) && (d == DP);
-  const int ntile = (Tn + AK - 1) / AK;
+  const int ntile = (Tn + FK - 1) / FK;
 #define FWD_PREFETCH(t_)                                                                 \
   {                                                                                      \
-    const int k0_ = (t_) * AK;                                                           \
-    tile_load<T, AK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + AK <= Tn);       \
-    if constexpr (VTR) tile_load<T, AK, DP>(rv2, Vt, p.ld, k0_, Tn, 0, d, tid, v_al && k0_ + AK <= Tn); \
-    else tile_load<T, DP, AK>(rv, Vt, Tp, 0, DP, k0_, Tp, tid, true);                    \
-    if (bias) bias_load<T, AQ>(rb, bias, p.bias_ld, q0, Tn, k0_, tid);                   \
-    if constexpr (DROP) rw = wq[k0_];                                                    \
+    const int k0_ = (t_) * FK;                                                           \
+    tile_load<T, FK, DP>(rk, K, p.ld, k0_, Tn, 0, d, tid, k_al && k0_ + FK <= Tn);       \
+    if constexpr (VTR) tile_load<T, FK, DP>(rv2, Vt, p.ld, k0_, Tn, 0, d, tid, v_al && k0_ + FK <= Tn); \
+    else tile_load<T, DP, FK>(rv, Vt, Tp, 0, DP, k0_, Tp, tid, true);                    \
+    if (bias) bias_load<T, AQ, FK>(rb, bias, p.bias_ld, q0, Tn, k0_, tid);               \
+    if constexpr (DROP) rw = wq[k0_ & ~63];   /* lane L: word L of the 64-key group */    \
   }
   FWD_PREFETCH(0)
   for (int t = 0; t < ntile; ++t) {
-    const int k0 = t * AK;
+    const int k0 = t * FK;
     __syncthreads();  // previous tile fully consumed
-    tile_store<T, AK, DP>(rk, sK, tid);
-    if constexpr (VTR) tile_store<T, AK, DP>(rv2, sVt, tid); else tile_store<T, DP, AK>(rv, sVt, tid);
-    if (bias) bias_store<T, AQ>(rb, sB, tid);
-    if (tid < AK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] : 0.f) : MASKED;
+    tile_store<T, FK, DP>(rk, sK, tid);
+    if constexpr (VTR) tile_store<T, FK, DP>(rv2, sVt, tid); else tile_store<T, DP, FK>(rv, sVt, tid);
+    if (bias) bias_store<T, AQ, FK>(rb, sB, tid);
+    if (tid < FK) sKb[tid] = (k0 + tid < Tn) ? (kb ? kb[k0 + tid] : 0.f) : MASKED;
     __syncthreads();
-    const uint32_t cw = rw;                   // this tile's keep words (lane L: word L)
+    const uint32_t cw = rw;                   // this tile's keep words (lane L: word L of its 64-key group)
+    const int wsel = (FK == 32) ? 32 * (t & 1) : 0;   // 32-key tiles: the odd tile uses the group's second half
     FWD_PREFETCH(t + 1 < ntile ? t + 1 : t)   // unconditional: keeps the staging registers out of scratch
 
     // The tile's two 32-key blocks go through the online softmax one after the other (one 16-register score tile live at
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? FWD_OCC : 1) vo
       for (int g = 0; g < 4; ++g) {
         const int kl = kt * 32 + 8 * g + 4 * half;   // 4 consecutive keys: regs 4g .. 4g+3
         float bb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) bias_read4<T>(sB, qrow, kl, bb);
+        if (bias) bias_read4<T, FK>(sB, qrow, kl, bb);
         if (add_kb) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) bb[e] += sKb[kl + e];
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? FWD_OCC : 1) vo
         constexpr int r = decltype(r_c)::value;
         float e = fast_exp2(fmaf(s[r], LOG2E, nm));
         ls += e;
-        if constexpr (DROP) e = mask_keep(e, lane_words_mask<16 * kt + r>(cw));
+        if constexpr (DROP) e = mask_keep(e, lane_words_mask(cw, 2 * (16 * kt + r) + wsel));
         s[r] = e;
       };
       soft(std::integral_constant<int, 0>{}); soft(std::integral_constant<int, 1>{});
@@ -459,13 +463,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DP <= 64) ? FWD_OCC : 1) vo
         for (int t2 = 0; t2 < DT; ++t2) {
           Frag<T> vf;
           if constexpr (VTR) vf = frag_tr<Pitch<T, DP>::v>(sVt, t2 * 32, 16 * kk + 4 * half, 16 * kk + 4 * half + 8, lane);
-          else vf = FragReader<T, AK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
+          else vf = FragReader<T, FK>::perm(sVt, t2 * 32 + (lane & 31), 16 * kk + 4 * half);
           mma_step(vf, pf, o[t2]);
         }
       }
     };
     block(std::integral_constant<int, 0>{});
-    if (k0 + 32 < Tn) block(std::integral_constant<int, 1>{});
+    if constexpr (FK == 64) {
+      if (k0 + 32 < Tn) block(std::integral_constant<int, 1>{});
+    }
   }
 #undef FWD_PREFETCH
 
@@ -1198,9 +1204,9 @@ template <int DP> static size_t fused_smem() {
   return a > o ? a : o;
 }
 
-template <typename T, int DP> static size_t fwd_smem() {
-  size_t vt = (size_t)DP * Pitch<T, AK>::v, vr = (size_t)AK * Pitch<T, DP>::v;
-  size_t a = (size_t)AK * Pitch<T, DP>::v + (vt > vr ? vt : vr) + (size_t)AQ * BiasPitch<T>::v + AK * sizeof(float);
+template <typename T, int DP, int FK> static size_t fwd_smem() {
+  size_t vt = (size_t)DP * Pitch<T, FK>::v, vr = (size_t)FK * Pitch<T, DP>::v;
+  size_t a = (size_t)FK * Pitch<T, DP>::v + (vt > vr ? vt : vr) + (size_t)AQ * BiasPitch<T, FK>::v + FK * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
@@ -1230,19 +1236,33 @@ static int set_smem(KernelT kern, size_t bytes) {
 
 template <typename T, int DP, bool DROP>
 static int launch_fwd_d(const AttnParams& p, hipStream_t st) {
-  size_t sh = fwd_smem<T, DP>();
   dim3 grid((p.T + AQ - 1) / AQ, p.nh, p.B);
   if constexpr (sizeof(T) == 2) {
     if (p.vt == nullptr) {   // V given row-major: transpose reads
-      int rc = set_smem(attn_fwd_kernel<T, DP, DROP, true>, sh);
+      if constexpr (DP <= 64) {
+        // 32-key tiles (three workgroups per CU) when the grid does not fit the 512 slots of two per CU: 8 documents of 709
+        // tokens, 576 workgroups, 46 instead of 60 us; a grid that fits is a few per cent faster on 64-key tiles
+        static const int forced = getenv("PENEO_ATTN_FWD_KEYS") ? atoi(getenv("PENEO_ATTN_FWD_KEYS")) : 0;
+        const bool narrow = forced ? forced == 32 : (int64_t)grid.x * grid.y * grid.z > 512;
+        if (narrow) {
+          const size_t sh = fwd_smem<T, DP, 32>();
+          int rc = set_smem(attn_fwd_kernel<T, DP, DROP, true, 32>, sh);
+          if (rc) return rc;
+          hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, true, 32>), grid, dim3(256), sh, st, p);
+          return check_launch("peneo_attn_fwd");
+        }
+      }
+      const size_t sh = fwd_smem<T, DP, AK>();
+      int rc = set_smem(attn_fwd_kernel<T, DP, DROP, true, AK>, sh);
       if (rc) return rc;
-      hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, true>), grid, dim3(256), sh, st, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, true, AK>), grid, dim3(256), sh, st, p);
       return check_launch("peneo_attn_fwd");
     }
   }
-  int rc = set_smem(attn_fwd_kernel<T, DP, DROP, false>, sh);
+  const size_t sh = fwd_smem<T, DP, AK>();
+  int rc = set_smem(attn_fwd_kernel<T, DP, DROP, false, AK>, sh);
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, false>), grid, dim3(256), sh, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DP, DROP, false, AK>), grid, dim3(256), sh, st, p);
   return check_launch("peneo_attn_fwd");
 }
 template <typename T, int DP>

@@ -513,6 +513,40 @@ def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops):
         assert rel_err(dqkv, leaf.grad) < 4e-2, (single, rel_err(dqkv, leaf.grad))
 
 
+@pytest.mark.parametrize("T,d", [(70, 16), (200, 64)])
+def test_attention_keep_words_are_the_forward_mask_in_both_precisions(ops, T, d):
+    """peneo_attn_drop_words defines the mask: bit (q & 31) of words[b * nh + h][q >> 5][kslot(key)].  The forward's mask is read
+    off with one-hot V blocks for the fp32 and the bf16 kernel and must be exactly that bit map (the two kernels schedule the
+    SGPR mask moves differently: a missing hazard pad between v_readlane and the select once gave the fp32 kernel wrong bits)."""
+    B, nh, p_drop = 2, 2, 0.2
+    H = nh * d
+    g = torch.Generator().manual_seed(5)
+    qkv = (0.7 * torch.randn(B * T, 3 * H, generator=g)).to(DEV)
+    Tp = ops.attn_padded_len(T)
+    w = ops.attn_drop_words(B, nh, T, p_drop, 77)[0]
+    kb = torch.zeros(B, Tp, device=DEV)
+    kb[:, T:] = -1e30
+    Tk = w.shape[-1]
+    kslot = lambda k: (k & ~31) | (((k >> 3) & 3) << 3) | ((k & 3) << 1) | ((k >> 2) & 1)
+    ks = torch.tensor([kslot(k) for k in range(T)], device=DEV)
+    q = torch.arange(T, device=DEV)
+    ww = w.view(B, nh, -1, Tk).long() & 0xFFFFFFFF
+    ref = ((ww[:, :, (q >> 5)][:, :, :, ks] >> (q & 31).view(1, 1, T, 1)) & 1).bool()
+    assert abs(float(ref.float().mean()) - (1 - p_drop)) < 0.02
+    for dt in (torch.float32, torch.bfloat16):
+        dropped = torch.zeros(B, nh, T, T, device=DEV)
+        for j in range(0, T, d):
+            vj = torch.zeros(B, T, nh, d, device=DEV)
+            n = min(d, T - j)
+            vj[:, j:j + n] = torch.eye(d, device=DEV)[:n].view(1, n, 1, d)
+            x = qkv.clone()
+            x[:, 2 * H:] = vj.view(B * T, H)
+            x = x.to(dt)
+            o, _ = ops.attn_fwd(x[:, :H], x[:, H:2 * H], x[:, 2 * H:], B, nh, T, d, 0.2, None, kb, drop_p=p_drop, drop_words=w)
+            dropped[..., j:j + n] = o.float().view(B, T, nh, d).permute(0, 2, 1, 3)[..., :n]
+        assert torch.equal(dropped != 0, ref), dt
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_key_bias_only(ops, dtype):
     """LiLT-style: no bias tensor, padding mask as an additive per-key row."""
