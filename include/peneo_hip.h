@@ -218,6 +218,11 @@ int peneo_visual_assemble_bwd(int dtype, const void* d_vis, int B, int np, int H
  * lut[|delta|] holds the *unsigned* part of relative_position_bucket (the host fills it with
  * the reference's own fp32 formula so bucket indices are bit-exact); the sign adds nb/2.
  * ------------------------------------------------------------------------------------------ */
+/* Per-token inputs of peneo_relpos_buckets and the attention key mask over the concatenated text + visual sequence
+ * (T = S + nv; modeling_layoutlmv3.py:1052-1080, 586-676): one launch.  int32 [B, T] outputs, each may be NULL;
+ * attention_mask int64 [B, S] (NULL = all ones), bbox int64 [B, S, 4], vx / vy int32 [nv] grid coordinates of the patches. */
+int peneo_relpos_inputs(const int64_t* attention_mask, const int64_t* bbox, const int32_t* vx, const int32_t* vy, int B, int S,
+                        int nv, int32_t* key_mask, int32_t* pos, int32_t* xs, int32_t* ys, peneo_stream_t stream);
 int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const int32_t* ys, int B, int T,
                          const uint8_t* lut1, int lut1_len, int half1,
                          const uint8_t* lut2, int lut2_len, int half2,

@@ -212,6 +212,35 @@ extern "C" int peneo_relpos_bias_bwd_layers(const void* ds, int L, int64_t layer
   return check_launch("peneo_relpos_bias_bwd_layers");
 }
 
+// Inputs of the bucket kernel and the key mask over text + visual tokens in one launch (they used to be a dozen torch
+// element-wise kernels - arange, cat, casts, slice copies - in front of every forward): token t < S is text token t
+// (position t, x = bbox[..., 0], y = bbox[..., 3], attended iff attention_mask), t >= S visual token t - S (position t - S,
+// the patch's grid coordinates, always attended: modeling_layoutlmv3.py:1052-1080).
+__global__ __launch_bounds__(256) void relpos_inputs_kernel(const int64_t* attention_mask, const int64_t* bbox, const int32_t* vx,
+                                                            const int32_t* vy, int B, int S, int nv, int32_t* key_mask, int32_t* pos,
+                                                            int32_t* xs, int32_t* ys) {
+  const int T = S + nv;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * T) return;
+  const int b = (int)(i / T), t = (int)(i % T);
+  const bool text = t < S;
+  const int64_t src = (int64_t)b * S + t;
+  if (key_mask) key_mask[i] = text ? (attention_mask ? (int32_t)(attention_mask[src] != 0) : 1) : 1;
+  if (pos) pos[i] = text ? t : t - S;
+  if (xs) xs[i] = text ? (int32_t)bbox[src * 4 + 0] : vx[t - S];
+  if (ys) ys[i] = text ? (int32_t)bbox[src * 4 + 3] : vy[t - S];
+}
+
+extern "C" int peneo_relpos_inputs(const int64_t* attention_mask, const int64_t* bbox, const int32_t* vx, const int32_t* vy, int B, int S,
+                                   int nv, int32_t* key_mask, int32_t* pos, int32_t* xs, int32_t* ys, peneo_stream_t stream) {
+  PENEO_REQUIRE(B > 0 && S > 0 && nv >= 0, "peneo_relpos_inputs: bad sizes");
+  PENEO_REQUIRE(!(xs || ys) || (xs && ys && bbox && (nv == 0 || (vx && vy))), "peneo_relpos_inputs: 2-D inputs missing");
+  const int64_t n = (int64_t)B * (S + nv);
+  hipLaunchKernelGGL(relpos_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, attention_mask, bbox, vx,
+                     vy, B, S, nv, key_mask, pos, xs, ys);
+  return check_launch("peneo_relpos_inputs");
+}
+
 extern "C" int peneo_relpos_buckets(const int32_t* pos, const int32_t* xs, const int32_t* ys, int B, int T,
                                     const uint8_t* lut1, int lut1_len, int half1, const uint8_t* lut2, int lut2_len,
                                     int half2, uint8_t* bk1, uint8_t* bkx, uint8_t* bky, peneo_stream_t stream) {

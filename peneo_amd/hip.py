@@ -103,6 +103,7 @@ SIGNATURES = {
     "peneo_im2col_patch16": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "peneo_visual_assemble_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "peneo_visual_assemble_bwd": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "peneo_relpos_inputs": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "peneo_relpos_buckets": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "peneo_relpos_bias_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_relpos_bias_bwd_layers": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _i, _i, _vp]),

@@ -166,27 +166,19 @@ class _EmbedStage(torch.autograd.Function):
         else:
             emb = cat
 
-        # key mask over text + visual tokens (visual tokens are always attended: :1075-1080)
-        km = torch.ones((B, T), dtype=torch.int32, device=dev)
-        km[:, :S] = attention_mask.to(torch.int32)
-        st.key_mask = km
-
-        # K4: bucket maps + summed bias, shared by every layer
+        # key mask over text + visual tokens (visual tokens are always attended: :1075-1080) and the per-token inputs of the
+        # bucket maps, one launch
         nh = cfg.num_attention_heads
         d = H // nh
         use1, use2 = cfg.has_relative_attention_bias, cfg.has_spatial_attention_bias
+        vx, vy = model.visual_xy(dev, nv) if (use2 and nv > 0) else (None, None)
+        km, pos_t, xs, ys = ops.relpos_inputs(attention_mask, bbox, vx, vy, B, S, nv, use1, use2)
+        st.key_mask = km
+
+        # K4: bucket maps + summed bias, shared by every layer
         if use1 or use2:
-            pos_t = xs = ys = lut1 = lut2 = None
-            if use1:
-                p_text = torch.arange(S, dtype=torch.int32, device=dev)
-                p_vis = torch.arange(nv, dtype=torch.int32, device=dev)
-                pos_t = torch.cat([p_text, p_vis]).unsqueeze(0).expand(B, T).contiguous()
-                lut1 = model.lut("1d", cfg.rel_pos_bins, cfg.max_rel_pos, dev)
-            if use2:
-                vx, vy = model.visual_xy(dev, nv)
-                xs = torch.cat([bbox[:, :, 0].to(torch.int32), vx.unsqueeze(0).expand(B, nv)], dim=1).contiguous()
-                ys = torch.cat([bbox[:, :, 3].to(torch.int32), vy.unsqueeze(0).expand(B, nv)], dim=1).contiguous()
-                lut2 = model.lut("2d", cfg.rel_2d_pos_bins, cfg.max_rel_2d_pos, dev)
+            lut1 = model.lut("1d", cfg.rel_pos_bins, cfg.max_rel_pos, dev) if use1 else None
+            lut2 = model.lut("2d", cfg.rel_2d_pos_bins, cfg.max_rel_2d_pos, dev) if use2 else None
             st.buckets = ops.relpos_buckets(pos_t, xs, ys, B, T, lut1, cfg.rel_pos_bins // 2, lut2, cfg.rel_2d_pos_bins // 2)
             st.bucket_inputs = (pos_t, xs, ys, lut1, lut2)
             ri = iter(rel)
@@ -598,13 +590,16 @@ class LayoutLMv3Model(nn.Module):
         B, S = input_ids.shape
         if bbox is None:
             bbox = torch.zeros((B, S, 4), dtype=torch.long, device=input_ids.device)
-        if attention_mask is None:
-            attention_mask = torch.ones((B, S), dtype=torch.long, device=input_ids.device)
+        if attention_mask is not None and attention_mask.dtype != torch.int64:
+            attention_mask = attention_mask.long()       # (None = every text token attended: the mask kernel takes NULL)
+        if bbox.dtype != torch.int64:
+            bbox = bbox.long()
         self.refresh_working_weights(self.compute_dtype)
         st = _FwdState()
         st.dtype = self.compute_dtype
         st.seeds = DropoutSeeds(self.training, cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob)
-        x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(), attention_mask.contiguous(), image,
+        x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(),
+                              attention_mask.contiguous() if attention_mask is not None else None, image,
                               *self.embed_params())
         _, _, T = st.dims
         for i, layer in enumerate(self.encoder.layer):

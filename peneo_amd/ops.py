@@ -375,6 +375,22 @@ def visual_assemble_bwd(d_vis: torch.Tensor, d_cls: Optional[torch.Tensor], d_po
 # ----------------------------------------------------------------------------------------------
 # relative-position bias
 # ----------------------------------------------------------------------------------------------
+def relpos_inputs(attention_mask: Optional[torch.Tensor], bbox: Optional[torch.Tensor], vx: Optional[torch.Tensor],
+                  vy: Optional[torch.Tensor], B: int, S: int, nv: int, want_pos: bool, want_xy: bool):
+    """-> (key_mask, pos, xs, ys): int32 [B, S + nv] each (pos / xs, ys None when not wanted), one launch."""
+    dev = (attention_mask if attention_mask is not None else bbox).device
+    mk = lambda: torch.empty((B, S + nv), dtype=torch.int32, device=dev)
+    km, pos = mk(), (mk() if want_pos else None)
+    xs, ys = (mk(), mk()) if want_xy else (None, None)
+    if attention_mask is not None:
+        assert attention_mask.dtype == torch.int64 and attention_mask.is_contiguous()
+    if want_xy:
+        assert bbox.dtype == torch.int64 and bbox.is_contiguous()
+    check(lib().peneo_relpos_inputs(ptr(attention_mask), ptr(bbox), ptr(vx), ptr(vy), B, S, nv, ptr(km), ptr(pos), ptr(xs), ptr(ys),
+                                    stream()), "peneo_relpos_inputs")
+    return km, pos, xs, ys
+
+
 def relpos_buckets(pos: Optional[torch.Tensor], xs: Optional[torch.Tensor], ys: Optional[torch.Tensor], B: int, T: int,
                    lut1: Optional[torch.Tensor], half1: int, lut2: Optional[torch.Tensor], half2: int):
     dev = (pos if pos is not None else xs).device
