@@ -147,14 +147,17 @@ int peneo_layernorm_fwd(int dtype, const void* x, int64_t x_rpb, int64_t x_bstri
 /* dx may alias dy.  dgamma/dbeta (fp32, [H]) are accumulated into.
  * dx_dropped (may be NULL): a second, contiguous [rows, H] output = dx through the dropout mask (drop2_p, drop2_seed,
  * element index r*H + c) of the GEMM that produced this LayerNorm's input — the gradient that GEMM's dgrad/wgrad need,
- * without a separate masking pass. */
+ * without a separate masking pass.
+ * dx_colsum (may be NULL; fp32 [H], accumulated into): the column sums over the rows of dx_dropped (of dx when dx_dropped is
+ * NULL), summed in fp32 before the rounding to the output dtype = the BIAS gradient of the Linear that produced the
+ * LayerNorm's input (modeling_layoutlmv3.py:482-529: dense -> dropout -> + residual -> LayerNorm), without a column-sum launch. */
 int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, int64_t dy_bstride,
                         const void* x, int64_t x_rpb, int64_t x_bstride,
                         void* dx, int64_t dx_rpb, int64_t dx_bstride,
                         const float* gamma, const float* mean, const float* rstd,
                         float* dgamma, float* dbeta, int64_t rows, int H,
                         float drop_p, uint32_t drop_seed, void* dx_dropped, float drop2_p, uint32_t drop2_seed,
-                        peneo_stream_t stream);
+                        float* dx_colsum, peneo_stream_t stream);
 /* The same backward with the parameter gradients left as per-workgroup partial sums, partials[P][2][H] (fp32; row 0 of a
  * pair = gamma, row 1 = beta), P = peneo_layernorm_bwd_partial_rows(dtype, rows, H); 0 means this dtype / row length has
  * no such form (use peneo_layernorm_bwd).  The caller reduces them with peneo_colsum over [P, 2H] whenever it likes (the

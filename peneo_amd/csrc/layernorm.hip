@@ -74,7 +74,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                      const float* gamma, const float* mean, const float* rstd,
                                                      float* dgamma, float* dbeta, int64_t rows, int H, float drop_p,
-                                                     uint32_t seed, T* dx2, float drop2_p, uint32_t seed2) {
+                                                     uint32_t seed, T* dx2, float drop2_p, uint32_t seed2, float* dcol) {
   constexpr int VEC = Elem<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int nvec = H / VEC;
@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, con
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const uint32_t thresh2 = (uint32_t)fminf(drop2_p * 4294967296.0f, 4294967040.0f);
   const float keep2 = drop2_p > 0.f ? 1.0f / (1.0f - drop2_p) : 1.0f;
-  float ag[LN_MAXNV][VEC], ab[LN_MAXNV][VEC];
+  float ag[LN_MAXNV][VEC], ab[LN_MAXNV][VEC], ac[LN_MAXNV][VEC];   // ac: column sums of the (dropped) dx = the feeding Linear's bias gradient
 #pragma unroll
   for (int k = 0; k < LN_MAXNV; ++k)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; ac[k][e] = 0.f; }
 
   for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
     const T* dyr = dy + ln_row_off(r, dym, H);
@@ -134,6 +134,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, LnMap dym, con
             o[e] = (drop2_p > 0.f && !dropout_keep(seed2, (uint64_t)r * H + vi * VEC + e, thresh2)) ? 0.f : o[e] * keep2;
           *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + vi * VEC) = pack16<T>(o);
         }
+        if (dcol) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ac[k][e] += o[e];
+        }
+      }
+    }
+  }
+  if (dcol) {   // (this generic form: one atomic per column and wave)
+#pragma unroll
+    for (int k = 0; k < LN_MAXNV; ++k) {
+      const int vi = lane + 64 * k;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) atomicAdd(dcol + vi * VEC + e, ac[k][e]);
       }
     }
   }
@@ -239,7 +253,7 @@ template <typename T, int NV, bool DROP, int LW = 32>
 __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                        const float* gamma, const float* mean, const float* rstd,
                                                        float* dgamma, float* dbeta, int64_t rows, float drop_p,
-                                                       uint32_t seed, T* dx2, float drop2_p, uint32_t seed2, float* partial) {
+                                                       uint32_t seed, T* dx2, float drop2_p, uint32_t seed2, float* partial, float* dcol) {
   constexpr int VEC = Elem<T>::kVec;
   constexpr int H = LW * NV * VEC;
   const int hl = threadIdx.x & 31;
@@ -248,13 +262,13 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
   const float keep_scale = DROP ? 1.0f / (1.0f - drop_p) : 1.0f;
   const uint32_t thresh2 = (uint32_t)fminf(drop2_p * 4294967296.0f, 4294967040.0f);
   const float keep2 = drop2_p > 0.f ? 1.0f / (1.0f - drop2_p) : 1.0f;
-  float gm[NV][VEC], ag[NV][VEC], ab[NV][VEC];
+  float gm[NV][VEC], ag[NV][VEC], ab[NV][VEC], ac[NV][VEC];   // ac: column sums of the (dropped) dx
 #pragma unroll
   for (int k = 0; k < NV; ++k)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       gm[k][e] = act ? gamma[(hl + LW * k) * VEC + e] : 0.f;
-      ag[k][e] = 0.f; ab[k][e] = 0.f;
+      ag[k][e] = 0.f; ab[k][e] = 0.f; ac[k][e] = 0.f;
     }
   // the rows of a half-wave are software-pipelined: the loads of its next row are in flight while this one is reduced
   const int64_t rstep = (int64_t)gridDim.x * 8;
@@ -317,6 +331,10 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
           o[e] = (drop2_p > 0.f && !dropout_keep_b(b2, (uint32_t)((uint64_t)r * H + (hl + LW * k) * VEC + e), thresh2)) ? 0.f : o[e] * keep2;
         *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + (hl + LW * k) * VEC) = pack16<T>(o);
       }
+      if (dcol) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ac[k][e] += o[e];
+      }
     }
   }
   // parameter gradients: 8 half-waves -> LDS -> one atomic per column per block
@@ -344,6 +362,21 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
       if (dbeta) atomicAdd(dbeta + c, b);
     }
   }
+  if (dcol) {   // the bias gradient of the Linear that fed this LayerNorm: same reduction, the LDS rows reused
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (act) red[0][hw][(hl + LW * k) * VEC + e] = ac[k][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[0][w][c];
+      atomicAdd(dcol + c, a);
+    }
+  }
 }
 
 template <typename T, int NV, int LW = 32>
@@ -361,7 +394,7 @@ template <typename T, int NV, int LW = 32>
 static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const void* x, LnMap xm, void* dx, LnMap dxm,
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                             int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2,
-                            float* partial = nullptr, int64_t partial_rows = 0) {
+                            float* partial = nullptr, int64_t partial_rows = 0, float* dcol = nullptr) {
   static const int64_t cap = [] { const char* e = getenv("PENEO_LN_BWD_BLOCKS"); return (int64_t)(e ? atoi(e) : 256); }();   // 256: fewer same-address atomics on dgamma / dbeta (measured 64..1024)
   int64_t blocks = (rows + 7) / 8;
   if (partial) blocks = partial_rows;          // one partial row per block: the caller sized the buffer (ln_partial_rows)
@@ -369,10 +402,10 @@ static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const voi
   dim3 grid((unsigned)blocks);
   if (drop_p > 0.f)
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true, LW>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial);
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial, dcol);
   else
     hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false, LW>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial);
+                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial, dcol);
 }
 // blocks of the partial-sum form: one row per half-wave up to 1024 blocks (4 per CU), then a grid-stride loop
 static int64_t ln_partial_rows(int64_t rows) {
@@ -465,7 +498,7 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
                                    int64_t x_rpb, int64_t x_bstride, void* dx, int64_t dx_rpb, int64_t dx_bstride,
                                    const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                                    int64_t rows, int H, float drop_p, uint32_t drop_seed, void* dx_dropped, float drop2_p,
-                                   uint32_t drop2_seed, peneo_stream_t stream) {
+                                   uint32_t drop2_seed, float* dx_colsum, peneo_stream_t stream) {
   int rc = ln_check("peneo_layernorm_bwd", dtype, rows, H);
   if (rc) return rc;
   PENEO_REQUIRE(dy && x && dx && gamma && mean && rstd, "peneo_layernorm_bwd: null pointer");
@@ -475,19 +508,19 @@ extern "C" int peneo_layernorm_bwd(int dtype, const void* dy, int64_t dy_rpb, in
   if (ln_aligned(dy, dy_bstride, dtype) && ln_aligned(x, x_bstride, dtype) && ln_aligned(dx, dx_bstride, dtype)) {
     hipStream_t st = (hipStream_t)stream;
     bool done = dtype == PENEO_BF16
-        ? ln32_dispatch<bf16_t>(H, [&](auto nv, auto lw) { launch_ln_bwd32<bf16_t, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); })
-        : ln32_dispatch<float>(H, [&](auto nv, auto lw) { launch_ln_bwd32<float, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed); });
+        ? ln32_dispatch<bf16_t>(H, [&](auto nv, auto lw) { launch_ln_bwd32<bf16_t, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, nullptr, 0, dx_colsum); })
+        : ln32_dispatch<float>(H, [&](auto nv, auto lw) { launch_ln_bwd32<float, decltype(nv)::value, decltype(lw)::value>(st, dy, dym, x, xm, dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, drop_p, drop_seed, dx_dropped, drop2_p, drop2_seed, nullptr, 0, dx_colsum); });
     if (done) return check_launch("peneo_layernorm_bwd");
   }
   dim3 grid(ln_grid(rows, 8));  // <= 256 blocks: each wave reduces several rows; one atomic per column per block
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, dym,
                        (const bf16_t*)x, xm, (bf16_t*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed,
-                       (bf16_t*)dx_dropped, drop2_p, drop2_seed);
+                       (bf16_t*)dx_dropped, drop2_p, drop2_seed, dx_colsum);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, dym,
                        (const float*)x, xm, (float*)dx, dxm, gamma, mean, rstd, dgamma, dbeta, rows, H, drop_p, drop_seed,
-                       (float*)dx_dropped, drop2_p, drop2_seed);
+                       (float*)dx_dropped, drop2_p, drop2_seed, dx_colsum);
   return check_launch("peneo_layernorm_bwd");
 }
 

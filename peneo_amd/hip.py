@@ -92,7 +92,7 @@ SIGNATURES = {
     "peneo_colsum": (_i, [_i, _vp, _i64, _i64, _i64, _vp, _i, _vp]),
     "peneo_layernorm_fwd": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _f, _vp, _vp, _i64, _i, _f, _u32, _vp]),
     "peneo_layernorm_bwd": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
-                                 _i, _f, _u32, _vp, _f, _u32, _vp]),
+                                 _i, _f, _u32, _vp, _f, _u32, _vp, _vp]),
     "peneo_layernorm_bwd_partial_rows": (_i64, [_i, _i64, _i]),
     "peneo_layernorm_bwd_partial": (_i, [_i, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64,
                                          _i, _f, _u32, _vp, _f, _u32, _vp]),

@@ -100,6 +100,13 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, embed_dim, kernel_size=16, stride=16)
 
 
+# PENEO_LN_BIAS_FOLD=1: the output / FFN2 bias gradients come out of the LayerNorm backward (peneo_layernorm_bwd's dx_colsum)
+# instead of two column-sum launches per layer on the weight-gradient stream.  Measured at 8 documents: 24 launches and 0.6 ms of
+# side-stream kernel time less, and the step 0.1 ms SLOWER (interleaved A/B 18.83 / 18.91 / 18.52 against 18.70 / 18.80 / 18.67):
+# the extra reduction sits on the main stream, the column sums ran beside it - so the default is off.
+LN_BIAS_FOLD = os.environ.get("PENEO_LN_BIAS_FOLD", "0") == "1"
+
+
 class _FwdState:
     """Per-forward scratch shared by the stages (rel-pos bias, its gradient accumulator, seeds)."""
 
@@ -350,29 +357,34 @@ class _LayerStage(torch.autograd.Function):
         # end, one row per half-wave), column-summed on the weight-gradient stream (model.ln_partials; dg | db are adjacent)
         side_keep = []
 
-        def ln_bwd(dy, hx, g, m, r, dgb, dxd, seed_):
+        # ... and, with LN_BIAS_FOLD, the column sums of that second output = the dense layer's bias gradient
+        def ln_bwd(dy, hx, g, m, r, dgb, dxd, seed_, dbias):
             if model.ln_partials and side is not None:
                 dxo, part = ops.layernorm_bwd_partial(dy, hx, g, m, r, dx_dropped=dxd, drop2_p=seeds.p_hidden, drop2_seed=seed_)
                 if part is not None:
                     side_keep.append(part)       # read by the side stream: stays referenced until the join
-                    return dxo, (lambda: ops.colsum(part, out=dgb, accumulate=True))
+                    return dxo, (lambda: (ops.colsum(part, out=dgb, accumulate=True),
+                                          ops.colsum(dxd if dxd is not None else dxo, out=dbias, accumulate=True)))
+            if not LN_BIAS_FOLD:   # default: the bias gradient as a column sum on the weight-gradient stream (see LN_BIAS_FOLD)
+                dxo = ops.layernorm_bwd(dy, hx, g, m, r, dgb[:H], dgb[H:], dx_dropped=dxd, drop2_p=seeds.p_hidden, drop2_seed=seed_)
+                return dxo, (lambda: ops.colsum(dxd if dxd is not None else dxo, out=dbias, accumulate=True))
             return ops.layernorm_bwd(dy, hx, g, m, r, dgb[:H], dgb[H:], dx_dropped=dxd, drop2_p=seeds.p_hidden,
-                                     drop2_seed=seed_), (lambda: None)
+                                     drop2_seed=seed_, dx_colsum=dbias), (lambda: None)
 
         d_dense2 = torch.empty_like(h2) if seeds.p_hidden > 0 else None
-        d_h2, red2 = ln_bwd(d_out, h2, g2, m2, r2, pool[:2 * H], d_dense2, seeds.seed(site + 3))
+        d_h2, red2 = ln_bwd(d_out, h2, g2, m2, r2, pool[:2 * H], d_dense2, seeds.seed(site + 3), dbo2)
         if d_dense2 is None:
             d_dense2 = d_h2
-        r_o2 = on_side_late(lambda: (red2(), ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter))[1:])
+        r_o2 = on_side_late(lambda: (red2(), wgrad(d_dense2, inter)))
         d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
         r_i = on_side_late(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
         d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
 
         d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
-        d_h1, red1 = ln_bwd(d_a, h1, g1, m1, r1, pool[2 * H:4 * H], d_dense1, seeds.seed(site + 2))
+        d_h1, red1 = ln_bwd(d_a, h1, g1, m1, r1, pool[2 * H:4 * H], d_dense1, seeds.seed(site + 2), dbo)
         if d_dense1 is None:
             d_dense1 = d_h1
-        r_o = on_side_late(lambda: (red1(), ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att))[1:])
+        r_o = on_side_late(lambda: (red1(), wgrad(d_dense1, att)))
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
         dqkv = torch.empty_like(qkv)

@@ -263,8 +263,11 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
                   dgamma: torch.Tensor, dbeta: torch.Tensor, dx: Optional[torch.Tensor] = None, drop_p: float = 0.0,
                   drop_seed: int = 0, dx_dropped: Optional[torch.Tensor] = None, drop2_p: float = 0.0,
-                  drop2_seed: int = 0) -> torch.Tensor:
+                  drop2_seed: int = 0, dx_colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx_colsum (fp32 [H], accumulated into): column sums of dx_dropped (of dx without it) = the bias gradient of the Linear in
+    front of this LayerNorm."""
     H = x.shape[-1]
+    assert dx_colsum is None or (dx_colsum.dtype == torch.float32 and dx_colsum.numel() == H and dx_colsum.is_contiguous())
     rows, xr, xb = _rowmap(x, H)
     drows, dr, db = _rowmap(dy, H)
     assert drows == rows and dy.dtype == x.dtype
@@ -273,7 +276,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     _, gr, gb = _rowmap(dx, H)
     check(lib().peneo_layernorm_bwd(dtype_code(x.dtype), ptr(dy), dr, db, ptr(x), xr, xb, ptr(dx), gr, gb, ptr(gamma),
                                     ptr(mean), ptr(rstd), ptr(dgamma), ptr(dbeta), rows, H, drop_p,
-                                    drop_seed & 0xFFFFFFFF, ptr(dx_dropped), drop2_p, drop2_seed & 0xFFFFFFFF, stream()),
+                                    drop_seed & 0xFFFFFFFF, ptr(dx_dropped), drop2_p, drop2_seed & 0xFFFFFFFF, ptr(dx_colsum),
+                                    stream()),
           "peneo_layernorm_bwd")
     return dx
 

@@ -201,6 +201,30 @@ def test_layernorm_fwd_bwd(ops, dtype, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H", [768, 192, 96])
+def test_layernorm_bwd_column_sums_of_the_dropped_output(ops, dtype, H):
+    """dx_colsum of peneo_layernorm_bwd = column sums of its second (dropped) output, or of dx without one: the bias gradient of
+    the Linear in front of the LayerNorm, which used to be a separate column-sum launch (fast half-wave kernels and the generic one)."""
+    R = 777
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(R, H, generator=g).to(DEV).to(dtype)
+    dy = torch.randn(R, H, generator=g).to(DEV).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV)
+    beta = torch.zeros(H, device=DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    for with_drop in (False, True):
+        dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        col = torch.full((H,), 0.5, device=DEV)        # accumulated into
+        dxd = torch.empty_like(x) if with_drop else None
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dx_dropped=dxd, drop2_p=0.2 if with_drop else 0.0, drop2_seed=9,
+                               dx_colsum=col)
+        src = dxd if with_drop else dx
+        ref = src.float().sum(0) + 0.5
+        scale = float(src.float().abs().sum(0).max())
+        assert float((col - ref).abs().max()) < (2e-5 if dtype == torch.float32 else 6e-3) * scale, (dtype, H, with_drop)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("H", [768, 48, 192])
 def test_layernorm_dropout_fwd_bwd_share_the_mask(ops, dtype, H):
     rows = 300
