@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void ln_fwd32_kernel(const T* x, LnMap xm, T* 
   }
 }
 
-template <typename T, int NV, bool DROP, int LW = 32>
+template <typename T, int NV, bool DROP, int LW = 32, bool COL = false>
 __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, const T* x, LnMap xm, T* dx, LnMap dxm,
                                                        const float* gamma, const float* mean, const float* rstd,
                                                        float* dgamma, float* dbeta, int64_t rows, float drop_p,
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
           o[e] = (drop2_p > 0.f && !dropout_keep_b(b2, (uint32_t)((uint64_t)r * H + (hl + LW * k) * VEC + e), thresh2)) ? 0.f : o[e] * keep2;
         *reinterpret_cast<uint4*>(dx2 + r * (int64_t)H + (hl + LW * k) * VEC) = pack16<T>(o);
       }
-      if (dcol) {
+      if constexpr (COL) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) ac[k][e] += o[e];
       }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void ln_bwd32_kernel(const T* dy, LnMap dym, c
       if (dbeta) atomicAdd(dbeta + c, b);
     }
   }
-  if (dcol) {   // the bias gradient of the Linear that fed this LayerNorm: same reduction, the LDS rows reused
+  if constexpr (COL) {   // the bias gradient of the Linear that fed this LayerNorm: same reduction, the LDS rows reused
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NV; ++k)
@@ -400,12 +400,12 @@ static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const voi
   if (partial) blocks = partial_rows;          // one partial row per block: the caller sized the buffer (ln_partial_rows)
   else if (blocks > cap) blocks = cap;
   dim3 grid((unsigned)blocks);
-  if (drop_p > 0.f)
-    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, true, LW>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial, dcol);
-  else
-    hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, false, LW>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm,
-                       gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial, dcol);
+#define PENEO_LN_BWD32(DROP_, COL_)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd32_kernel<T, NV, DROP_, LW, COL_>), grid, dim3(256), 0, st, (const T*)dy, dym, (const T*)x, xm, (T*)dx, dxm, \
+                     gamma, mean, rstd, dgamma, dbeta, rows, drop_p, seed, (T*)dx2, drop2_p, seed2, partial, dcol)
+  if (dcol) { if (drop_p > 0.f) PENEO_LN_BWD32(true, true); else PENEO_LN_BWD32(false, true); }
+  else { if (drop_p > 0.f) PENEO_LN_BWD32(true, false); else PENEO_LN_BWD32(false, false); }
+#undef PENEO_LN_BWD32
 }
 // blocks of the partial-sum form: one row per half-wave up to 1024 blocks (4 per CU), then a grid-stride loop
 static int64_t ln_partial_rows(int64_t rows) {

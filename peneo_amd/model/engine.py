@@ -103,9 +103,12 @@ class DropoutSeeds:
         from .. import ops
         main = torch.cuda.current_stream(device)
         side = side_stream(device, "rel")
-        side.wait_stream(main)      # (the buffer below is allocated on `main`: whatever used its memory before has been queued there)
+        # the buffer belongs to the MAIN stream's allocator pool (it is read and freed there); the side stream only fills it,
+        # behind whatever the main stream had queued on that memory before
+        words = torch.empty(ops.attn_drop_words_shape(B, nh, T, n_layers), dtype=torch.int32, device=device)
+        side.wait_stream(main)
         with torch.cuda.stream(side):
-            self._attn_words = ops.attn_drop_words(B, nh, T, self.p_attn, self.seed(7), device, sets=n_layers)
+            self._attn_words = ops.attn_drop_words(B, nh, T, self.p_attn, self.seed(7), device, sets=n_layers, out=words)
             self._attn_words_ready = torch.cuda.Event()
             self._attn_words_ready.record(side)
 

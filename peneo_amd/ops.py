@@ -467,12 +467,20 @@ def head_transpose(x: torch.Tensor, B: int, nh: int, T: int, d: int) -> torch.Te
     return out
 
 
-def attn_drop_words(B: int, nh: int, T: int, drop_p: float, drop_seed: int, device=None, sets: int = 1) -> torch.Tensor:
-    """Keep bits of the attention dropout (peneo_attn_drop_words): int32 [sets, B * nh, query blocks, key slots], one launch for
-    `sets` independent calls of the same shape (e.g. all layers of a step); hand set i to attn_fwd / attn_bwd of call i."""
+def attn_drop_words_shape(B: int, nh: int, T: int, sets: int = 1):
     nqb, tk = C.c_int(0), C.c_int(0)
     lib().peneo_attn_drop_words_dims(T, C.byref(nqb), C.byref(tk))
-    words = torch.empty((sets, B * nh, nqb.value, tk.value), dtype=torch.int32, device=device or torch.device("cuda"))
+    return (sets, B * nh, nqb.value, tk.value)
+
+
+def attn_drop_words(B: int, nh: int, T: int, drop_p: float, drop_seed: int, device=None, sets: int = 1,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Keep bits of the attention dropout (peneo_attn_drop_words): int32 [sets, B * nh, query blocks, key slots], one launch for
+    `sets` independent calls of the same shape (e.g. all layers of a step); hand set i to attn_fwd / attn_bwd of call i.
+    `out`: a buffer of attn_drop_words_shape(...) allocated by the caller (e.g. on another stream than the one that fills it)."""
+    shape = attn_drop_words_shape(B, nh, T, sets)
+    words = out if out is not None else torch.empty(shape, dtype=torch.int32, device=device or torch.device("cuda"))
+    assert tuple(words.shape) == shape and words.dtype == torch.int32 and words.is_contiguous()
     check(lib().peneo_attn_drop_words(ptr(words), sets * B, nh, T, drop_p, drop_seed & 0xFFFFFFFF, stream()), "peneo_attn_drop_words")
     return words
 

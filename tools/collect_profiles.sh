@@ -5,7 +5,7 @@ OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1            # first touch of a fresh box is slow
 python bench.py > $OUT/default_line.json 2> $OUT/default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/steps5_line.json 2> $OUT/steps5.err
-python tools/timeline.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) 2 > $OUT/step_timeline.txt 2>&1
+python tools/timeline.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) +4 > $OUT/step_timeline.txt 2>&1
 python tools/prof_summary_csv.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) 40 > $OUT/steps5_summary.txt 2>&1
 bash tools/pmc_traffic.sh pair_bwd_ws_kernel tools/run_pair_bwd_once.py > $OUT/pmc_pair_bwd.txt 2>&1
 bash tools/pmc_traffic.sh pair_heads_fwd tools/run_pair.py > $OUT/pmc_pair_fwd.txt 2>&1

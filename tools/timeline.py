@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline view of one training step from a rocprofv3 kernel trace (csv).
 
-    python tools/timeline.py <..._kernel_trace.csv> [step_index_from_end=2] [--list] [--gaps]
+    python tools/timeline.py <..._kernel_trace.csv> [step_index_from_end=2 | +K = K-th train step from the start] [--list] [--gaps]
 
 Splits the trace into steps at every `pair_heads_fwd_kernel` launch of a train step (one per step), takes one steady-state
 step and prints: wall span, union busy time, idle time, per-queue busy time, and per kernel name the total duration, the
@@ -20,7 +20,8 @@ def short(name: str) -> str:
 
 def main():
     path = sys.argv[1]
-    back = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 2
+    arg = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "2"
+    back = int(arg) if not arg.startswith("+") else None      # "+K": the K-th train step from the START of the trace (0-based)
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -32,10 +33,17 @@ def main():
     for a, b in zip(marks, marks[1:] + [len(rows)]):
         if any(("pair_dz" in rows[k][3] or "pair_bwd" in rows[k][3]) for k in range(a, b)):
             train.append(a)
-    if len(train) < back + 1:
-        print("not enough train steps in the trace", len(train))
-        return
-    a, b = train[-back - 1], train[-back]
+    if back is None:
+        k = int(arg[1:])
+        if len(train) < k + 2:
+            print("not enough train steps in the trace", len(train))
+            return
+        a, b = train[k], train[k + 1]
+    else:
+        if len(train) < back + 1:
+            print("not enough train steps in the trace", len(train))
+            return
+        a, b = train[-back - 1], train[-back]
     # a step starts at the first kernel after the previous step's last backward kernel: walk back from the pair_heads launch
     # to the embedding kernel of the same forward
     def step_start(i):
