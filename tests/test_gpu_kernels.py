@@ -329,6 +329,41 @@ def test_embed_fwd_bwd(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_bwd_with_the_collisions_of_real_batches(ops, dtype):
+    """Embedding-table gradients under the collision pattern of real batches - line boxes replicated over a line's tokens, two
+    heights / widths in the whole batch, position rows shared by all documents - against torch's index_add.  (An LDS-image form of
+    the small tables was tried against the token-per-wave atomics: 0.28-0.33 ms against 0.185 ms, not kept.)"""
+    B, S, H, cs, ss, V = 3, 200, 192, 32, 32, 500
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(3, V, (B, S), generator=g)
+    ids[2, 150:] = 1
+    lines = torch.randint(0, 20, (B, S), generator=g)                     # 20 line boxes per document
+    x0, y0 = (lines * 37) % 800, lines * 40
+    bbox = torch.stack([x0, y0, x0 + 150 - 20 * (lines % 2), y0 + 8 + 4 * (lines % 2)], -1)
+    tabs = {n: torch.zeros(sh, device=DEV) for n, sh in
+            dict(word=(V, H), pos=(S + 2, H), x=(1024, cs), y=(1024, cs), h=(1024, ss), w=(1024, ss)).items()}
+    ids, bbox = ids.to(DEV), bbox.to(DEV)
+    pid = ops.position_ids(ids, 1)
+    d_out = torch.randn(B, S, H, generator=g).to(DEV).to(dtype)
+    grads = {n: torch.full_like(t, 0.25) for n, t in tabs.items()}          # accumulated into
+    ops.embed_bwd(d_out, B, S, H, input_ids=ids, pos_ids=pid, bbox=bbox, g_word=grads["word"], g_pos=grads["pos"],
+                  g_x=grads["x"], g_y=grads["y"], g_h=grads["h"], g_w=grads["w"], pad_id=1)
+    d = d_out.float().view(B * S, H)
+    ref = {n: torch.full_like(t, 0.25) for n, t in tabs.items()}
+    keep = (ids.view(-1) != 1)
+    ref["word"].index_add_(0, ids.view(-1)[keep], d[keep])
+    keep_p = (pid.view(-1) != 1)
+    ref["pos"].index_add_(0, pid.view(-1).long()[keep_p], d[keep_p])
+    bb = bbox.view(-1, 4)
+    ref["x"].index_add_(0, bb[:, 0], d[:, 0:cs]); ref["x"].index_add_(0, bb[:, 2], d[:, 2 * cs:3 * cs])
+    ref["y"].index_add_(0, bb[:, 1], d[:, cs:2 * cs]); ref["y"].index_add_(0, bb[:, 3], d[:, 3 * cs:4 * cs])
+    ref["h"].index_add_(0, (bb[:, 3] - bb[:, 1]).clip(0, 1023), d[:, 4 * cs:4 * cs + ss])
+    ref["w"].index_add_(0, (bb[:, 2] - bb[:, 0]).clip(0, 1023), d[:, 4 * cs + ss:4 * cs + 2 * ss])
+    for n in tabs:
+        assert rel_err(grads[n], ref[n]) < 2e-5, n
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_patch_embed_pieces(ops, dtype):
     B, H = 2, 64
     img = torch.randn(B, 3, 224, 224, device=DEV)
