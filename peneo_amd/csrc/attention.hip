@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256) void dq_finish_kernel(const float* acc, int64_
 
 template <int DP> static size_t fused_smem() {
   size_t a = (size_t)2 * FQ * Pitch<bf16_t, DP>::v + (size_t)FKEYS * Pitch<bf16_t, DP>::v + (size_t)FKEYS * (FQ * 2 + 16) +
-             (size_t)FQ * (FKEYS * 2 + 16) + 3 * FQ * sizeof(float);
+             (size_t)FQ * (FKEYS * 2 + 16) + 2 * FQ * sizeof(float);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;
 }
@@ -1217,7 +1217,7 @@ template <typename T, int DP> static size_t dq_smem() {
   return a > o ? a : o;
 }
 template <typename T, int DP> static size_t dkv_smem() {
-  size_t a = (size_t)2 * AK * Pitch<T, DP>::v + (size_t)2 * DP * Pitch<T, AK>::v + 3 * AK * sizeof(float) +
+  size_t a = (size_t)2 * AK * Pitch<T, DP>::v + (size_t)2 * DP * Pitch<T, AK>::v + 2 * AK * sizeof(float) +
              (size_t)AK * (AQ * sizeof(T) + 16);
   size_t o = (size_t)4 * 32 * (DP + 1) * sizeof(float);
   return a > o ? a : o;

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Statistics of the attention-dropout mask function (attention.hip: attn_mix24 / attn_pairhash) against mix32, in numpy.
+"""Statistics of the two counter-based dropout generators, in numpy (CPU only).
 
-One hash serves the two keys (2j, 2j+1) of a query row (low / high 16 bits); the mixer uses 24-bit multiplies.  Prints keep
-rate (even / odd keys), bit balance of the hash, correlations of the keep decisions between the two halves of one hash,
-neighbouring hashes, neighbouring rows and a few lags, and the spread of per-row / per-key keep counts against the binomial
-expectation.  CPU only."""
+attention (attention.hip: attn_drop_words_kernel): one dword = the 32 queries of a block for one key, a chain of 32 fields
+(st <- st[23:0] * 0xC2B2AF + 0x9E3779, field = st >> 16) seeded by mix32(seed ^ word index * 0x9E3779B9).  classifier (common.h:
+pair_drop_*): one chain of 16 fields per (pair, slab, half), seeded by a 24-bit mix.  Prints keep rates, correlations along
+the chains and across neighbouring chains, joint probabilities and the spread of keep counts against the binomial expectation."""
 import numpy as np
 
 M = np.uint64(0xFFFFFFFF)
@@ -25,24 +25,28 @@ def mix24(x):
     return x
 
 
-def main(p=0.1, T=709, rows=2000, seed=12345):
-    rid = np.arange(rows, dtype=np.uint64)
-    rh = mix32(u(seed) ^ ((rid * u(0x9E3779B9)) & M))
-    keys = np.arange(0, T + 1, dtype=np.uint64)
+def main(p=0.1, nqb=24, Tk=768, bh=8, seed=12345):
+    """Attention keep words: [bh][query block][key slot] dwords, bit i = query 32 qb + i."""
+    n = bh * nqb * Tk
+    idx = np.arange(n, dtype=np.uint64)
+    st = mix32(u(seed) ^ ((idx * u(0x9E3779B9)) & M))
     th = round(p * 65536)
-    for name, fn in (("mix24", mix24), ("mix32", mix32)):
-        h = fn(rh[:, None] ^ (keys >> u(1))[None, :])
-        v = np.where((keys & u(1))[None, :] == 1, h >> u(16), h & u(0xFFFF))
-        keep = v >= th
-        k = keep.astype(float) - keep.mean()
-        c = lambda a, b: float((a * b).mean() / k.var())
-        bits = [float(((h >> u(b)) & u(1)).mean()) for b in range(32)]
-        print(f"{name}: keep {keep.mean():.5f} (even {keep[:, 0::2].mean():.5f}, odd {keep[:, 1::2].mean():.5f}), want {1 - th / 65536:.5f}")
-        print(f"   hash bit means {min(bits):.4f} .. {max(bits):.4f}")
-        print(f"   corr: halves of one hash {c(k[:, 0:-1:2], k[:, 1::2]):+.4f}, neighbouring hashes {c(k[:, 1:-1:2], k[:, 2::2]):+.4f}, "
-              f"rows {c(k[:-1], k[1:]):+.4f}, lags 2/4/8/32 " + " ".join(f"{c(k[:, :-l], k[:, l:]):+.4f}" for l in (2, 4, 8, 32)))
-        print(f"   keep-count std per row {keep.sum(1).std():.2f} (binomial {np.sqrt((T + 1) * p * (1 - p)):.2f}), "
-              f"per key {keep.sum(0).std():.2f} (binomial {np.sqrt(rows * p * (1 - p)):.2f});  noise floor of a correlation ~ {1 / np.sqrt(k.size):.4f}")
+    keep = np.zeros((n, 32), dtype=bool)
+    for bit in range(32):
+        st = (((st & u(0xFFFFFF)) * u(0xC2B2AF)) + u(0x9E3779)) & M
+        keep[:, bit] = (st >> u(16)) >= th
+    # [bh, q = 32 qb + bit, key slot]
+    m = keep.reshape(bh, nqb, Tk, 32).transpose(0, 1, 3, 2).reshape(bh, nqb * 32, Tk)
+    k = m.astype(float) - m.mean()
+    c = lambda a, b: float((a * b).mean() / k.var())
+    print(f"attention words: keep {m.mean():.5f}, want {1 - th / 65536:.5f}")
+    print("   corr along queries (the chain): " + " ".join(f"lag{l} {c(k[:, :-l], k[:, l:]):+.5f}" for l in (1, 2, 3, 4, 8, 31, 32)) +
+          ";  along key slots: " + " ".join(f"lag{l} {c(k[:, :, :-l], k[:, :, l:]):+.5f}" for l in (1, 2, 64)) +
+          f";  next (b, h) {c(k[:-1], k[1:]):+.5f};  noise floor ~ {1 / np.sqrt(k.size):.5f}")
+    print(f"   P(keep, keep) along queries {float((m[:, :-1] & m[:, 1:]).mean()):.5f} (independent {m.mean() ** 2:.5f}), "
+          f"P(drop, drop) {float((~m[:, :-1] & ~m[:, 1:]).mean()):.5f} ({(1 - m.mean()) ** 2:.5f})")
+    print(f"   keep-count std per query row {m.sum(2).std():.2f} (binomial {np.sqrt(Tk * p * (1 - p)):.2f}), per key "
+          f"{m.sum(1).std():.2f} ({np.sqrt(nqb * 32 * p * (1 - p)):.2f})")
 
 
 def k12(p=0.1, P=3000, nslab=60, seed=12345):
