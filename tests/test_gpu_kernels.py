@@ -572,12 +572,13 @@ def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops):
         assert rel_err(dqkv, leaf.grad) < 4e-2, (single, rel_err(dqkv, leaf.grad))
 
 
-@pytest.mark.parametrize("T,d", [(70, 16), (200, 64)])
-def test_attention_keep_words_are_the_forward_mask_in_both_precisions(ops, T, d):
+@pytest.mark.parametrize("B,nh,T,d", [(2, 2, 70, 16), (2, 2, 200, 64), (4, 12, 1389, 64)])
+def test_attention_keep_words_are_the_forward_mask_in_both_precisions(ops, B, nh, T, d):
     """peneo_attn_drop_words defines the mask: bit (q & 31) of words[b * nh + h][q >> 5][kslot(key)].  The forward's mask is read
     off with one-hot V blocks for the fp32 and the bf16 kernel and must be exactly that bit map (the two kernels schedule the
-    SGPR mask moves differently: a missing hazard pad between v_readlane and the select once gave the fp32 kernel wrong bits)."""
-    B, nh, p_drop = 2, 2, 0.2
+    SGPR mask moves differently: a missing hazard pad between v_readlane and the select once gave the fp32 kernel wrong bits).
+    The last case has 528 workgroups: the bf16 forward then runs its 32-key tiles (three workgroups per CU)."""
+    p_drop = 0.2
     H = nh * d
     g = torch.Generator().manual_seed(5)
     qkv = (0.7 * torch.randn(B * T, 3 * H, generator=g)).to(DEV)
