@@ -116,17 +116,38 @@ __global__ __launch_bounds__(256) void pair_bwd_reduce_kernel(const float* part_
   float* out = d_ab + ((int64_t)b * N + n) * 2 * D;
   const int ti = n / PB_TI, first = pb_tiles_before(ti, N), cnt = ncolt - (ti >> 1);
   const int tj = n / PB_TJ, ti_max = min(pb_row_tiles(N) - 1, 2 * tj + 1);
-  for (int d = threadIdx.x; d < 2 * D; d += blockDim.x) {
-    float v = 0.f;
-    if (d < D) {
-      for (int k = 0; k < cnt; ++k) v += pa[((int64_t)(first + k) * PB_TI + (n % PB_TI)) * D + d];
-    } else {
-      for (int t = 0; t <= ti_max; ++t) {
-        const int tile = pb_tiles_before(t, N) + (tj - (t >> 1));
-        v += pb[((int64_t)tile * PB_TJ + (n % PB_TJ)) * D + (d - D)];
+  // 16 bytes per lane and four partial rows in flight (D % 4 == 0: D is a multiple of 32): the rows of one sum lie 12 / 24 KiB
+  // apart, one scalar load at a time left the launch at 1.9 TB/s for 312 MB
+  const int nv = D / 4;
+  for (int v = threadIdx.x; v < 2 * nv; v += blockDim.x) {
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [](float4& a, const float4 x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; };
+    if (v < nv) {
+      const float* src = pa + ((int64_t)first * PB_TI + (n % PB_TI)) * D + 4 * v;
+      const int64_t step = (int64_t)PB_TI * D;
+      int k = 0;
+      for (; k + 4 <= cnt; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(acc[u], *reinterpret_cast<const float4*>(src + (k + u) * step));
       }
+      for (; k < cnt; ++k) add(acc[0], *reinterpret_cast<const float4*>(src + k * step));
+    } else {
+      const int c4 = 4 * (v - nv);
+      auto row = [&](int t) {
+        const int tile = pb_tiles_before(t, N) + (tj - (t >> 1));
+        return pb + ((int64_t)tile * PB_TJ + (n % PB_TJ)) * D + c4;
+      };
+      int t = 0;
+      for (; t + 4 <= ti_max + 1; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(acc[u], *reinterpret_cast<const float4*>(row(t + u)));
+      }
+      for (; t <= ti_max; ++t) add(acc[0], *reinterpret_cast<const float4*>(row(t)));
     }
-    out[d] = v;
+    add(acc[0], acc[1]); add(acc[2], acc[3]); add(acc[0], acc[2]);
+    *reinterpret_cast<float4*>(out + 4 * v) = acc[0];
   }
 }
 
