@@ -121,6 +121,62 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const T* d_out, int
   }
 }
 
+// Box-table gradients with the duplicates of a token chunk summed in LDS first.  A line's box is replicated over its tokens and
+// heights / widths take a handful of values, so in the token-per-wave kernel above thousands of fp32 atomics queue on the same few
+// hundred addresses (140 of its 160 us at 8 x 512 tokens).  Here a workgroup takes EBX_TOK consecutive tokens: per index kind
+// (left, top, right, bottom, height, width) a token's slot is the FIRST token of the chunk with the same index; the chunk's
+// d_out rows are added into an LDS image [slot][H] (a thread owns its columns: no LDS atomics), and only first occurrences go to the
+// table with global atomics.
+constexpr int EBX_TOK = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void embed_box_bwd_kernel(const T* d_out, int64_t rpb, int64_t bstride, const int64_t* bbox,
+                                                            peneo_embed_grads g, int cs, int ss, int max_2d, int64_t rows, int H,
+                                                            int clip_hw) {
+  extern __shared__ float ebx_acc[];                       // [EBX_TOK][H]
+  __shared__ int idx[6][EBX_TOK];
+  __shared__ int slot[6][EBX_TOK];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * EBX_TOK;
+  if (tid < EBX_TOK) {
+    const int64_t r = r0 + tid;
+    SpatialIdx sp{};
+    bool ok = false;
+    if (r < rows) { sp = spatial_idx(bbox + r * 4, max_2d, clip_hw); ok = sp.ok; }
+    idx[0][tid] = ok ? sp.l : -1 - tid; idx[1][tid] = ok ? sp.t : -1 - tid; idx[2][tid] = ok ? sp.r : -1 - tid;
+    idx[3][tid] = ok ? sp.b : -1 - tid; idx[4][tid] = ok ? sp.h : -1 - tid; idx[5][tid] = ok ? sp.w : -1 - tid;
+  }
+  for (int i = tid; i < EBX_TOK * H; i += 256) ebx_acc[i] = 0.f;
+  __syncthreads();
+  if (tid < 6 * EBX_TOK) {
+    const int k = tid / EBX_TOK, i = tid % EBX_TOK, me = idx[k][i];
+    int s = i;
+    for (int j = 0; j < i; ++j)
+      if (idx[k][j] == me) { s = j; break; }
+    slot[k][i] = s;
+  }
+  __syncthreads();
+  // a thread owns its columns: every cell (slot, c) of the image is touched by one thread only - plain LDS read-modify-write
+  const int ntok = (int)min((int64_t)EBX_TOK, rows - r0);
+  for (int c = tid; c < H; c += 256) {
+    const int k = c < 4 * cs ? c / cs : (c < 4 * cs + ss ? 4 : 5);
+    const T* col = d_out + c;
+    float* acc = ebx_acc + c;
+#pragma unroll 1
+    for (int i0 = 0; i0 < ntok; i0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i0 + u < ntok) ? Elem<T>::load(col + row_off(r0 + i0 + u, rpb, bstride, H)) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < ntok && idx[0][i0 + u] >= 0) acc[slot[k][i0 + u] * H] += v[u];
+    }
+    float* tab = (k == 0 || k == 2) ? g.x : (k == 1 || k == 3) ? g.y : (k == 4 ? g.h : g.w);
+    const int wdt = k < 4 ? cs : ss, cc = k < 4 ? c - k * cs : (k == 4 ? c - 4 * cs : c - 4 * cs - ss);
+    for (int i = 0; i < ntok; ++i)
+      if (slot[k][i] == i && idx[k][i] >= 0) atomicAdd(tab + (int64_t)idx[k][i] * wdt + cc, acc[i * H]);   // first occurrences only
+  }
+}
+
 // ---- patches: [B, C, Hi, Wi] -> [B * gh * gw, C*256], k = c*256 + py*16 + px (conv weight order) ----
 template <typename T>
 __global__ void im2col_kernel(const float* img, int B, int Cc, int Hi, int Wi, T* out) {
@@ -213,12 +269,34 @@ extern "C" int peneo_embed_text_bwd(int dtype, const void* d_out, int64_t rpb, i
   if (g->x) PENEO_REQUIRE(bbox && g->y && g->h && g->w, "peneo_embed_text_bwd: spatial grads incomplete");
   int64_t rows = (int64_t)B * S;
   dim3 grid((unsigned)((rows + 3) / 4));
+  peneo_embed_grads rest = *g;
+  const size_t box_lds = (size_t)EBX_TOK * H * sizeof(float);
+  if (g->x && H == 4 * coord_size + 2 * shape_size && coord_size > 0 && shape_size > 0 && box_lds <= 150 * 1024 && rows >= 4 * EBX_TOK) {
+    // the box tables: duplicates of 32-token chunks summed in LDS, first occurrences to the tables (embed_box_bwd_kernel)
+    dim3 bgrid((unsigned)((rows + EBX_TOK - 1) / EBX_TOK));
+#define PENEO_EBX_LAUNCH(T_)                                                                                                      \
+  {                                                                                                                               \
+    if (box_lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(embed_box_bwd_kernel<T_>),                       \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)box_lds) != hipSuccess) {     \
+      set_error("peneo_embed_text_bwd: cannot raise dynamic LDS to %zu bytes", box_lds);                                          \
+      return PENEO_ERR_LAUNCH;                                                                                                    \
+    }                                                                                                                             \
+    hipLaunchKernelGGL(embed_box_bwd_kernel<T_>, bgrid, dim3(256), box_lds, (hipStream_t)stream, (const T_*)d_out, rpb, bstride,  \
+                       bbox, *g, coord_size, shape_size, max_2d, rows, H, clip_hw);                                               \
+  }
+    if (dtype == PENEO_BF16) PENEO_EBX_LAUNCH(bf16_t) else PENEO_EBX_LAUNCH(float)
+#undef PENEO_EBX_LAUNCH
+    int rc = check_launch("peneo_embed_text_bwd (box tables)");
+    if (rc) return rc;
+    rest.x = rest.y = rest.h = rest.w = nullptr;
+    if (!rest.word) return PENEO_OK;
+  }
   if (dtype == PENEO_BF16)
     hipLaunchKernelGGL(embed_text_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_out, rpb,
-                       bstride, input_ids, pos_ids, bbox, *g, coord_size, shape_size, max_2d, rows, H, clip_hw, pad_id);
+                       bstride, input_ids, pos_ids, bbox, rest, coord_size, shape_size, max_2d, rows, H, clip_hw, pad_id);
   else
     hipLaunchKernelGGL(embed_text_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)d_out, rpb,
-                       bstride, input_ids, pos_ids, bbox, *g, coord_size, shape_size, max_2d, rows, H, clip_hw, pad_id);
+                       bstride, input_ids, pos_ids, bbox, rest, coord_size, shape_size, max_2d, rows, H, clip_hw, pad_id);
   return check_launch("peneo_embed_text_bwd");
 }
 

@@ -137,18 +137,28 @@ def zeros_like_param(p: torch.Tensor) -> torch.Tensor:
     return torch.zeros(p.shape, dtype=torch.float32, device=p.device)
 
 
-def zeros_like_params(params) -> dict:
+def zeros_like_params(params, fill_stream=None):
     """{id(p): zeroed fp32 gradient buffer}: views of ONE zero-filled allocation (one fill launch instead of one per
-    parameter); every view starts on a 16-byte boundary."""
+    parameter); every view starts on a 16-byte boundary.  With `fill_stream` the buffer is allocated here (the current stream's
+    pool) but zeroed on that stream, and (dict, event) is returned: the user waits for the event before the first write."""
     params = [p for p in params if p is not None]
     if not params:
-        return {}
+        return {} if fill_stream is None else ({}, None)
     offs, total = [], 0
     for p in params:
         offs.append(total)
         total += (p.numel() + 3) // 4 * 4
-    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
-    return {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+    dev = params[0].device
+    if fill_stream is None:
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        return {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    fill_stream.wait_stream(torch.cuda.current_stream(dev))   # behind whatever used this memory before
+    with torch.cuda.stream(fill_stream):
+        flat.zero_()
+        ev = torch.cuda.Event()
+        ev.record(fill_stream)
+    return {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}, ev
 
 
 # ---- side streams ------------------------------------------------------------------------------------------------
