@@ -27,6 +27,7 @@ HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_gro
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
               "line_grouping_head_rel_shaking_tag", "line_grouping_tail_rel_shaking_tag")
 HEAD_CLASSES = (2, 3, 3, 3, 3)
+_HEAD_OF_CLASS_SLOT: dict = {}   # device -> int64 [sum(HEAD_CLASSES)]: head index of every class slot
 
 
 class HandshakingTaggingScheme:
@@ -397,12 +398,17 @@ class _DecoderStage(torch.autograd.Function):
         D = sv["D"]
         nh = len(HEAD_NAMES)
         dw2, db1cat = ops.pair_dz_finish(dz_ws, nh, D, HEAD_CLASSES)
-        db2cat = sv["dls"]
+        # db2 of head h = its dlogit sums x scale_h: one multiply for all heads (was one tiny kernel per head on the main stream)
+        hidx = _HEAD_OF_CLASS_SLOT.get(scale.device)
+        if hidx is None:
+            hidx = _HEAD_OF_CLASS_SLOT[scale.device] = torch.tensor([h for h, c in enumerate(HEAD_CLASSES) for _ in range(c)],
+                                                                    device=scale.device)
+        db2cat = sv["dls"] * scale[hidx]
         head_grads = []
         off = 0
         for h in range(nh):
             c = HEAD_CLASSES[h]
-            head_grads += [dW1cat[h * D:(h + 1) * D], db1cat[h * D:(h + 1) * D], dw2[h], db2cat[off:off + c] * scale[h]]
+            head_grads += [dW1cat[h * D:(h + 1) * D], db1cat[h * D:(h + 1) * D], dw2[h], db2cat[off:off + c]]
             off += c
         return _DecoderStage._front_backward(ctx, dec, sv, params, d_ab, head_grads, w1s)
 
