@@ -384,6 +384,42 @@ def test_patch_embed_pieces(ops, dtype):
     assert rel_err(dp, dv.float().sum(0)) < 1e-5 and rel_err(dc, dv.float()[:, 0].sum(0)) < 1e-5
 
 
+def test_relpos_inputs_one_launch(ops):
+    """peneo_relpos_inputs: key mask over text + visual tokens and the per-token inputs of the bucket maps (the reference builds
+    them with arange / cat / slicing: modeling_layoutlmv3.py:1052-1080, 586-676)."""
+    B, S, nv = 3, 40, 17
+    g = torch.Generator().manual_seed(2)
+    am = (torch.rand(B, S, generator=g) > 0.2).long().to(DEV)
+    bbox = torch.randint(0, 1000, (B, S, 4), generator=g).to(DEV)
+    vx = torch.randint(0, 1000, (nv,), generator=g).int().to(DEV)
+    vy = torch.randint(0, 1000, (nv,), generator=g).int().to(DEV)
+    km, pos, xs, ys = ops.relpos_inputs(am, bbox, vx, vy, B, S, nv, True, True)
+    assert torch.equal(km, torch.cat([am.int(), torch.ones(B, nv, dtype=torch.int32, device=DEV)], 1))
+    assert torch.equal(pos, torch.cat([torch.arange(S), torch.arange(nv)]).int().to(DEV).expand(B, -1))
+    assert torch.equal(xs, torch.cat([bbox[..., 0].int(), vx.expand(B, -1)], 1))
+    assert torch.equal(ys, torch.cat([bbox[..., 3].int(), vy.expand(B, -1)], 1))
+    km2, pos2, xs2, ys2 = ops.relpos_inputs(None, bbox, None, None, B, S, 0, False, True)     # no mask given, no visual tokens, no 1-D part
+    assert pos2 is None and bool((km2 == 1).all()) and torch.equal(xs2, bbox[..., 0].int()) and torch.equal(ys2, bbox[..., 3].int())
+
+
+def test_attention_drop_words_sets_are_independent_and_reproducible(ops):
+    """One launch makes the keep bits of several calls (layers): same seed -> same bits, another seed or another set -> other bits,
+    every set at the requested keep rate."""
+    B, nh, T, p_drop = 2, 3, 300, 0.1
+    w1 = ops.attn_drop_words(B, nh, T, p_drop, 123, sets=4)
+    w2 = ops.attn_drop_words(B, nh, T, p_drop, 123, sets=4)
+    w3 = ops.attn_drop_words(B, nh, T, p_drop, 124, sets=4)
+    assert torch.equal(w1, w2) and not torch.equal(w1, w3)
+    assert w1.shape[:2] == (4, B * nh) and w1.shape[2] * 32 >= T and w1.shape[3] >= T
+    bits = ((w1.long().unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1).float()
+    for s_ in range(4):
+        rate = float(bits[s_].mean())
+        assert abs(rate - (1 - p_drop)) < 2e-3, (s_, rate)
+        if s_:
+            assert not torch.equal(w1[s_], w1[0])
+
+
+
 # ---------------------------------------------------------------------------------------------- rel-pos bias
 def test_relpos_buckets_and_bias(ops):
     from oracle import peneo_oracle as O
