@@ -124,6 +124,7 @@ class _FwdState:
         self.dtype = torch.float32
         self.dims = None       # (B, S, T)
         self.grad_pools = None  # [layers, pool] fp32 accumulators of the layer stages' backward (one zero fill per step)
+        self.grad_mode = False  # torch.is_grad_enabled() of the model call (inside an autograd.Function it is always off)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -205,7 +206,7 @@ class _EmbedStage(torch.autograd.Function):
         # the gradient buffers of this stage (the 154 MB word table among them) are zero-filled NOW, on a side stream beside the
         # forward: filled in the backward they sat on the critical path at the very end of the step (128 us)
         ctx.g_pre = None
-        if any(ctx.needs_input_grad[6:]):
+        if st.grad_mode and any(ctx.needs_input_grad[6:]):   # (needs_input_grad is set under no_grad too)
             ctx.g_pre = zeros_like_params(params, fill_stream=model.side_stream(dev, "rel"))
         return emb.view(B * T, H)
 
@@ -619,6 +620,7 @@ class LayoutLMv3Model(nn.Module):
         self.refresh_working_weights(self.compute_dtype)
         st = _FwdState()
         st.dtype = self.compute_dtype
+        st.grad_mode = torch.is_grad_enabled()
         st.seeds = DropoutSeeds(self.training, cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob)
         x = _EmbedStage.apply(self, st, input_ids.contiguous(), bbox.contiguous(),
                               attention_mask.contiguous() if attention_mask is not None else None, image,

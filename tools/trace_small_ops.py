@@ -12,7 +12,16 @@ m = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"
 m.backbone.check_inputs = False
 b = {k: v.cuda() for k, v in synthetic_rfund_batch(8, 512, 128, 50265, seed=1).items()}
 
+EVAL = os.environ.get("EVAL", "0") == "1"      # EVAL=1: the eval forward alone
+if EVAL:
+    m.eval()
+
+
 def step():
+    if EVAL:
+        with torch.no_grad():
+            m(**b)
+        return
     for p in m.parameters():
         p.grad = None
     m(**b)["loss"].backward()
@@ -27,7 +36,7 @@ LEAF = {"aten::fill_", "aten::zero_", "aten::copy_", "aten::mul", "aten::mul_", 
         "aten::sub", "aten::div", "aten::sum", "aten::stack", "aten::index_select", "aten::where", "aten::eq", "aten::ne", "aten::cumsum", "aten::_to_copy",
         "aten::clone", "aten::contiguous", "aten::zeros", "aten::zeros_like", "aten::full", "aten::ones", "aten::sqrt", "aten::rsqrt", "aten::exp",
         "aten::masked_fill_", "aten::masked_fill", "aten::bitwise_and", "aten::lt", "aten::gt", "aten::ge", "aten::le", "aten::index", "aten::gather"}
-KERNEL = {"aten::zero_", "aten::fill_", "aten::copy_", "aten::mul", "aten::mul_", "aten::cat", "aten::neg", "aten::arange", "aten::add", "aten::add_", "aten::sub",
+KERNEL = {"aten::zero_", "aten::fill_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::empty_like", "aten::expand", "aten::reshape", "aten::copy_", "aten::mul", "aten::mul_", "aten::cat", "aten::neg", "aten::arange", "aten::add", "aten::add_", "aten::sub",
           "aten::div", "aten::sum", "aten::index_select", "aten::where", "aten::eq", "aten::ne", "aten::cumsum", "aten::masked_fill_", "aten::index",
           "aten::gather", "aten::lt", "aten::gt", "aten::ge", "aten::le", "aten::bitwise_and", "aten::sqrt", "aten::rsqrt", "aten::exp"}
 cnt = collections.Counter()
