@@ -562,10 +562,11 @@ def test_attention_bf16_single_pass_matches_two_kernel_path_with_dropout(ops, d)
         assert rel_err(b_, a_) < 1e-2
 
 
-def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops):
+@pytest.mark.parametrize("B,nh,T,d", [(2, 3, 200, 64), (1, 2, 129, 80), (2, 2, 70, 32)])
+def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops, B, nh, T, d):
     """The forward's keep mask is read off with one-hot V blocks (out = dropped probabilities), its rate is checked, and an
     autograd statement of softmax -> that mask -> PV must give the gradients of the fused backward (same seed)."""
-    B, nh, T, d, p_drop, seed = 2, 3, 200, 64, 0.2, 1234
+    p_drop, seed = 0.2, 1234
     H = nh * d
     g = torch.Generator().manual_seed(5)
     qkv = (0.7 * torch.randn(B * T, 3 * H, generator=g)).to(DEV).to(torch.bfloat16)
@@ -585,8 +586,9 @@ def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops):
     keep = dropped != 0          # probabilities are > 0 everywhere (no masked keys here)
     rate = float(keep.float().mean())
     assert abs(rate - (1 - p_drop)) < 4 * math.sqrt(p_drop * (1 - p_drop) / keep.numel()) + 1e-4, rate
-    # both keys of a pair share one hash but not one decision
-    assert 0.05 < float((keep[..., 0::2] != keep[..., 1::2]).float().mean()) < 2 * p_drop
+    # neighbouring keys decide independently
+    n2 = T // 2 * 2
+    assert 0.05 < float((keep[..., 0:n2:2] != keep[..., 1:n2:2]).float().mean()) < 2 * p_drop
     # a different seed gives a different mask, the same seed the same one
     o1, lse = ops.attn_fwd(q, k, v, B, nh, T, d, scale, bias, None, drop_p=p_drop, drop_seed=seed)
     o2, _ = ops.attn_fwd(q, k, v, B, nh, T, d, scale, bias, None, drop_p=p_drop, drop_seed=seed)
@@ -608,7 +610,7 @@ def test_attention_dropout_mask_of_the_forward_is_the_mask_of_the_backward(ops):
         assert rel_err(dqkv, leaf.grad) < 4e-2, (single, rel_err(dqkv, leaf.grad))
 
 
-@pytest.mark.parametrize("B,nh,T,d", [(2, 2, 70, 16), (2, 2, 200, 64), (4, 12, 1389, 64)])
+@pytest.mark.parametrize("B,nh,T,d", [(2, 2, 70, 16), (2, 2, 200, 64), (4, 12, 1389, 64), (1, 3, 17, 32), (2, 2, 129, 80), (1, 2, 257, 128)])
 def test_attention_keep_words_are_the_forward_mask_in_both_precisions(ops, B, nh, T, d):
     """peneo_attn_drop_words defines the mask: bit (q & 31) of words[b * nh + h][q >> 5][kslot(key)].  The forward's mask is read
     off with one-hot V blocks for the fp32 and the bf16 kernel and must be exactly that bit map (the two kernels schedule the
@@ -628,7 +630,7 @@ def test_attention_keep_words_are_the_forward_mask_in_both_precisions(ops, B, nh
     q = torch.arange(T, device=DEV)
     ww = w.view(B, nh, -1, Tk).long() & 0xFFFFFFFF
     ref = ((ww[:, :, (q >> 5)][:, :, :, ks] >> (q & 31).view(1, 1, T, 1)) & 1).bool()
-    assert abs(float(ref.float().mean()) - (1 - p_drop)) < 0.02
+    assert abs(float(ref.float().mean()) - (1 - p_drop)) < 4 * math.sqrt(p_drop * (1 - p_drop) / ref.numel()) + 2e-3
     for dt in (torch.float32, torch.bfloat16):
         dropped = torch.zeros(B, nh, T, T, device=DEV)
         for j in range(0, T, d):
