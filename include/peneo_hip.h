@@ -260,7 +260,7 @@ int peneo_relpos_bias_bwd(const float* g, int64_t ldg, const uint8_t* bk1, const
  *
  * Dropout on the attention probabilities (modeling_layoutlmv3.py:396-399): the keep bits of one call are made by
  * peneo_attn_drop_words - a pure function of (seed, word index), Bernoulli(1 - p) per bit with p realised to 2^-17 - into
- * `words`, uint32 [B * nh][n_query_blocks][n_key_slots] (peneo_attn_drop_words_dims; 64-byte aligned), and handed to the
+ * `words`, uint32 [B * nh][n_query_blocks][n_key_slots] (peneo_attn_drop_words_dims), and handed to the
  * forward and to the backward of that call (`drop_words`; NULL with drop_p = 0).  One dword holds the 32 queries of a
  * block for one key; the key slots of a 32-key block are ordered as the forward kernel's accumulator registers see them,
  * so the kernels read whole select masks instead of hashing per element (csrc/attention.hip, top).

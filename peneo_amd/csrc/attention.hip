@@ -1420,8 +1420,8 @@ extern "C" int peneo_attn_fwd(int dtype, const void* q, const void* k, const voi
   PENEO_REQUIRE(q && k && out && (vt || (v && dtype == PENEO_BF16)), "peneo_attn_fwd: null pointer (fp32 needs the transposed copy vt)");
   PENEO_REQUIRE(ld_qk >= (int64_t)nh * d && ld_out >= (int64_t)nh * d, "peneo_attn_fwd: leading dims too small");
   PENEO_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "peneo_attn_fwd: drop_p out of range");
-  PENEO_REQUIRE(drop_p == 0.f || (drop_words && (reinterpret_cast<uintptr_t>(drop_words) & 63) == 0),
-                "peneo_attn_fwd: drop_p > 0 needs the keep words of peneo_attn_drop_words (64-byte aligned)");
+  PENEO_REQUIRE(drop_p == 0.f || (drop_words && (reinterpret_cast<uintptr_t>(drop_words) & 3) == 0),
+                "peneo_attn_fwd: drop_p > 0 needs the keep words of peneo_attn_drop_words");
   AttnParams p = {};
   p.q = q; p.k = k; p.v = v; p.ld = ld_qk; p.vt = vt; p.B = B; p.nh = nh; p.T = T; p.d = d; p.Tp = peneo_attn_padded_len(T);
   p.scale = scale; p.bias = bias; p.bias_ld = bias_ld; p.key_bias = key_bias; p.out = out; p.ld_out = ld_out; p.lse = lse;
