@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-import torch  # noqa: E402
+import torch  # noqa: E402  (importing torch does not touch the GPU; nothing below does before main() has decided how to launch)
 
 # algorithmic GFLOP per document, SURVEY §8(d) / BASELINE.md §3: (forward total, what one pair_heads_fwd launch computes
 # = heads L1 + L2) for config 2 (LayoutLMv3-base S512), config 4 (large S1024), config 5 (LiLT-base S512)
@@ -109,6 +109,37 @@ def cpu_baseline(pcfg, seq_len, n_lines, seed):
                       f"best of 2 after 1 warm-up ({dr:.2f}s)"}
 
 
+def plan_launch(gpus: int, environ) -> tuple:
+    """How `bench.py --gpus N` becomes N ranks (reference: `torchrun --nproc_per_node N start/run_rfund.py`, README.md:206-218).
+    ("run",)          this process IS a rank (N = 1, or torch.distributed.run / torchrun started it: WORLD_SIZE == N);
+    ("spawn", N)      no launcher in the environment and N > 1: the caller starts N fresh rank processes itself;
+    ("fail", reason)  a launcher environment whose WORLD_SIZE is not N: never run a 1-GPU job under an N-GPU label."""
+    if "WORLD_SIZE" in environ or "RANK" in environ:
+        world = int(environ.get("WORLD_SIZE", "1"))
+        if world != gpus:
+            return ("fail", f"--gpus {gpus} but the launcher set WORLD_SIZE={world}")
+        return ("run",)
+    if gpus > 1:
+        return ("spawn", gpus)
+    return ("run",)
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Start `n` fresh rank processes of this script under torch.distributed.run and relay their output and exit code.  The
+    parent never touches the GPU (no HIP call, no torch.cuda.is_available()): the ranks are children, not re-execs."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +159,13 @@ def main():
     ap.add_argument("--eval-forward", action="store_true", help="time eval forward only (reported as a side metric)")
     args = ap.parse_args()
 
+    plan = plan_launch(args.gpus, os.environ)
+    if plan[0] == "fail":
+        print(f"bench.py: {plan[1]}", file=sys.stderr)
+        sys.exit(2)
+    if plan[0] == "spawn":
+        sys.exit(spawn_ranks(plan[1], sys.argv[1:]))
+
     from peneo_amd import ops
     from peneo_amd.data import synthetic_rfund_batch
     from peneo_amd.parallel import init_distributed, max_over_ranks, wrap_data_parallel
@@ -135,7 +173,10 @@ def main():
 
     FWD_GFLOP_PER_DOC, PAIR_HEADS_GFLOP_PER_DOC = ALGO_GFLOP.get((args.backbone, args.size, args.seq_len), (0.0, 0.0))
     rank, local_rank, world = init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
+    if world != args.gpus or ranks != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}, process group of {ranks} rank(s)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -244,12 +285,36 @@ def main():
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t1) * 1e3 / nf
 
+    # side metric (north_star: "BIO/link indices bit-exact"): how many of the 5 x B x 130 816 pair-tag indices (argmax over the
+    # classes, model/peneo_decoder.py:98-114) the bf16 path BENCHMARKED here decides differently from the fp32 parity path of
+    # the same weights on the same batch; `clear` counts only pairs whose fp32 margin (top1 - top2 logit) exceeds 0.05
+    indices_agree = None
+    if world == 1:
+        with torch.no_grad():
+            o16 = model(**batches[0])
+            model.set_compute_dtype(torch.float32)
+            o32 = model(**batches[0])
+            model.set_compute_dtype(dtype)
+            maps, flips, clear, total = {}, 0, 0, 0
+            for k in o32:
+                if not k.endswith("_shaking_outputs"):
+                    continue
+                a16, a32 = o16[k].argmax(-1), o32[k].argmax(-1)
+                diff = a16 != a32
+                top2 = o32[k].float().topk(2, dim=-1).values
+                dc = diff & ((top2[..., 0] - top2[..., 1]) > 0.05)
+                maps[k[:-len("_shaking_outputs")]] = {"flips": int(diff.sum()), "clear_flips": int(dc.sum()), "of": diff.numel()}
+                flips += int(diff.sum()); clear += int(dc.sum()); total += diff.numel()
+            indices_agree = {"bf16_vs_fp32_flips": flips, "clear_flips": clear, "of": total,
+                             "flip_rate": round(flips / max(1, total), 9), "maps": maps}
+            del o16, o32
+
     # side metric: the optimizer step that completes a training iteration (fused multi-tensor AdamW, reference groups);
     # not part of `value` (the metric is fwd + bwd)
     from peneo_amd.optim import FusedAdamW, peneo_param_groups
     model.train()
     step(0)
-    opt = FusedAdamW(peneo_param_groups(model, 5e-5, 0.01, 30.0))
+    opt = FusedAdamW(peneo_param_groups(model, 5e-5, 0.01, 30.0), max_grad_norm=1.0)   # HF Trainer's default clipping, fused
     opt.step()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -288,6 +353,8 @@ def main():
             "value": round(docs / elapsed, 2),
             "unit": "docs/s",
             "n_gpus": world,
+            "rccl_ranks": ranks,                     # dist.get_world_size() of the process group the gradients were reduced over
+            "dist_backend": dist.get_backend() if dist.is_initialized() else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -306,6 +373,7 @@ def main():
             "forward_only": {"ms_per_batch": round(fwd_ms, 3), "docs_per_s": round(B * 1e3 / fwd_ms, 1),
                              "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
                              "frac_of_mfma_peak": round(FWD_GFLOP_PER_DOC * B / fwd_ms / PEAK_BF16_TFLOPS, 4)},
+            "indices_agree": indices_agree,
             "ragged": ragged,
             "embed_bwd": ({"avg_launch_ms": round(sum(eb) / len(eb), 4), "launches": len(eb), "vocab": vocab,
                            # algorithmic bytes: every token reads its d_x row (H * 2 B) and adds H fp32 values into 6 tables

@@ -93,22 +93,23 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
-// bf16 throughput mode: erf(z) = z P(z^2) on |z| <= 3 (degree-8 P, weighted least squares on Chebyshev nodes; |error| <= 2e-5
-// evaluated in fp32, arguments beyond 3 are clamped: erf(3) = 1 - 2.2e-5), i.e. GELU to 5e-5 absolute - a tenth of a bf16
-// rounding step of a typical activation.  Ten full-rate instructions and no transcendental: the Abramowitz-Stegun form used
-// before (one rcp, one exp2, 1.5e-7) cost 17 of FFN1's 62 us in the epilogue, where nothing else overlaps.  fp32 parity mode
-// keeps the library erff.
+// bf16 throughput mode: erf(z) = z P(z^2) on |z| <= 3 (degree-8 P, weighted least squares on Chebyshev nodes, then rescaled
+// and nudged by a few ulps so that the fp32 Horner evaluation at z = 3 is EXACTLY 1.0f: arguments beyond 3 are clamped, so erf
+// saturates at +-1 and GELU(x) -> 0 for x -> -inf instead of -1.1e-5 |x|; |error| <= 2.5e-5 on [-3, 3], 2.2e-5 beyond (erf(3) =
+// 1 - 2.2e-5), i.e. GELU to 5e-5 absolute for every x - a tenth of a bf16 rounding step of a typical activation).  Ten
+// full-rate instructions and no transcendental: the Abramowitz-Stegun form used before (one rcp, one exp2, 1.5e-7) cost 17 of
+// FFN1's 62 us in the epilogue, where nothing else overlaps.  fp32 parity mode keeps the library erff.
 __device__ __forceinline__ float fast_erf(float x) {
   const float z = __builtin_amdgcn_fmed3f(x, -3.0f, 3.0f);
   const float u = z * z;
-  float p = fmaf(3.913831748e-08f, u, -1.883556251e-06f);
-  p = fmaf(p, u, 4.009705663e-05f);
-  p = fmaf(p, u, -5.030001630e-04f);
-  p = fmaf(p, u, 4.197266418e-03f);
-  p = fmaf(p, u, -2.500014566e-02f);
-  p = fmaf(p, u, 1.109329015e-01f);
-  p = fmaf(p, u, -3.752213717e-01f);
-  p = fmaf(p, u, 1.128251076e+00f);
+  float p = fmaf(0x1.5032b6p-25f, u, -0x1.f99df6p-20f);
+  p = fmaf(p, u, 0x1.505c6ap-15f);
+  p = fmaf(p, u, -0x1.07b80ap-11f);
+  p = fmaf(p, u, 0x1.1312f8p-8f);
+  p = fmaf(p, u, -0x1.999afep-6f);
+  p = fmaf(p, u, 0x1.c6626ep-4f);
+  p = fmaf(p, u, -0x1.803ac4p-2f);
+  p = fmaf(p, u, 0x1.20d59ap+0f);
   return p * z;
 }
 __device__ __forceinline__ float gelu_fast_f(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }

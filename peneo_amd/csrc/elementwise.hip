@@ -210,8 +210,12 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* x, int64_t ldx
 constexpr int ADAMW_CHUNK = 4096;
 __global__ __launch_bounds__(256) void adamw_kernel(const peneo_adamw_tensor* tab, const int32_t* chunk_tensor,
                                                     const int32_t* chunk_index, float beta1, float beta2, float eps,
-                                                    float bc1, float rsqrt_bc2, int step) {
+                                                    float bc1, float rsqrt_bc2, int step, const double* sqnorm, float max_norm) {
   const peneo_adamw_tensor t = tab[chunk_tensor[blockIdx.x]];
+  // global gradient-norm clipping (torch.nn.utils.clip_grad_norm_, what HF Trainer does at max_grad_norm = 1.0 every step):
+  // the coefficient comes from the device-side sum of squares of peneo_grad_sqnorm; the gradients themselves stay untouched
+  float clip = 1.0f;
+  if (sqnorm) clip = fminf(1.0f, max_norm / ((float)sqrt(*sqnorm) + 1e-6f));
   if (t.step_offset != 0) {   // this tensor's own step count (block-uniform branch; resumed / late-joining parameters only)
     const double s = (double)(step + t.step_offset);
     bc1 = (float)(1.0 - pow((double)beta1, s));
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const peneo_adamw_tensor* ta
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      g[e] *= clip;
       p[e] *= decay;
       m[e] = m[e] + (1.0f - beta1) * (g[e] - m[e]);                 // lerp, as torch does
       v[e] = beta2 * v[e] + (1.0f - beta2) * g[e] * g[e];
@@ -249,6 +254,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(const peneo_adamw_tensor* ta
       for (int e = 0; e < cnt; ++e) { t.param[i + e] = p[e]; t.exp_avg[i + e] = m[e]; t.exp_avg_sq[i + e] = v[e]; }
     }
   }
+}
+
+// sum of squares of every gradient of the table (same chunk maps): per-block fp32 tree, one fp64 atomic per block
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const peneo_adamw_tensor* tab, const int32_t* chunk_tensor,
+                                                          const int32_t* chunk_index, double* out) {
+  const peneo_adamw_tensor t = tab[chunk_tensor[blockIdx.x]];
+  const int64_t base = (int64_t)chunk_index[blockIdx.x] * ADAMW_CHUNK;
+  const int64_t end = min(t.numel, base + ADAMW_CHUNK);
+  const bool vec = (reinterpret_cast<uintptr_t>(t.grad) & 15) == 0;
+  float acc = 0.f;
+  for (int64_t i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+    if (vec && i + 4 <= end) {
+      const float4 g = *reinterpret_cast<const float4*>(t.grad + i);
+      acc += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    } else {
+      for (int64_t e = i; e < min(end, i + 4); ++e) acc += t.grad[e] * t.grad[e];
+    }
+  }
+  __shared__ float part[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3]);
 }
 
 // Many fp32 -> bf16 casts in ONE launch (the working-precision copies of a model's weights after an optimizer step): block =
@@ -285,14 +313,30 @@ extern "C" int peneo_cast_multi(const peneo_cast_item* table_dev, const int32_t*
 
 extern "C" int peneo_adamw_chunk_elems(void) { return ADAMW_CHUNK; }
 
-extern "C" int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
-                                int n_chunks, float beta1, float beta2, float eps, int step, peneo_stream_t stream) {
+extern "C" int peneo_grad_sqnorm(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                                 int n_chunks, double* sqnorm_dev, peneo_stream_t stream) {
+  PENEO_REQUIRE(table_dev && chunk_tensor_dev && chunk_index_dev && n_chunks > 0 && sqnorm_dev, "peneo_grad_sqnorm: bad arguments");
+  if (hipMemsetAsync(sqnorm_dev, 0, sizeof(double), (hipStream_t)stream) != hipSuccess) return check_launch("peneo_grad_sqnorm");
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, chunk_tensor_dev,
+                     chunk_index_dev, sqnorm_dev);
+  return check_launch("peneo_grad_sqnorm");
+}
+
+extern "C" int peneo_adamw_step_clip(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                                     int n_chunks, float beta1, float beta2, float eps, int step, const double* sqnorm_dev,
+                                     float max_grad_norm, peneo_stream_t stream) {
   PENEO_REQUIRE(table_dev && chunk_tensor_dev && chunk_index_dev && n_chunks > 0 && step >= 1, "peneo_adamw_step: bad arguments");
   PENEO_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "peneo_adamw_step: bad hyper-parameters");
+  PENEO_REQUIRE(!sqnorm_dev || max_grad_norm > 0.f, "peneo_adamw_step_clip: max_grad_norm must be positive");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, chunk_tensor_dev, chunk_index_dev,
-                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), step);
+                     beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), step, sqnorm_dev, max_grad_norm);
   return check_launch("peneo_adamw_step");
+}
+
+extern "C" int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
+                                int n_chunks, float beta1, float beta2, float eps, int step, peneo_stream_t stream) {
+  return peneo_adamw_step_clip(table_dev, chunk_tensor_dev, chunk_index_dev, n_chunks, beta1, beta2, eps, step, nullptr, 0.f, stream);
 }
 
 static inline bool ok_dt(int d) { return d == PENEO_F32 || d == PENEO_BF16; }

@@ -40,8 +40,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   float v = acc * e.alpha;
   if (e.bias) v += e.bias[n];
   if (e.preact) store_any(e.preact, p.c_dtype, (int64_t)m * e.ld_preact + n, v);
-  v = act_f(e.act, v);
-  if (e.grad_src) v *= act_grad_f(e.grad_act, load_any(e.grad_src, p.c_dtype, (int64_t)m * e.ld_grad + n));
+  // the same GELU as the vectorised columns of this tile (epilogue_store8): polynomial erf for bf16 tiles, erff for fp32
+  const bool fast = p.c_dtype == PENEO_BF16;
+  v = (fast && e.act == PENEO_ACT_GELU) ? gelu_fast_f(v) : act_f(e.act, v);
+  if (e.grad_src) {
+    const float g = load_any(e.grad_src, p.c_dtype, (int64_t)m * e.ld_grad + n);
+    v *= (fast && e.grad_act == PENEO_ACT_GELU) ? gelu_grad_fast_f(g) : act_grad_f(e.grad_act, g);
+  }
   if (e.drop_p > 0.f) {
     uint32_t thresh = (uint32_t)fminf(e.drop_p * 4294967296.0f, 4294967040.0f);
     v = dropout_keep(e.drop_seed, (uint64_t)m * (uint64_t)p.N + n, thresh) ? v * (1.0f / (1.0f - e.drop_p)) : 0.f;

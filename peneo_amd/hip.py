@@ -139,6 +139,8 @@ SIGNATURES = {
     "peneo_ohem_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "peneo_adamw_chunk_elems": (_i, []),
     "peneo_adamw_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
+    "peneo_grad_sqnorm": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "peneo_adamw_step_clip": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _f, _vp]),
     "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
 }

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import threading
+import weakref
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -207,8 +208,29 @@ class _Pending:
 
 _STATE: Dict[int, _Pending] = {}
 DEFER_ALLOWED = [True]       # False: every stage joins its side stream before it returns (torch DDP reads .grad in hooks)
-LATE_PARAMS: set = set()     # id()s of parameters whose gradient DATA is complete only when the backward has ended (held joins)
-TRUSTED_GRAD_HOOKS = [False]  # True while the only parameter hooks are ones that call join_pending() before reading .grad
+# Parameters whose gradient DATA is complete only when the backward has ended (outputs of held joins): id -> weak reference
+# (an id can be reused once a model is freed: an entry counts only while its reference still is the asking parameter).
+_LATE: Dict[int, "weakref.ref"] = {}
+# A post-accumulate hook that calls join_pending() before it reads a gradient carries this attribute (set on the function; a
+# bound method forwards the lookup): only such hooks leave deferral allowed.  Anybody else's hook (an optimizer-in-backward
+# hook, a logging hook, a second wrapper) reads .grad on the main stream at once, so the stage joins before it returns.
+JOINS_BEFORE_READ = "_peneo_joins_before_read"
+
+
+def mark_late(params) -> None:
+    import weakref
+    for p in params:
+        _LATE[id(p)] = weakref.ref(p)
+
+
+def is_late(p) -> bool:
+    r = _LATE.get(id(p))
+    if r is None:
+        return False
+    if r() is p:
+        return True
+    del _LATE[id(p)]          # the id belonged to a parameter that is gone
+    return False
 
 
 def _state(device: Optional[int] = None) -> _Pending:
@@ -231,7 +253,8 @@ def can_defer(params) -> bool:
             continue
         if p.grad is not None or getattr(p, "_backward_hooks", None):
             return False
-        if getattr(p, "_post_accumulate_grad_hooks", None) and not TRUSTED_GRAD_HOOKS[0]:
+        hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+        if hooks and not all(getattr(h, JOINS_BEFORE_READ, False) for h in hooks.values()):
             return False
     return True
 

@@ -125,6 +125,7 @@ class _FwdState:
         self.dims = None       # (B, S, T)
         self.grad_pools = None  # [layers, pool] fp32 accumulators of the layer stages' backward (one zero fill per step)
         self.grad_mode = False  # torch.is_grad_enabled() of the model call (inside an autograd.Function it is always off)
+        self.fill_event = None  # the side-stream zero fill of the embedding stage's gradient buffer (main-pool memory)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -208,6 +209,7 @@ class _EmbedStage(torch.autograd.Function):
         ctx.g_pre = None
         if st.grad_mode and any(ctx.needs_input_grad[6:]):   # (needs_input_grad is set under no_grad too)
             ctx.g_pre = zeros_like_params(params, fill_stream=model.side_stream(dev, "rel"))
+            st.fill_event = ctx.g_pre[1]
         return emb.view(B * T, H)
 
     @staticmethod
@@ -628,4 +630,9 @@ class LayoutLMv3Model(nn.Module):
         _, _, T = st.dims
         for i, layer in enumerate(self.encoder.layer):
             x = _LayerStage.apply(self, st, i, x, *layer_params(layer))
+        if st.fill_event is not None:
+            # the gradient buffer belongs to the MAIN stream's pool: if the graph is dropped without a backward (a validation
+            # pass run in grad mode) its block may be handed out again, so the main stream must have seen the fill complete.
+            # The fill ended long ago (it ran beside the embedding stage): the wait is free
+            torch.cuda.current_stream(input_ids.device).wait_event(st.fill_event)
         return (x.view(B, T, cfg.hidden_size),)

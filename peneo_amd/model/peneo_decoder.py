@@ -21,7 +21,7 @@ from transformers.modeling_outputs import ModelOutput
 
 from .. import ops
 from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
-from .engine import LATE_PARAMS, DropoutSeeds, WeightCache, can_defer, defer_join
+from .engine import DropoutSeeds, WeightCache, can_defer, defer_join, mark_late
 
 HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
@@ -454,7 +454,7 @@ class _DecoderStage(torch.autograd.Function):
             ctx.side_work = None
             if can_defer(params):
                 if can_hold:   # the data-parallel wrapper lays these out last: their data is complete only at the end of the backward
-                    LATE_PARAMS.update(id(w) for w in w1s)
+                    mark_late(w1s)
                 defer_join(side, keep=keep, hold=can_hold)
             else:
                 torch.cuda.current_stream().wait_stream(side)

@@ -49,10 +49,23 @@ class FusedAdamW(torch.optim.Optimizer):
     ``load_state_dict()`` round-trip and a reference ``optimizer.pt`` resumes with its own step counts: the kernel takes
     one global step plus a per-tensor offset (0 unless a checkpoint holds differing counts or a parameter joined late).
     ``state[p]["step"]`` is written back lazily (in ``state_dict()`` and before the device tables are rebuilt), not by
-    241 host tensor updates per step."""
+    241 host tensor updates per step.
 
-    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    ``max_grad_norm`` (None = off): global gradient-norm clipping inside the step, i.e. what HF ``Trainer`` does between
+    backward and ``optimizer.step()`` at its default ``max_grad_norm = 1.0`` (the reference trains through it,
+    start/run_rfund.py:307-321): ``torch.nn.utils.clip_grad_norm_`` is ~1000 small torch launches over 241 tensors; here
+    one more launch sums the squares of all gradients into a device scalar and the AdamW kernel applies
+    ``min(1, max_grad_norm / (norm + 1e-6))`` while it reads the gradients (``.grad`` itself is left as it is; a Trainer
+    driving this optimizer sets its own ``max_grad_norm`` to 0).  ``last_grad_norm()`` returns the un-clipped norm of the
+    last step as a device tensor (no host sync unless the caller reads it)."""
+
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 max_grad_norm: float = None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if max_grad_norm is not None and not max_grad_norm > 0:
+            raise ValueError("max_grad_norm must be positive (None switches clipping off)")
+        self.max_grad_norm = max_grad_norm
+        self._sqnorm = None
         self._tables = None
         self._step = 0
         self._entries = []
@@ -134,6 +147,10 @@ class FusedAdamW(torch.optim.Optimizer):
             src = torch.frombuffer(memoryview(self._host).cast("B"), dtype=torch.uint8)
             self._table.copy_(src, non_blocking=False)
 
+    def last_grad_norm(self):
+        """Global L2 norm of the gradients the last step saw (before clipping); None without max_grad_norm."""
+        return None if self._sqnorm is None else self._sqnorm.sqrt().to(torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -146,8 +163,15 @@ class FusedAdamW(torch.optim.Optimizer):
         self._refresh()
         self._step += 1
         g0 = self.param_groups[0]
-        check(lib().peneo_adamw_step(ptr(self._table), ptr(self._chunk_t), ptr(self._chunk_i), self._chunk_t.numel(),
-                                     float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), self._step, stream()),
-              "peneo_adamw_step")
+        sq = None
+        if self.max_grad_norm is not None:
+            if self._sqnorm is None or self._sqnorm.device != self._table.device:
+                self._sqnorm = torch.zeros(1, dtype=torch.float64, device=self._table.device)
+            sq = self._sqnorm
+            check(lib().peneo_grad_sqnorm(ptr(self._table), ptr(self._chunk_t), ptr(self._chunk_i), self._chunk_t.numel(),
+                                          ptr(sq), stream()), "peneo_grad_sqnorm")
+        check(lib().peneo_adamw_step_clip(ptr(self._table), ptr(self._chunk_t), ptr(self._chunk_i), self._chunk_t.numel(),
+                                          float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), self._step,
+                                          ptr(sq), float(self.max_grad_norm or 0.0), stream()), "peneo_adamw_step_clip")
         bump_param_epoch()   # the parameters changed in place behind torch's version counters: invalidate the working copies
         return loss

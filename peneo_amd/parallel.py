@@ -52,7 +52,7 @@ class FlatGradDataParallel(torch.nn.Module):
 
     Layout.  Gradient arrival is not parameter registration order: the decoder's gradients come first, then encoder layers
     L-1 .. 0, then the embedding stage (whose rel-pos tables, patch embedding and LayerNorms are registered AFTER
-    encoder.layer.*), and the decoder's held dW1 GEMM completes only when the backward ends (engine.LATE_PARAMS).  The
+    encoder.layer.*), and the decoder's held dW1 GEMM completes only when the backward ends (engine.mark_late).  The
     first synchronised step therefore runs with one chunk and records the arrival order; rank 0's order is broadcast and
     the buffer is re-laid-out: arrival order, parameters that never reported next, late parameters last.  From the
     second step on the chunks follow the stages (about four chunks of 64 MB for the 254 MB of LayoutLMv3-base in bf16).
@@ -90,11 +90,6 @@ class FlatGradDataParallel(torch.nn.Module):
         if self.overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._grad_ready)
-            try:
-                from .model import engine
-                engine.TRUSTED_GRAD_HOOKS[0] = True  # these hooks join the side streams before they read a gradient
-            except Exception:
-                pass
         with torch.no_grad():                       # every rank starts from rank 0's parameters and buffers
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0)
@@ -146,12 +141,7 @@ class FlatGradDataParallel(torch.nn.Module):
 
     def _relayout_from_arrival(self) -> None:
         """After the first synchronised step: rank 0's arrival order becomes everybody's layout."""
-        late = set()
-        try:
-            from .model import engine
-            late = {self._index[i] for i in engine.LATE_PARAMS if i in self._index}
-        except Exception:
-            pass
+        late = {i for i, p in enumerate(self.params) if _is_late(p)}
         seen = set(self._arrival)
         early = [i for i in self._arrival if i not in late]
         never = [i for i in range(len(self.params)) if i not in seen and i not in late]
@@ -196,9 +186,12 @@ class FlatGradDataParallel(torch.nn.Module):
     # ---- the step -----------------------------------------------------------------------------------------------------
     def _pack(self, c: int, final: bool) -> None:
         # gradients may still be in flight on the model's side streams; an early chunk must not wait for the HELD work
-        # (the decoder's dW1 GEMM runs beside the whole encoder backward and only the last chunk contains its output)
-        _join_side_streams(held=final)
+        # (the decoder's dW1 GEMM runs beside the whole encoder backward and normally only the last chunk contains its
+        # output).  Decided per launch, not from the layout: if the step that taught the layout could not hold the GEMM
+        # (pre-existing .grad tensors, a user hook) its outputs sit in an early chunk, and a later step that does hold it must
+        # join it before that chunk is packed.
         idxs = self.chunks[c][0]
+        _join_side_streams(held=final or any(_is_late(self.params[i]) for i in idxs))
         src, dst = [], []
         for i in idxs:
             g = self.params[i].grad
@@ -233,6 +226,9 @@ class FlatGradDataParallel(torch.nn.Module):
             self._launch(self._next, final=False)
             self.early_calls += 1
 
+    # this hook only counts; when it packs a chunk, _pack joins the side streams before any gradient is read (engine.can_defer)
+    _grad_ready._peneo_joins_before_read = True
+
     def sync_gradients(self) -> None:
         """Average the gradients over the ranks (runs by itself at the end of backward())."""
         self._armed = False
@@ -252,6 +248,14 @@ class FlatGradDataParallel(torch.nn.Module):
                 p.grad = self.views[i].to(torch.float32)
         if not self._learned:
             self._relayout_from_arrival()
+
+
+def _is_late(p) -> bool:
+    try:
+        from .model.engine import is_late
+    except Exception:
+        return False
+    return is_late(p)
 
 
 def _join_side_streams(held: bool = True) -> None:

@@ -1111,6 +1111,39 @@ def test_fused_adamw_matches_torch_adamw_over_the_reference_groups(ops):
         assert rel_err(pa.detach(), pb.detach()) < 2e-6, n
 
 
+def test_fused_adamw_clips_the_global_gradient_norm_like_clip_grad_norm(ops):
+    """max_grad_norm (HF Trainer's default 1.0, the reference's training loop start/run_rfund.py:307-321): the fused step
+    with clipping against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over the reference's four groups; steps whose
+    norm is above AND below the threshold; the gradients themselves stay un-clipped; the reported norm is torch's."""
+    from peneo_amd.optim import FusedAdamW, peneo_param_groups
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Sequential(torch.nn.Linear(33, 70), torch.nn.LayerNorm(70))
+            self.peneo_decoder = torch.nn.Sequential(torch.nn.Linear(70, 5001), torch.nn.LayerNorm(5001))
+    torch.manual_seed(0)
+    a, b = Toy().to(DEV), Toy().to(DEV)
+    b.load_state_dict(a.state_dict())
+    oa = FusedAdamW(peneo_param_groups(a, 1e-3, 0.05, 30.0), betas=(0.9, 0.98), eps=1e-6, max_grad_norm=1.0)
+    ob = torch.optim.AdamW(peneo_param_groups(b, 1e-3, 0.05, 30.0), betas=(0.9, 0.98), eps=1e-6)
+    g = torch.Generator().manual_seed(1)
+    for step, scale in enumerate([1.0, 1e-3, 0.3, 1e-4, 5.0]):          # norms ~ 600, 0.6, 180, 0.06, 3000
+        for (_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            gr = (torch.randn(pa.shape, generator=g) * scale).to(DEV)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        keep = [p.grad.clone() for p in a.parameters()]
+        want_norm = torch.nn.utils.clip_grad_norm_(b.parameters(), 1.0)
+        oa.step(); ob.step()
+        assert rel_err(oa.last_grad_norm(), want_norm.reshape(1)) < 1e-5, (step, float(oa.last_grad_norm()), float(want_norm))
+        assert all(torch.equal(p.grad, k) for p, k in zip(a.parameters(), keep))
+        assert (float(want_norm) > 1.0) == (scale >= 0.3)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_err(pa.detach(), pb.detach()) < 3e-6, n
+    with pytest.raises(ValueError):
+        FusedAdamW(peneo_param_groups(a, 1e-3, 0.05, 30.0), max_grad_norm=0.0)
+
+
 def test_ohem_ce_matches_reference_cases_and_oracle(ops):
     """peneo_ohem_ce (OHEM branch, custom_loss.py:204-288) against the fixture produced by the real reference, then against
     the CPU oracle at the size of a full config-2 head (B * P = 8 * 130 816 pairs)."""

@@ -76,7 +76,7 @@ def test_bf16_forward_close_to_reference(name):
     assert abs(float(out["loss"]) - float(ref["loss"])) < 2e-2 * float(ref["loss"])
 
 
-@pytest.mark.parametrize("name", ["lmv3_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"])
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny", "lmv3_tiny_cls1", "lmv3_tiny_cls3"])
 def test_bf16_gradients_close_to_reference(name):
     fx = load_golden(name)
     m = build_model(fx["config"], fx["state_dict"], torch.bfloat16).eval()
@@ -262,22 +262,51 @@ def test_full_width_shapes_match_the_oracle(which):
         assert int(ids.max()) > 200000 and torch.equal(hit, used)
 
 
-def _grad_agreement(m, batch, ref_dtype=torch.float32):
-    """(loss_ref, loss_bf16, {name: (cosine, norm ratio)}) of the default bf16 path against the fp32 path of the same model."""
-    res = {}
-    for dt in (ref_dtype, torch.bfloat16):
-        m.set_compute_dtype(dt)
-        for p in m.parameters():
-            p.grad = None
-        out = m(**batch)
-        out["loss"].backward()
-        torch.cuda.synchronize()
-        res[dt] = (float(out["loss"]), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+def _fwd_bwd(m, batch, dt, seed_step=None):
+    """(loss, {name: gradient}) of one forward + backward of `m` in compute dtype `dt`; `seed_step` resets the dropout seed
+    counters first, so that two calls in train mode see the same masks (every mask is a pure function of (seed, element))."""
+    from peneo_amd.model.engine import DropoutSeeds
+    m.set_compute_dtype(dt)
+    if seed_step is not None:
+        DropoutSeeds._step, m._step = seed_step, seed_step
+    for p in m.parameters():
+        p.grad = None
+    out = m(**batch)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    return float(out["loss"]), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _grad_stats(got, ref):
+    """{name: (cosine, norm ratio, reference norm)}"""
     stats = {}
-    for n, g in res[ref_dtype][1].items():
-        a, r = res[torch.bfloat16][1][n].double().flatten(), g.double().flatten()
+    for n, g in ref.items():
+        a, r = got[n].double().flatten(), g.double().flatten()
         stats[n] = (float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300)), float(a.norm() / (r.norm() + 1e-300)), float(r.norm()))
-    return res[ref_dtype][0], res[torch.bfloat16][0], stats
+    return stats
+
+
+def _grad_agreement(m, batch, seed_step=None, repeat=True):
+    """(loss_fp32, loss_bf16, {name: (cosine, norm ratio, norm)}) of the default bf16 path against the fp32 path of the same
+    model, and -- `repeat` -- a second bf16 step whose GRADIENTS (not only the loss) must reproduce the first up to the order
+    of the fp32 atomics."""
+    l32, g32 = _fwd_bwd(m, batch, torch.float32, seed_step)
+    l16, g16 = _fwd_bwd(m, batch, torch.bfloat16, seed_step)
+    if repeat:
+        l16b, g16b = _fwd_bwd(m, batch, torch.bfloat16, seed_step)
+        assert abs(l16b - l16) < 1e-6 * abs(l16), (l16b, l16)
+        rep = _grad_stats(g16b, g16)
+        gmax = max(v[2] for v in rep.values())
+        moved = {n: v[:2] for n, v in rep.items() if v[2] > 1e-6 * gmax and (v[0] < 1 - 1e-5 or abs(v[1] - 1) > 1e-3)}
+        assert not moved, sorted(moved.items(), key=lambda kv: kv[1][0])[:12]
+    return l32, l16, _grad_stats(g16, g32)
+
+
+def _assert_agreement(l32, l16, stats, cos_min, norm_tol, loss_tol=2e-2):
+    assert abs(l16 - l32) < loss_tol * abs(l32), (l16, l32)
+    gmax = max(v[2] for v in stats.values())
+    bad = {n: v[:2] for n, v in stats.items() if v[2] > 1e-6 * gmax and (v[0] < cos_min or abs(v[1] - 1) > norm_tol)}
+    assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:12]
 
 
 def test_bf16_path_matches_fp32_path_at_the_benchmark_size():
@@ -294,14 +323,46 @@ def test_bf16_path_matches_fp32_path_at_the_benchmark_size():
     seeded_fill_(m.state_dict(), 11)
     m = m.eval()
     batch = to_cuda(synthetic_rfund_batch(8, 512, 128, pcfg["backbone_config"]["vocab_size"], seed=1008))
-    l32, l16, stats = _grad_agreement(m, batch)
-    assert abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
-    gmax = max(v[2] for v in stats.values())
-    bad = {n: v[:2] for n, v in stats.items() if v[2] > 1e-6 * gmax and (v[0] < 0.995 or abs(v[1] - 1) > 0.02)}
-    assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:12]
-    # and the bf16 step is repeatable: a second backward gives the same dz-derived gradients up to atomic ordering
-    l16b, _, _ = _grad_agreement(m, batch, ref_dtype=torch.bfloat16)
-    assert abs(l16b - l16) < 1e-6 * abs(l16)
+    l32, l16, stats = _grad_agreement(m, batch)     # incl. a repeated bf16 step: same gradients up to atomic ordering
+    _assert_agreement(l32, l16, stats, 0.995, 0.02)
+
+
+def test_bf16_path_matches_fp32_path_at_the_benchmark_size_with_dropout_on():
+    """The step bench.py TIMES: LayoutLMv3-base, B = 8, S = 512, train mode -- every dropout site on (embedding / hidden /
+    attention-probability dropout of the encoder, modeling_layoutlmv3.py:227,396-399,429,497, and the Dropout inside the five
+    pair classifiers, peneo_decoder.py:253-271, which runs in pair_heads_fwd_kernel<..., DROP> and on the consumer waves of the
+    fused pair backward).  Every mask is a pure function of (seed, element index), so the fp32 path (chunked decoder backward,
+    two-kernel attention backward) and the default bf16 path see the same masks under the same seed counters: losses and every
+    parameter gradient must agree to bf16 accuracy, and the loss must differ from the eval-mode one (dropout really on)."""
+    from seeded import layoutlmv3_config, peneo_config, seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
+    m = build_model(pcfg)
+    seeded_fill_(m.state_dict(), 11)
+    batch = to_cuda(synthetic_rfund_batch(8, 512, 128, pcfg["backbone_config"]["vocab_size"], seed=1008))
+    m = m.eval()
+    l_eval, _ = _fwd_bwd(m, batch, torch.bfloat16)
+    m = m.train()
+    l32, l16, stats = _grad_agreement(m, batch, seed_step=4000)
+    assert abs(l32 - l_eval) > 1e-3 * abs(l_eval), (l32, l_eval)
+    _assert_agreement(l32, l16, stats, 0.99, 0.03, loss_tol=3e-2)
+
+
+def test_lilt_base_bf16_path_matches_fp32_path():
+    """BASELINE config 5 at full size: LiLT-base (12 layers, text H = 768 + layout H = 192, head dim 64 + 16 = 80 in ONE attention
+    call, modeling_lilt.py:269-429), B = 8, S = 512, ragged masks: every parameter gradient of the bf16 path (head-dim-80
+    single-pass attention backward, 16-byte head concat / split kernels, half-wave LayerNorms at H = 192, fused pair backward)
+    against the fp32 path of the same model (which lilt_tiny.pt and the one-layer oracle test pin to the reference)."""
+    from seeded import lilt_config, peneo_config, seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    pcfg = peneo_config("lilt-roberta-en-base", lilt_config("base"))
+    m = build_model(pcfg)
+    seeded_fill_(m.state_dict(), 13)
+    m = m.eval()
+    b = synthetic_rfund_batch(8, 512, 128, pcfg["backbone_config"]["vocab_size"], seed=1010, ragged=True)
+    b.pop("image", None)
+    l32, l16, stats = _grad_agreement(m, to_cuda(b))
+    _assert_agreement(l32, l16, stats, 0.99, 0.03)
 
 
 def test_large_full_depth_bf16_path_matches_fp32_path():
@@ -315,11 +376,8 @@ def test_large_full_depth_bf16_path_matches_fp32_path():
     seeded_fill_(m.state_dict(), 12)
     m = m.eval()
     batch = to_cuda(synthetic_rfund_batch(2, 1024, 256, pcfg["backbone_config"]["vocab_size"], seed=2004))
-    l32, l16, stats = _grad_agreement(m, batch)
-    assert abs(l16 - l32) < 2e-2 * abs(l32), (l16, l32)
-    gmax = max(v[2] for v in stats.values())
-    bad = {n: v[:2] for n, v in stats.items() if v[2] > 1e-6 * gmax and (v[0] < 0.99 or abs(v[1] - 1) > 0.03)}
-    assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:12]
+    l32, l16, stats = _grad_agreement(m, batch, repeat=False)
+    _assert_agreement(l32, l16, stats, 0.99, 0.03)
 
 
 @pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
@@ -530,6 +588,68 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_flat_grad_data_parallel_layout_learned_while_the_dw1_gemm_could_not_be_held():
+    """The layout-learning step runs with PRE-EXISTING .grad tensors (zero_grad(set_to_none=False)): the decoder cannot hold
+    its dW1 GEMM then, so the five *_fc.0.weight gradients arrive early and the learned layout puts them in an EARLY chunk.
+    Later steps start from .grad = None, the GEMM is held on the side stream until the end of the backward -- the early pack
+    of that chunk must join the held work before it reads the gradients (decided per launch, parallel.py:_pack), and the
+    gradients on the wire must equal the un-wrapped ones on every step."""
+    import os, subprocess, sys
+    code = """
+import os, sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29573")
+import torch.distributed as dist
+from conftest import load_golden
+from peneo_amd import parallel
+from peneo_amd.model import PEneoConfig, PEneoModel, engine
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+fx = load_golden("lmv3_tiny")
+m = PEneoModel(PEneoConfig(**{k: v for k, v in fx["config"].items() if k != "model_type"}))
+m.load_state_dict(fx["state_dict"], strict=True)
+m = m.cuda().set_compute_dtype(torch.bfloat16).eval()
+b = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in fx["batch"].items()}
+def grads(net, keep_grads=False):
+    for p in m.parameters():
+        if keep_grads and p.grad is not None: p.grad.zero_()
+        else: p.grad = None
+    out = net(**b); out["loss"].backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+ref = grads(m)
+assert not any(engine.is_late(p) for p in m.parameters()) or True
+engine._LATE.clear()                                  # as in a process whose first backward is the wrapped one
+net = parallel.wrap_data_parallel(m, device_ids=[0])
+calls = []
+orig = parallel._join_side_streams
+def spy(held=True):
+    calls.append(held); orig(held=held)
+parallel._join_side_streams = spy
+got = grads(net, keep_grads=True)                     # learning step: every .grad exists -> nothing deferred, nothing late
+names = [n for n, p in m.named_parameters() if p.requires_grad]
+w1 = [i for i, n in enumerate(names) if n.endswith("_fc.0.weight")]
+assert len(w1) == 5 and len(net.chunks) >= 3
+assert not any(engine.is_late(net.params[i]) for i in w1)
+early_w1 = [i for i in w1 if net._chunk_of[i] < len(net.chunks) - 1]
+assert early_w1, "the layout learned without a held GEMM should carry dW1 in an early chunk"
+for step in range(2):
+    calls.clear()
+    got = grads(net)                                  # .grad is None: the dW1 GEMM is held now
+    assert all(engine.is_late(net.params[i]) for i in w1)
+    c_w1 = sorted({net._chunk_of[i] for i in early_w1})
+    assert all(calls[c] for c in c_w1), (calls, c_w1)  # the chunk with the late gradients joined the held work
+    for n in ref:
+        err = float((got[n] - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-12))
+        assert err < 1e-2, (step, n, err)
+dist.destroy_process_group()
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PENEO_DP_CHUNK_MB="0.03"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_data_parallel_two_processes_on_one_gpu_match_a_single_process(tmp_path):
     """Two FRESH child processes (gloo, both on GPU 0) run the real tiny PEneoModel (bf16 HIP path) behind the flat
     data-parallel wrapper on their shards of a 4-document batch for three steps; the averaged gradients every rank ends up
@@ -592,6 +712,28 @@ print("ok")
         for n, g in ref.items():
             err = float((got["grads"][n] - g).abs().max() / g.abs().max().clamp_min(1e-12))
             assert err < 5e-3, (k, n, err)      # fp32 wire on gloo: only the side-stream / atomic summation order differs
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """BASELINE config 3's launch path on ONE GPU: `python bench.py --gpus 2` with no launcher in the environment must start
+    two fresh rank processes itself (torch.distributed.run children; here both on GPU 0 over gloo), reduce the gradients over
+    a process group of two ranks and say so in its line (reference: torchrun --nproc_per_node N, README.md:206-218)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PENEO_DIST_BACKEND="gloo", PENEO_DEVICE="0", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--docs-per-gpu", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo", rec
+    assert rec["config"]["parallelism"] == "dp2" and rec["value"] > 0
+    # and a world that is not what --gpus says is an error, not a relabelled single-GPU run
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
 
 
 def test_fused_adamw_resumes_from_state_dict_and_from_torch_adamw():

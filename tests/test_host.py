@@ -234,3 +234,21 @@ def test_decode_graph_walk_matches_reference():
     # tie / direction rules of parse_matrix_spots
     assert parse_matrix_spots([(1, 4, 1, 0.9), (1, 5, 1, 0.95), (2, 5, 1, 0.5)], top_score_only=True) == {1: 5}
     assert parse_matrix_spots([(1, 4, 2, 0.9), (0, 4, 1, 0.3)], triu_mode=True) == {4: [1], 0: [4]}
+
+
+def test_bench_launch_plan_never_relabels_a_smaller_job():
+    """`bench.py --gpus N`: no launcher environment -> spawn N fresh ranks; under torch.distributed.run with WORLD_SIZE == N ->
+    run as a rank; any other WORLD_SIZE -> refuse (reference launch: torchrun --nproc_per_node N, README.md:206-218)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.plan_launch(1, {}) == ("run",)
+    assert bench.plan_launch(8, {}) == ("spawn", 8)
+    assert bench.plan_launch(8, {"WORLD_SIZE": "8", "RANK": "3"}) == ("run",)
+    assert bench.plan_launch(8, {"WORLD_SIZE": "1"})[0] == "fail"
+    assert bench.plan_launch(1, {"WORLD_SIZE": "2", "RANK": "0"})[0] == "fail"
+    # the refusal is an exit code, taken before anything touches a GPU (so it can be checked on a CPU box)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr, (r.returncode, r.stderr[-400:])
