@@ -1216,14 +1216,17 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
     return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (ld % 8) == 0 && ((kmajor ? k : rows) % 8) == 0 && rows >= 8;
   };
   static const bool legacy = getenv("PENEO_GEMM_LEGACY") != nullptr;
-  int rc;
-  if (dtype == PENEO_BF16 && !legacy && a_kmajor && split_k == 1 && dma_ok(A, lda, true, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K)) {
-    // large forward / dgrad problems: one 8-wave workgroup per CU on 256 x 256 / 384 x 192 / 256 x 128 tiles (gemm_big.hip)
+  int rc = PENEO_OK;
+  bool launched = false;
+  if (dtype == PENEO_BF16 && !legacy && a_kmajor && dma_ok(A, lda, true, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K)) {
+    // large forward / dgrad problems: one 8-wave workgroup per CU (gemm_p8.hip: 256 x 256, staggered wave groups, any split;
+    // gemm_big.hip: 384 x 192 / 256 x 128, split_k == 1)
     const int big = launch_gemm_big(p, b_kmajor != 0, st);
-    if (big == 1) return PENEO_OK;
     if (big < 0) return big;
+    launched = big == 1;
   }
-  if (dtype == PENEO_BF16 && !legacy && dma_ok(A, lda, a_kmajor != 0, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K))
+  if (launched) {
+  } else if (dtype == PENEO_BF16 && !legacy && dma_ok(A, lda, a_kmajor != 0, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K))
   {
     // measured (tools/run_blas_ref.py, run_gemm_shapes.py): the 4-stage pipeline wins for wgrad (both operands mn-major,
     // +4-8 %), the 2-stage one for the k-major forward shapes (FFN2 fwd 49 vs 56 us, 4096^3 945 vs 768 TFLOP/s)

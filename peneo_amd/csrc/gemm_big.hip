@@ -268,9 +268,16 @@ static double small_cost(int M, int N) {
 }
 
 static int g_big_mode = -1;   // PENEO_GEMM_BIG: 0 = off, 1 = auto (default), 256 / 384 / 128 = force that tile where it applies
+static int g_p8_mode = -1;    // PENEO_GEMM_P8: 0 = off, 1 = the staggered 256 x 256 kernel (gemm_p8.hip) wherever 256 x 256 is picked, 2 = forced
+int launch_gemm_p8(const GemmParams& p, bool b_kmajor, hipStream_t st);
 
 int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   if (g_big_mode < 0) { const char* e = getenv("PENEO_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
+  if (g_p8_mode < 0) { const char* e = getenv("PENEO_GEMM_P8"); g_p8_mode = e ? atoi(e) : 0; }
+  if (g_p8_mode == 2) {   // forced (tools): every aligned problem, any split
+    if (((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) || (p.lda * 2) % 16 != 0 || (p.ldb * 2) % 16 != 0) return 0;
+    return launch_gemm_p8(p, b_kmajor, st);
+  }
   if (g_big_mode == 0) return 0;
   // mn-major B = the dgrad GEMMs of the backward: in the step they run beside the weight-gradient stream, and a workgroup that
   // needs a CU's whole LDS cannot share it (measured: d_zi on 384 x 192 tiles 50 us alone, 166 us in the step; the step is
@@ -316,3 +323,4 @@ int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
 
 /* tools/ only (not in the header): 0 = off, 1 = choose by the cost model, 256 / 384 / 128 = force that tile shape */
 extern "C" void peneo_gemm_set_big_mode(int mode) { peneo::g_big_mode = mode; }
+extern "C" void peneo_gemm_set_p8_mode(int mode) { peneo::g_p8_mode = mode; }
