@@ -79,6 +79,11 @@ typedef struct peneo_gemm_epilogue {
    * No other epilogue option may be combined with it; split_k must be 1. */
   const struct peneo_pair_dz_args* pair_dz;
   float* pair_dz_ws;
+  /* wgrad fusion (a_kmajor = 0, b_kmajor = 0, bf16): a_colsum[m] += sum_k A(m, k) -- with A = dy [tokens, M] this is the
+   * bias gradient db = dy^T 1 of the same nn.Linear (autograd of modeling_layoutlmv3.py:292-294 and the Roberta dense
+   * layers), taken from the A tiles the weight-gradient product already holds in LDS (one extra MFMA against a ones
+   * operand in the workgroups of the first tile column; fp32 atomics, one per row and split slice).  [M] fp32 or NULL. */
+  float* a_colsum;
 } peneo_gemm_epilogue;
 
 size_t peneo_gemm_workspace_bytes(int M, int N, int K, int split_k);

@@ -646,8 +646,9 @@ __device__ __forceinline__ void pmma(const PFrag& a, const PFrag& b, f32x16_t& a
 
 // the tile (m0, n0, split slice) is chosen by the __global__ wrappers below: one problem per launch, or several
 // independent problems side by side in one launch (peneo_gemm_group)
-template <bool AK, bool BK>
-__device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* smem, const int m0, const int n0, const int zsplit) {
+template <bool AK, bool BK, bool CS = false>
+__device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* smem, const int m0, const int n0, const int zsplit,
+                                                   const int cs_col = 0, const int cs_mod = 1) {
   constexpr int STAGE = 2 * TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -733,6 +734,19 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
     }
   }
   PFrag fa[2][2], fb[2][2];   // [register set][row block]
+  // CS: a_colsum[m] += sum_k A(m, k) (the bias gradient beside a weight gradient): one extra MFMA per k-step against a
+  // ones operand -- every column of accb is the row sum.  The work is dealt evenly: the workgroups of one tile row share
+  // the same A tiles, tile column j takes the k-tiles with kt % (tile columns) == j, and of a workgroup's two waves on the
+  // same 64 rows wave wn takes the 32-row block wn; everybody adds its partial sums with fp32 atomics.
+  const bool cs_on = CS && p.ep.a_colsum != nullptr;
+  bool cs_now = false;
+  f32x16_t accb;
+  PFrag ones;
+  ones.v = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  if constexpr (CS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+  }
 #define PENEO_READ_STEP(SET_, KS_, BUFOFF_)                                                                     \
   {                                                                                                            \
     if constexpr (AK) {                                                                                        \
@@ -756,6 +770,9 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
     pmma(fa[SET_][0], fb[SET_][1], acc[0][1]); \
     pmma(fa[SET_][1], fb[SET_][0], acc[1][0]); \
     pmma(fa[SET_][1], fb[SET_][1], acc[1][1]); \
+    if constexpr (CS) {                        \
+      if (cs_now) { if (wn == 0) pmma(fa[SET_][0], ones, accb); else pmma(fa[SET_][1], ones, accb); } \
+    }                                          \
   }
   // DS instructions per read step (for the counted waits): 4 with two k-major operands, 8 with two mn-major ones
   constexpr int RPS = (AK ? 2 : 4) + (BK ? 2 : 4);
@@ -792,6 +809,7 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
       if (ragged_k && kt + 1 == ktiles - 1) sources(kt + 1); else advance();
       issue(1);
     }
+    if constexpr (CS) cs_now = cs_on && (kt % cs_mod) == cs_col;
     PENEO_KTILE(0)
     wait_vm<0>();
     __syncthreads();
@@ -800,6 +818,7 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
         if (ragged_k && kt + 2 == ktiles - 1) sources(kt + 2); else advance();
         issue(0);
       }
+      if constexpr (CS) cs_now = cs_on && ((kt + 1) % cs_mod) == cs_col;
       PENEO_KTILE(32768)
       wait_vm<0>();
       __syncthreads();
@@ -809,10 +828,19 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
 #undef PENEO_WAIT_NEWER
 #undef PENEO_MMA_STEP
 #undef PENEO_READ_STEP
+  if constexpr (CS) {
+    if (cs_on && (lane & 31) == 0) {      // column 0 of the 32 x 32 block: lanes 0 and 32 hold 16 rows each
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + wn * 32 + acc_row(r, lane);
+        if (m < p.M) atomicAdd(p.ep.a_colsum + m, accb[r]);
+      }
+    }
+  }
   tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
 }
 
-template <bool AK, bool BK>
+template <bool AK, bool BK, bool CS = false>
 __global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
@@ -820,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
   const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
   const int tile3 = xcd * q8 + min(xcd, r8) + slot;
   const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
-  gemm_dma_pipe_body<AK, BK>(p, smem, (tile / gx) * GB, (tile % gx) * GB, zsplit);
+  gemm_dma_pipe_body<AK, BK, CS>(p, smem, (tile / gx) * GB, (tile % gx) * GB, zsplit, tile % gx, gx);
 }
 
 // Several independent GEMMs of one operand layout in ONE launch (no split-k): the tiles of all problems are numbered
@@ -1075,6 +1103,7 @@ static int launch_gemm_dma_pipe(const GemmParams& p, bool ak, bool bk, dim3 grid
   if (ak && bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, true>), grid, dim3(256), shmem, st, p);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, false>), grid, dim3(256), shmem, st, p);
   else if (!ak && bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<false, true>), grid, dim3(256), shmem, st, p);
+  else if (p.ep.a_colsum) hipLaunchKernelGGL((gemm_dma_pipe_kernel<false, false, true>), grid, dim3(256), shmem, st, p);
   else hipLaunchKernelGGL((gemm_dma_pipe_kernel<false, false>), grid, dim3(256), shmem, st, p);
   return check_launch("peneo_gemm");
 }
@@ -1197,6 +1226,8 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
     p.dz_on = 1; p.dz = *a; p.dz_ws = p.ep.pair_dz_ws;
   }
   PENEO_REQUIRE(!p.ep.accumulate || c_dtype == PENEO_F32, "peneo_gemm: accumulate needs an fp32 C");
+  PENEO_REQUIRE(!p.ep.a_colsum || !a_kmajor, "peneo_gemm: a_colsum needs A as [K, M] (a_kmajor = 0)");
+  bool cs_fused = false;
   PENEO_REQUIRE(p.ep.drop_p >= 0.f && p.ep.drop_p < 1.f, "peneo_gemm: drop_p out of range");
   const int KT = dtype == PENEO_BF16 ? 64 : 32;
   const int ktiles = (K + KT - 1) / KT;
@@ -1237,11 +1268,16 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
     rc = stages == 2 ? launch_gemm_dma(p, a_kmajor != 0, b_kmajor != 0, grid, st)
          : stages == 3 ? launch_gemm_dma_pipe(p, a_kmajor != 0, b_kmajor != 0, grid, st)   // 3 = two stages, hand-scheduled reads
                        : launch_gemm_dma4(p, a_kmajor != 0, b_kmajor != 0, grid, st);
+    cs_fused = stages == 3 && !a_kmajor && !b_kmajor;       // the (mn-major, mn-major) instantiation sums A's columns itself
   }
   else
     rc = dtype == PENEO_BF16 ? launch_gemm<bf16_t>(p, a_kmajor != 0, b_kmajor != 0, grid, st)
                              : launch_gemm<float>(p, a_kmajor != 0, b_kmajor != 0, grid, st);
   if (rc != PENEO_OK) return rc;
+  if (p.ep.a_colsum && !cs_fused) {     // every other kernel: the column sums as their own pass over A = [K, M]
+    rc = peneo_colsum(dtype, A, lda, K, M, p.ep.a_colsum, 1, stream);
+    if (rc != PENEO_OK) return rc;
+  }
   if (split_k > 1) {
     int64_t total = (int64_t)M * N;
     const peneo_gemm_epilogue& e = p.ep;

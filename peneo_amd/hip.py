@@ -31,7 +31,7 @@ class GemmEpilogue(C.Structure):
         ("bias", _vp), ("act", _i), ("preact", _vp), ("ld_preact", _i64),
         ("grad_src", _vp), ("ld_grad", _i64), ("grad_act", _i),
         ("residual", _vp), ("ld_res", _i64), ("alpha", _f), ("accumulate", _i),
-        ("drop_p", _f), ("drop_seed", _u32), ("pair_dz", _vp), ("pair_dz_ws", _vp),
+        ("drop_p", _f), ("drop_seed", _u32), ("pair_dz", _vp), ("pair_dz_ws", _vp), ("a_colsum", _vp),
     ]
 
 

@@ -97,8 +97,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
          preact: Optional[torch.Tensor] = None, grad_src: Optional[torch.Tensor] = None, grad_act: int = ACT_NONE,
          out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, accumulate: bool = False,
          alpha: float = 1.0, drop_p: float = 0.0, drop_seed: int = 0, split_k: Optional[int] = None,
-         pair_dz=None, pair_dz_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = epilogue(alpha * A.B^T); a, b are 2-D (row stride may exceed the row length)."""
+         pair_dz=None, pair_dz_ws: Optional[torch.Tensor] = None, a_colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(alpha * A.B^T); a, b are 2-D (row stride may exceed the row length).
+    a_colsum (a_kmajor=False only): fp32 [M] that receives += the column sums of a = [K, M] -- the bias gradient beside a
+    weight gradient, from the tiles the product holds in LDS anyway."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
     assert a.stride(1) == 1 and b.stride(1) == 1
     if a_kmajor:
@@ -128,6 +130,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kmajor: bool = True, b_kmajor: b
     ep.alpha = alpha
     ep.accumulate = 1 if accumulate else 0
     ep.drop_p, ep.drop_seed = drop_p, drop_seed & 0xFFFFFFFF
+    if a_colsum is not None:
+        assert not a_kmajor and a_colsum.dtype == torch.float32 and a_colsum.numel() == M and a_colsum.is_contiguous()
+        ep.a_colsum = ptr(a_colsum)
     if pair_dz is not None:      # hip.PairDzArgs: the tile is z of the pair heads; store dz, accumulate dW2 / db1 partials
         ep.pair_dz, ep.pair_dz_ws = C.cast(C.pointer(pair_dz), C.c_void_p), ptr(pair_dz_ws)
         split_k = 1

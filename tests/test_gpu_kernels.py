@@ -1280,3 +1280,26 @@ def test_layernorm_bwd_partial_sums_equal_the_atomic_form(ops, dtype):
     assert rel_err(sums[:H], dg) < 1e-5 and rel_err(sums[H:], db) < 1e-5
     # no partial form for a row length outside the fast instantiations
     assert ops.layernorm_bwd_partial(dy[:, :40].contiguous(), x[:, :40].contiguous(), gamma[:40], mean, rstd)[0] is None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(5672, 2304, 768), (1000, 192, 520), (709, 768, 3072), (64, 40, 24)])
+def test_gemm_wgrad_with_fused_bias_gradient(ops, dtype, shape):
+    """dW = dy^T x with db = dy^T 1 out of the same launch (peneo_gemm's a_colsum; autograd of every nn.Linear of the encoder,
+    modeling_layoutlmv3.py:292-294,335-360): the sums are ADDED to the destination, every split-k slice contributes, shapes
+    that do not run the LDS-DMA kernel (fp32, ragged) fall back to a column-sum pass inside the same C call."""
+    K, M, N = shape                      # K = tokens, M = output features (rows of dW), N = input features
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randn(K, M, generator=g).to(DEV).to(dtype)
+    x = torch.randn(K, N, generator=g).to(DEV).to(dtype)
+    base = torch.randn(M, generator=g).to(DEV)
+    for split in (None, 1, 3):
+        db = base.clone()
+        dw = ops.gemm(dy, x, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32, a_colsum=db, split_k=split)
+        want_w = dy.float().t() @ x.float()
+        want_b = base + dy.float().sum(0)
+        tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+        assert rel_err(dw, want_w) < tol, (shape, split)
+        assert rel_err(db, want_b) < 1e-4, (shape, split, rel_err(db, want_b))
+    with pytest.raises(Exception):
+        ops.gemm(dy.t().contiguous(), x.t().contiguous(), a_colsum=base.clone())     # a_colsum needs A as [K, M]

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported_and_bound():
 def test_struct_layouts_match_the_header_sizes():
     from peneo_amd import hip
     # spot checks of the by-value / by-pointer structs shared with C (natural alignment on x86-64)
-    assert ctypes.sizeof(hip.GemmEpilogue) == 104
+    assert ctypes.sizeof(hip.GemmEpilogue) == 112
     assert ctypes.sizeof(hip.PairHeadsDesc) == 8 + 4 * 8 + 3 * 8 + 8
     assert ctypes.sizeof(hip.PairLoss) == 8 * 8 * 2 + 8 + 8 * 8
     assert ctypes.sizeof(hip.PairDzArgs) == 8 + 4 * 8 + 8 * 8 * 2 + 8 + 16 + 8
