@@ -474,6 +474,50 @@ int peneo_adamw_step_clip(const peneo_adamw_tensor* table_dev, const int32_t* ch
                           int n_chunks, float beta1, float beta2, float eps, int step, const double* sqnorm_dev,
                           float max_grad_norm, peneo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Composite stages: ONE call enqueues every kernel of an encoder layer (bf16 path) -- the per-kernel entry points above
+ * called back to back from C++ (csrc/stages.hip), so that a layer costs the host one FFI call instead of 7 (forward) or
+ * ~25 (backward).  Replaces LayoutLMv3Layer.forward and its autograd (modeling_layoutlmv3.py:482-529, :335-404; Roberta
+ * SelfOutput / Intermediate / Output).  Every buffer is the caller's; rows = B * T; all matrices contiguous:
+ *   x, att, h1, a, h2, out [rows, H]; qkv [rows, 3H] (q | k | v); zi, inter [rows, I]; lse [B, nh, T]; m*, r* [rows] (LayerNorm
+ *   statistics); Wqkv [3H, H], Wo [H, H], Wi [I, H], Wo2 [H, I] bf16 working copies; biases / LayerNorm parameters fp32.
+ * zi (GELU pre-activation) may be NULL in a forward that no backward follows.  Dropout: p_hidden with seed_o / seed_o2 on the
+ * two dense + residual sites (mask = f(seed, element), regenerated by the backward), p_attn with `drop_words`
+ * (peneo_attn_drop_words).  bias / key_bias as for peneo_attn_fwd.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct peneo_encoder_layer {
+  const void* Wqkv; const float* bqkv; const void* Wo; const float* bo; const float* g1; const float* b1;
+  const void* Wi; const float* bi; const void* Wo2; const float* bo2; const float* g2; const float* b2;
+  const void* bias; int64_t bias_ld; const float* key_bias; const uint32_t* drop_words;
+  const void* x; void* qkv; void* att; float* lse; void* h1; float* m1; float* r1; void* a; void* zi; void* inter; void* h2;
+  float* m2; float* r2;
+  int32_t B, T, H, nh, I, reserved;
+  float eps, attn_scale, p_hidden, p_attn;
+  uint32_t seed_o, seed_o2;
+} peneo_encoder_layer;
+/* Backward: gradients of the activations (caller's scratch, all written) and of the parameters.  d_dense1 / d_dense2 are
+ * only used with p_hidden > 0.  dw* fp32 [out, in] are overwritten; db*, dg* fp32 are ACCUMULATED into (zero them first);
+ * ds_out bf16 [B, nh, T, Tp] receives this layer's dS^T (peneo_attn_bwd); delta [B, nh, T] fp32 scratch. */
+typedef struct peneo_encoder_layer_grads {
+  const void* d_out; void* d_x;
+  void* d_h2; void* d_dense2; void* d_zi; void* d_a; void* d_h1; void* d_dense1; void* d_att; void* dqkv; float* delta; void* ds_out;
+  float* dwqkv; float* dbqkv; float* dwo; float* dbo; float* dg1; float* db1; float* dwi; float* dbi; float* dwo2; float* dbo2;
+  float* dg2; float* db2;
+} peneo_encoder_layer_grads;
+/* sizeof of the structs shared with a binding: 0 peneo_gemm_epilogue, 1 peneo_encoder_layer, 2 peneo_encoder_layer_grads */
+size_t peneo_struct_bytes(int which);
+/* split-k workspace of the layer's GEMMs: which = 0 forward, 1 backward main stream (dgrads), 2 backward side stream (wgrads) */
+size_t peneo_encoder_layer_workspace_bytes(int rows, int H, int I, int which);
+int peneo_encoder_layer_fwd(const peneo_encoder_layer* layer, void* out, void* workspace, size_t workspace_bytes,
+                            peneo_stream_t stream);
+/* The activation-gradient chain runs on `stream`; the parameter-gradient work (weight-gradient GEMMs, bias column sums) on
+ * `side_stream` behind HIP events recorded on `stream` (the FFN / output-projection part starts with the attention backward,
+ * the QKV part behind it).  The call does NOT join the two streams: the caller waits for `side_stream` before anything
+ * reads dw* / db* (side_stream NULL or == stream: everything in order on one stream). */
+int peneo_encoder_layer_bwd(const peneo_encoder_layer* layer, const peneo_encoder_layer_grads* grads, void* ws_main,
+                            size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, peneo_stream_t stream,
+                            peneo_stream_t side_stream);
+
 /* K13 input side ("next" row f.2): dense label maps [B, P] int64 from n sparse spots (b, i, j, tag) — replaces the
  * host loop of HandshakingTaggingScheme.spots2shaking_tag4batch (model/peneo_decoder.py:35-73, called per head by
  * data/collator.py:156-204) and the 5.2 MB/document host-to-device copy of its result.  Last spot wins, like the

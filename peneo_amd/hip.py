@@ -35,6 +35,20 @@ class GemmEpilogue(C.Structure):
     ]
 
 
+class EncoderLayer(C.Structure):
+    _fields_ = ([(n, _vp) for n in ("Wqkv", "bqkv", "Wo", "bo", "g1", "b1", "Wi", "bi", "Wo2", "bo2", "g2", "b2", "bias")] +
+                [("bias_ld", _i64)] +
+                [(n, _vp) for n in ("key_bias", "drop_words", "x", "qkv", "att", "lse", "h1", "m1", "r1", "a", "zi", "inter", "h2",
+                                    "m2", "r2")] +
+                [(n, _i) for n in ("B", "T", "H", "nh", "I", "reserved")] +
+                [(n, _f) for n in ("eps", "attn_scale", "p_hidden", "p_attn")] + [("seed_o", _u32), ("seed_o2", _u32)])
+
+
+class EncoderLayerGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("d_out", "d_x", "d_h2", "d_dense2", "d_zi", "d_a", "d_h1", "d_dense1", "d_att", "dqkv", "delta",
+                                   "ds_out", "dwqkv", "dbqkv", "dwo", "dbo", "dg1", "db1", "dwi", "dbi", "dwo2", "dbo2", "dg2", "db2")]
+
+
 class GemmProblem(C.Structure):
     _fields_ = [("M", _i), ("N", _i), ("K", _i), ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
                 ("accumulate", _i)]
@@ -141,6 +155,10 @@ SIGNATURES = {
     "peneo_adamw_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
     "peneo_grad_sqnorm": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "peneo_adamw_step_clip": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _f, _vp]),
+    "peneo_struct_bytes": (C.c_size_t, [_i]),
+    "peneo_encoder_layer_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "peneo_encoder_layer_fwd": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "peneo_encoder_layer_bwd": (_i, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
 }

@@ -19,8 +19,12 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+import ctypes as C
+
 from .. import ops
-from ..hip import ACT_GELU, ACT_NONE, PeneoHipError
+from ..hip import ACT_GELU, ACT_NONE, EncoderLayer, EncoderLayerGrads, PeneoHipError, check, ptr
+from ..hip import lib as hip_lib
+from ..hip import stream as hip_stream
 from .configuration_peneo import LayoutLMv3Config
 from .engine import DropoutSeeds, can_defer, WeightCache, defer_join, join_pending, zeros_like_param, zeros_like_params
 from .engine import side_stream as engine_side_stream
@@ -273,12 +277,197 @@ class _EmbedStage(torch.autograd.Function):
         return (None, None, None, None, None, None) + grads
 
 
+
+# ------------------------------------------------------------------------------------------------
+# composite layer calls (csrc/stages.hip): ONE C call per layer forward / backward instead of 7 / ~25 (bf16, default
+# schedule).  PENEO_STAGE_CALLS=0: the per-kernel sequence below (also what fp32 parity mode and the optional schedules run).
+# ------------------------------------------------------------------------------------------------
+STAGE_CALLS = os.environ.get("PENEO_STAGE_CALLS", "1") != "0"
+_WS_BYTES: dict = {}
+
+
+def _layer_ws_bytes(rows: int, H: int, I: int, which: int) -> int:
+    key = (rows, H, I, which)
+    if key not in _WS_BYTES:
+        _WS_BYTES[key] = int(hip_lib().peneo_encoder_layer_workspace_bytes(rows, H, I, which))
+    return _WS_BYTES[key]
+
+
+def _use_stage_calls(model, st, H: int, I: int) -> bool:
+    return (STAGE_CALLS and st.dtype == torch.bfloat16 and H % 8 == 0 and I % 8 == 0 and not model.ln_partials and not LN_BIAS_FOLD
+            and (model.wgrad_late or not model.wgrad_on_side_stream) and model.rel_after_dgrad)
+
+
+class _LayerBuffers:
+    """Activations of one layer forward carved from ONE bf16 and ONE fp32 allocation (the C call takes raw pointers)."""
+    __slots__ = ("flat", "stats", "R", "H", "I", "has_zi", "o")
+
+    def __init__(self, R: int, H: int, I: int, nlse: int, has_zi: bool, dev) -> None:
+        self.R, self.H, self.I, self.has_zi = R, H, I, has_zi
+        n = R * (3 * H + 4 * H + I + (I if has_zi else 0))     # qkv | att | h1 | a | h2 | inter | zi
+        self.flat = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self.stats = torch.empty(nlse + 4 * R, dtype=torch.float32, device=dev)   # lse | m1 | r1 | m2 | r2
+        self.o = nlse
+
+    def fill(self, L) -> None:
+        R, H, I = self.R, self.H, self.I
+        b, e = self.flat.data_ptr(), 2
+        L.qkv = b
+        L.att = b + e * R * 3 * H
+        L.h1 = L.att + e * R * H
+        L.a = L.h1 + e * R * H
+        L.h2 = L.a + e * R * H
+        L.inter = L.h2 + e * R * H
+        L.zi = (L.inter + e * R * I) if self.has_zi else None
+        s = self.stats.data_ptr()
+        L.lse = s
+        L.m1 = s + 4 * self.o
+        L.r1 = L.m1 + 4 * R
+        L.m2 = L.r1 + 4 * R
+        L.r2 = L.m2 + 4 * R
+
+
+def _describe_layer(model, st, idx, params, x, bufs):
+    (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2) = params
+    cfg, wc, dt = model.config, model.weight_cache, st.dtype
+    B, S, T = st.dims
+    H, nh = cfg.hidden_size, cfg.num_attention_heads
+    seeds = st.seeds
+    site = 16 * (idx + 1)
+    Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
+    bqkv = wc.get((f"L{idx}.bqkv",), [bq, bk, bv], lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]))
+    Wo, Wi, Wo2 = wc.cast(f"L{idx}.o", wo, dt), wc.cast(f"L{idx}.i", wi, dt), wc.cast(f"L{idx}.o2", wo2, dt)
+    L = EncoderLayer()
+    L.Wqkv, L.bqkv, L.Wo, L.bo, L.g1, L.b1 = Wqkv.data_ptr(), bqkv.data_ptr(), Wo.data_ptr(), bo.data_ptr(), g1.data_ptr(), b1.data_ptr()
+    L.Wi, L.bi, L.Wo2, L.bo2, L.g2, L.b2 = Wi.data_ptr(), bi.data_ptr(), Wo2.data_ptr(), bo2.data_ptr(), g2.data_ptr(), b2.data_ptr()
+    if st.bias is not None:
+        L.bias, L.bias_ld = st.bias.data_ptr(), st.bias.shape[-1]
+    if st.key_bias is not None:
+        L.key_bias = st.key_bias.data_ptr()
+    words = seeds.attn_words(idx, cfg.num_hidden_layers, B, nh, T, x.device)
+    if words is not None:
+        L.drop_words = words.data_ptr()
+    L.x = x.data_ptr()
+    bufs.fill(L)
+    L.B, L.T, L.H, L.nh, L.I = B, T, H, nh, cfg.intermediate_size
+    L.eps, L.attn_scale, L.p_hidden, L.p_attn = cfg.layer_norm_eps, 1.0 / math.sqrt(H // nh), seeds.p_hidden, seeds.p_attn
+    L.seed_o, L.seed_o2 = seeds.seed(site + 2), seeds.seed(site + 3)
+    return L, (Wqkv, bqkv, Wo, Wi, Wo2, words)      # (the working copies stay referenced while the call is in flight)
+
+
+def _stage_forward(ctx, model, st, idx, x, params):
+    cfg = model.config
+    B, S, T = st.dims
+    H, nh, I = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+    R, dev = B * T, x.device
+    if not x.is_contiguous():
+        x = x.contiguous()
+    bufs = _LayerBuffers(R, H, I, B * nh * T, any(ctx.needs_input_grad), dev)
+    L, keep = _describe_layer(model, st, idx, params, x, bufs)
+    out = torch.empty((R, H), dtype=st.dtype, device=dev)
+    wsb = _layer_ws_bytes(R, H, I, 0)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+    check(hip_lib().peneo_encoder_layer_fwd(C.byref(L), out.data_ptr(), ptr(ws), wsb, hip_stream()), "peneo_encoder_layer_fwd")
+    ctx.model, ctx.st, ctx.idx = model, st, idx
+    ctx.saved = (x, bufs)
+    ctx.params = params
+    ctx.stage_call = True
+    return out
+
+
+def _stage_backward(ctx, d_out):
+    model, st, idx = ctx.model, ctx.st, ctx.idx
+    params = ctx.params
+    x, bufs = ctx.saved
+    cfg, dt = model.config, st.dtype
+    B, S, T = st.dims
+    H, nh, I = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+    R, dev = B * T, x.device
+    seeds = st.seeds
+    d_out = d_out.contiguous()
+    L, keep = _describe_layer(model, st, idx, params, x, bufs)
+    main = torch.cuda.current_stream()
+    side = model.side_stream(dev) if model.wgrad_on_side_stream else None
+    # small fp32 accumulators of all layers: one zero fill per step (the last layer runs backward first)
+    psz = 4 * H + (H + I + H + 3 * H)
+    nl = len(model.encoder.layer)
+    if getattr(st, "grad_pools", None) is None or idx == nl - 1:
+        st.grad_pools = torch.zeros((nl, psz), dtype=torch.float32, device=dev)
+    pool = st.grad_pools[idx]
+    dg2, db2, dg1, db1 = pool[:H], pool[H:2 * H], pool[2 * H:3 * H], pool[3 * H:4 * H]
+    o_ = 4 * H
+    dbo2, dbi, dbo, dbqkv = pool[o_:o_ + H], pool[o_ + H:o_ + H + I], pool[o_ + H + I:o_ + 2 * H + I], pool[o_ + 2 * H + I:]
+    if st.bias is not None and model.rel_tables_need_grad():
+        # this layer's dS^T goes to its own bf16 slab; the three bias tables are reduced from all slabs once (layer 0, below)
+        if st.ds_layers is None:
+            st.ds_layers = torch.empty((cfg.num_hidden_layers, B, nh, T, st.bias.shape[-1]), dtype=dt, device=dev)
+        ds = st.ds_layers[idx]
+    else:   # nobody wants the slab but the dQ kernel of this call
+        ds = torch.empty((B, nh, T, ops.attn_padded_len(T)), dtype=dt, device=dev)
+    drop = seeds.p_hidden > 0
+    # activation-gradient scratch: d_h2 | d_a | d_h1 | d_att | (d_dense2 | d_dense1) | d_zi | dqkv   (one allocation)
+    nsc = R * (4 * H + (2 * H if drop else 0) + I + 3 * H)
+    scratch = torch.empty(nsc, dtype=dt, device=dev)
+    delta = torch.empty(B * nh * T, dtype=torch.float32, device=dev)
+    d_x = torch.empty((R, H), dtype=dt, device=dev)
+    dwqkv = torch.empty((3 * H, H), dtype=torch.float32, device=dev)
+    dwo = torch.empty((H, H), dtype=torch.float32, device=dev)
+    dwi = torch.empty((I, H), dtype=torch.float32, device=dev)
+    dwo2 = torch.empty((H, I), dtype=torch.float32, device=dev)
+    G = EncoderLayerGrads()
+    G.d_out, G.d_x = d_out.data_ptr(), d_x.data_ptr()
+    b, e = scratch.data_ptr(), 2
+    G.d_h2 = b
+    G.d_a = b + e * R * H
+    G.d_h1 = G.d_a + e * R * H
+    G.d_att = G.d_h1 + e * R * H
+    nxt = G.d_att + e * R * H
+    if drop:
+        G.d_dense2, G.d_dense1 = nxt, nxt + e * R * H
+        nxt += 2 * e * R * H
+    G.d_zi = nxt
+    G.dqkv = nxt + e * R * I
+    G.delta = delta.data_ptr()
+    G.ds_out = ds.data_ptr()
+    G.dwqkv, G.dwo, G.dwi, G.dwo2 = dwqkv.data_ptr(), dwo.data_ptr(), dwi.data_ptr(), dwo2.data_ptr()
+    p0 = pool.data_ptr()
+    G.dg2, G.db2, G.dg1, G.db1 = p0, p0 + 4 * H, p0 + 8 * H, p0 + 12 * H
+    G.dbo2 = p0 + 4 * o_
+    G.dbi = G.dbo2 + 4 * H
+    G.dbo = G.dbi + 4 * I
+    G.dbqkv = G.dbo + 4 * H
+    wmb, wsb = _layer_ws_bytes(R, H, I, 1), _layer_ws_bytes(R, H, I, 2)
+    wm = torch.empty(wmb, dtype=torch.uint8, device=dev) if wmb else None
+    wsd = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+    check(hip_lib().peneo_encoder_layer_bwd(C.byref(L), C.byref(G), ptr(wm), wmb, ptr(wsd), wsb, main.cuda_stream,
+                                            side.cuda_stream if side is not None else None), "peneo_encoder_layer_bwd")
+    if idx == 0 and st.ds_layers is not None:
+        # the bias-table gradient of all layers from their dS^T slabs, on its own stream (joined by _EmbedStage.backward)
+        rel_stream = model.side_stream(dev, "rel")
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(rel_stream):
+            rel_stream.wait_event(ev)
+            model.reduce_rel_group(st, 0, cfg.num_hidden_layers, B, T)
+    if side is not None:
+        if model.defer_wgrad_join and can_defer(params):
+            defer_join(side, keep=(scratch, bufs.flat, x, wsd, *keep))     # what the side stream still reads
+        else:
+            main.wait_stream(side)
+    grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, db1,
+             dwi, dbi, dwo2, dbo2, dg2, db2)
+    grads = tuple(gr if p.requires_grad else None for gr, p in zip(grads, params))
+    return (None, None, None, d_x) + grads
+
 # ------------------------------------------------------------------------------------------------
 # stage 2: one encoder layer
 # ------------------------------------------------------------------------------------------------
 class _LayerStage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, st, idx, x, *params):
+        ctx.stage_call = False
+        if _use_stage_calls(model, st, model.config.hidden_size, model.config.intermediate_size):
+            return _stage_forward(ctx, model, st, idx, x, params)
         (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2) = params
         cfg, wc, dt = model.config, model.weight_cache, st.dtype
         B, S, T = st.dims
@@ -308,6 +497,8 @@ class _LayerStage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        if ctx.stage_call:
+            return _stage_backward(ctx, d_out)
         model, st, idx = ctx.model, ctx.st, ctx.idx
         (wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2) = ctx.params
         x, qkv, att, lse, h1, m1, r1, a, zi, inter, h2, m2, r2 = ctx.saved

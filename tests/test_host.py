@@ -33,6 +33,11 @@ def test_struct_layouts_match_the_header_sizes():
     from peneo_amd import hip
     # spot checks of the by-value / by-pointer structs shared with C (natural alignment on x86-64)
     assert ctypes.sizeof(hip.GemmEpilogue) == 112
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    lib.peneo_struct_bytes.restype = ctypes.c_size_t
+    # the C side's own sizeof of the structs a binding fills field by field
+    assert [lib.peneo_struct_bytes(i) for i in range(3)] == [ctypes.sizeof(hip.GemmEpilogue), ctypes.sizeof(hip.EncoderLayer),
+                                                             ctypes.sizeof(hip.EncoderLayerGrads)]
     assert ctypes.sizeof(hip.PairHeadsDesc) == 8 + 4 * 8 + 3 * 8 + 8
     assert ctypes.sizeof(hip.PairLoss) == 8 * 8 * 2 + 8 + 8 * 8
     assert ctypes.sizeof(hip.PairDzArgs) == 8 + 4 * 8 + 8 * 8 * 2 + 8 + 16 + 8
