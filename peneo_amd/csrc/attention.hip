@@ -1242,8 +1242,7 @@ static int launch_fwd_d(const AttnParams& p, hipStream_t st) {
       if constexpr (DP <= 64) {
         // 32-key tiles (three workgroups per CU) when the grid does not fit the 512 slots of two per CU: 8 documents of 709
         // tokens, 576 workgroups, 46 instead of 60 us; a grid that fits is a few per cent faster on 64-key tiles
-        static const int forced = getenv("PENEO_ATTN_FWD_KEYS") ? atoi(getenv("PENEO_ATTN_FWD_KEYS")) : 0;
-        const bool narrow = forced ? forced == 32 : (int64_t)grid.x * grid.y * grid.z > 512;
+        const bool narrow = (int64_t)grid.x * grid.y * grid.z > 512;
         if (narrow) {
           const size_t sh = fwd_smem<T, DP, 32>();
           int rc = set_smem(attn_fwd_kernel<T, DP, DROP, true, 32>, sh);
@@ -1299,8 +1298,7 @@ static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
       }
       size_t sf = fused_smem<DP>();
       dim3 fgrid((p.T + FKEYS - 1) / FKEYS, p.nh, p.B);
-      static const int occ_env = getenv("PENEO_ATTN_OCC") ? atoi(getenv("PENEO_ATTN_OCC")) : 0;
-      const int occ = occ_env ? occ_env : (DP <= 64 ? 2 : 1);
+      const int occ = DP <= 64 ? 2 : 1;        // workgroups per CU (256 registers at head dims above 64)
 #define PENEO_LAUNCH_FUSED(HB_, OCC_)                                                                        \
   {                                                                                                          \
     rc = set_smem(attn_bwd_fused_kernel<DP, DROP, HB_, OCC_>, sf);                                           \

@@ -480,137 +480,6 @@ __device__ __forceinline__ void dma_src_mnmajor(DmaSrc& s, const bf16_t* X, int6
   }
 }
 
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 2 * TILE_BYTES;            // A tile + B tile
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs; give each XCD a contiguous band of tiles
-  // (n fastest) so that its L2 sees one slice of A and streams B, instead of every L2 seeing everything.
-  // (with split-k the k slices are part of the same linear order: the n-tiles that share one A panel of one k slice are
-  // neighbours on one XCD and hit its L2 instead of re-reading the panel from HBM)
-  const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
-  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
-  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
-  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
-  const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
-  const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
-  DzPre dzpre = {};
-  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
-
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-  const int ktiles = (p.K + 63) / 64;
-  int kt_begin = 0, kt_end = ktiles;
-  if (p.split_k > 1) {
-    kt_begin = zsplit * p.kt_per_split;
-    kt_end = min(ktiles, kt_begin + p.kt_per_split);
-  }
-  const bool ragged_k = (p.K & 63) != 0;
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const uint32_t lbase = lds_addr(smem) + wave * 4096;   // this wave's 4 pieces inside a 16 KiB tile
-  const int64_t stepA = AK ? 128 : (int64_t)64 * p.lda * 2, stepB = BK ? 128 : (int64_t)64 * p.ldb * 2;
-  DmaSrc sa, sb;
-  auto sources = [&](int kt) {
-    const bool guard = ragged_k && kt == ktiles - 1;
-    if (AK) dma_src_kmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
-    else dma_src_mnmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
-    if (BK) dma_src_kmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
-    else dma_src_mnmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
-  };
-  auto issue = [&](int buf) {
-    const uint32_t d = lbase + buf * STAGE;
-    lds_dma_1k<0>(sa.p[0], d);
-    lds_dma_1k<0>(sa.p[1], d + 1024);
-    lds_dma_1k<0>(sa.p[2], d + 2048);
-    lds_dma_1k<0>(sa.p[3], d + 3072);
-    lds_dma_1k<0>(sb.p[0], d + TILE_BYTES);
-    lds_dma_1k<0>(sb.p[1], d + TILE_BYTES + 1024);
-    lds_dma_1k<0>(sb.p[2], d + TILE_BYTES + 2048);
-    lds_dma_1k<0>(sb.p[3], d + TILE_BYTES + 3072);
-  };
-  auto advance = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sa.p[j] += stepA; sb.p[j] += stepB; }
-  };
-
-  // per-lane fragment addresses (constant over the k loop)
-  //   k-major: row*128 + ((2ks + (lane >> 5)) ^ ((row >> 1) & 7)) * 16
-  //   mn-major: piece (kblock = 2ks + (lane >> 5), nhalf) * 1024 + kr * 128 + ((n & 63) * 2 ^ swap), kr = 4 sub + ((lane & 15) >> 2)
-  int fa_off[2], fb_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (AK) fa_off[i] = (wm * 64 + i * 32 + (lane & 31)) * ROWB;
-    else {
-      const int n = wm * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-      fa_off[i] = ((lane >> 5) * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
-    }
-    if (BK) fb_off[i] = (wn * 64 + i * 32 + (lane & 31)) * ROWB;
-    else {
-      const int n = wn * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-      fb_off[i] = ((lane >> 5) * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
-    }
-  }
-  const int swzA = ((wm * 64 + (lane & 31)) >> 1) & 7;   // rows i*32 apart share (row >> 1) & 7
-  const int swzB = ((wn * 64 + (lane & 31)) >> 1) & 7;
-  auto frag = [&](const char* tile, bool kmajor, int off, int swz, int ks) -> Frag<bf16_t> {
-    Frag<bf16_t> f;
-    if (kmajor) {
-      f.v = *reinterpret_cast<const uint4*>(tile + off + (((2 * ks + (lane >> 5)) ^ swz) << 4));
-    } else {
-      typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
-      const char* q = tile + off + ks * 4096;
-      s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q));
-      s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q + 512));
-      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-      f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
-    }
-    return f;
-  };
-
-  if (kt_begin < kt_end) {
-    sources(kt_begin);
-    issue(0);
-  }
-  wait_vm<0>();
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) {
-      if (ragged_k && kt + 1 == ktiles - 1) sources(kt + 1); else advance();
-      issue(buf ^ 1);
-    }
-    const char* tA = smem + buf * STAGE;
-    const char* tB = tA + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      Frag<bf16_t> fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag(tA, AK, fa_off[i], swzA, ks);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = frag(tB, BK, fb_off[j], swzB, ks);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma_step(fa[i], fb[j], acc[i][j]);
-    }
-    wait_vm<0>();
-    __syncthreads();
-  }
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
-}
-
 // ================================================================================================
 // Two-stage kernel with the LDS -> register fragment reads scheduled by hand: the compiler's schedule re-uses one
 // fragment register set and waits (lgkmcnt) for each k-step's reads right in front of its MFMAs, exposing the LDS
@@ -875,166 +744,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_pipe_group_kernel(GemmGroup g
   gemm_dma_pipe_body<AK, BK>(g.p[i], smem, (tile / gx) * GB, (tile % gx) * GB, 0);
 }
 
-// ================================================================================================
-// Same tile, deeper pipeline: k-tiles of 32 (64 B per row), FOUR 16 KiB stages, LDS-DMA three k-tiles ahead with
-// counted vmcnt and a raw s_barrier per k-tile.  The two-stage kernel above waits for a DMA it issued one k-tile
-// (512 MFMA cycles) earlier, far less than the L2/HBM latency under load, so its MFMA pipe idles about half the time;
-// here a stage has three k-tiles (and the other resident workgroup) to land.
-//   k-major tile  [128 rows][64 B]: 16-byte slot s of row r at slot s ^ ((r >> 2) & 3); 1 KiB piece = 16 rows
-//   mn-major tile [32 k][128 rows]: the [8 k][64 rows] pieces of the two-stage kernel, 8 per tile
-// ================================================================================================
-constexpr int T4_BYTES = GB * 64;          // one operand tile of a stage
-constexpr int STAGE4 = 2 * T4_BYTES;       // A + B
-constexpr int NST4 = 4;
-struct DmaSrc2 { const char* p[2]; };
-
-__device__ __forceinline__ void dma4_src_kmajor(DmaSrc2& s, const bf16_t* X, int64_t ld, int r0, int rmax, int K, int kt,
-                                                int wave, int lane, bool guard) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wave * 2 + j) * 16 + (lane >> 2);
-    const int sg = (lane & 3) ^ ((row >> 2) & 3);
-    const int k = kt * 32 + sg * 8;
-    const int r = min(r0 + row, rmax - 1);
-    const char* q = reinterpret_cast<const char*>(X + (int64_t)r * ld + k);
-    if (guard && k >= K) q = reinterpret_cast<const char*>(g_zero_line);
-    s.p[j] = q;
-  }
-}
-__device__ __forceinline__ void dma4_src_mnmajor(DmaSrc2& s, const bf16_t* X, int64_t ld, int r0, int rmax, int K, int kt,
-                                                 int wave, int lane, bool guard) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int kr = lane >> 3;
-    const int k = kt * 32 + wave * 8 + kr;               // piece (kblock = wave, nhalf = j)
-    const int cg = (lane & 7) ^ (((kr >> 1) & 1) << 2);
-    const int col = min(r0 + j * 64 + cg * 8, rmax - 8);
-    const char* q = reinterpret_cast<const char*>(X + (int64_t)k * ld + col);
-    if (guard && k >= K) q = reinterpret_cast<const char*>(g_zero_line);
-    s.p[j] = q;
-  }
-}
-
-template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
-  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
-  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
-  const int tile3 = xcd * q8 + min(xcd, r8) + slot;
-  const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
-  const int m0 = (tile / gx) * GB, n0 = (tile % gx) * GB;
-  DzPre dzpre = {};
-  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
-
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-  const int ktiles = (p.K + 31) / 32;
-  int kt_begin = 0, kt_end = ktiles;
-  if (p.split_k > 1) {                       // kt_per_split counts 64-wide k-tiles
-    kt_begin = zsplit * p.kt_per_split * 2;
-    kt_end = min(ktiles, kt_begin + p.kt_per_split * 2);
-  }
-  const int nk = max(kt_end - kt_begin, 0);
-  const bool ragged_k = (p.K & 31) != 0;
-
-  f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const uint32_t lbase = lds_addr(smem) + wave * 2048;   // this wave's 2 pieces inside an 8 KiB operand tile
-  const int64_t stepA = AK ? 64 : (int64_t)32 * p.lda * 2, stepB = BK ? 64 : (int64_t)32 * p.ldb * 2;
-  DmaSrc2 sa, sb;
-  int next_kt = kt_begin;                    // k-tile the source pointers stand at
-  auto sources = [&](int kt) {
-    const bool guard = ragged_k && kt == ktiles - 1;
-    if (AK) dma4_src_kmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
-    else dma4_src_mnmajor(sa, A, p.lda, m0, p.M, p.K, kt, wave, lane, guard);
-    if (BK) dma4_src_kmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
-    else dma4_src_mnmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
-  };
-  auto issue_next = [&](int buf) {           // DMA of k-tile next_kt into stage `buf`, then step the pointers
-    if (ragged_k && next_kt == ktiles - 1) sources(next_kt);
-    const uint32_t d = lbase + buf * STAGE4;
-    lds_dma_1k<0>(sa.p[0], d);
-    lds_dma_1k<0>(sa.p[1], d + 1024);
-    lds_dma_1k<0>(sb.p[0], d + T4_BYTES);
-    lds_dma_1k<0>(sb.p[1], d + T4_BYTES + 1024);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { sa.p[j] += stepA; sb.p[j] += stepB; }
-    ++next_kt;
-  };
-
-  int fa_off[2], fb_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (AK) fa_off[i] = (wm * 64 + i * 32 + (lane & 31)) * 64;
-    else {
-      const int n = wm * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-      fa_off[i] = ((lane >> 5) * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
-    }
-    if (BK) fb_off[i] = (wn * 64 + i * 32 + (lane & 31)) * 64;
-    else {
-      const int n = wn * 64 + i * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-      fb_off[i] = ((lane >> 5) * 2 + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 + (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
-    }
-  }
-  const int swzA = ((wm * 64 + (lane & 31)) >> 2) & 3;   // rows 32 apart share (row >> 2) & 3
-  const int swzB = ((wn * 64 + (lane & 31)) >> 2) & 3;
-  auto frag = [&](const char* tl, bool kmajor, int off, int swz, int ks) -> Frag<bf16_t> {
-    Frag<bf16_t> f;
-    if (kmajor) {
-      f.v = *reinterpret_cast<const uint4*>(tl + off + (((2 * ks + (lane >> 5)) ^ swz) << 4));
-    } else {
-      typedef __attribute__((address_space(3))) s16x4_t* lds_s4p;
-      const char* q = tl + off + ks * 4096;
-      s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q));
-      s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q + 512));
-      uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-      f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
-    }
-    return f;
-  };
-
-  if (nk > 0) sources(kt_begin);
-#pragma unroll
-  for (int s0 = 0; s0 < NST4 - 1; ++s0)
-    if (s0 < nk) issue_next(s0);
-  for (int it = 0; it < nk; ++it) {
-    // stages it+1 and it+2 (when they exist) may still be in flight: 4 DMA instructions per stage and wave
-    const int ahead = min(NST4 - 2, nk - 1 - it);
-    if (ahead >= 2) wait_vm<8>(); else if (ahead == 1) wait_vm<4>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();            // stage `it` landed for every wave; stage (it-1) is free (all waves read it)
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    if (it + NST4 - 1 < nk) issue_next((it + NST4 - 1) & (NST4 - 1));
-    const char* tA = smem + (it & (NST4 - 1)) * STAGE4;
-    const char* tB = tA + T4_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Frag<bf16_t> fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag(tA, AK, fa_off[i], swzA, ks);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = frag(tB, BK, fb_off[j], swzB, ks);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma_step(fa[i], fb[j], acc[i][j]);
-    }
-  }
-  wait_vm<0>();
-  __syncthreads();
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
-}
-
 __global__ void splitk_reduce_kernel(GemmParams p) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t total = (int64_t)p.M * p.N;
@@ -1108,33 +817,6 @@ static int launch_gemm_dma_pipe(const GemmParams& p, bool ak, bool bk, dim3 grid
   return check_launch("peneo_gemm");
 }
 
-static int launch_gemm_dma4(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  size_t shmem = NST4 * STAGE4 + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
-  if (p.dz_on) {
-    if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
-  }
-  if (ak && bk) hipLaunchKernelGGL((gemm_dma4_kernel<true, true>), grid, dim3(256), shmem, st, p);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_dma4_kernel<true, false>), grid, dim3(256), shmem, st, p);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_dma4_kernel<false, true>), grid, dim3(256), shmem, st, p);
-  else hipLaunchKernelGGL((gemm_dma4_kernel<false, false>), grid, dim3(256), shmem, st, p);
-  return check_launch("peneo_gemm");
-}
-
-static int launch_gemm_dma(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  size_t shmem = 4 * TILE_BYTES + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
-  if (p.dz_on) {   // > 64 KiB of dynamic LDS needs the opt-in (the pair-dz epilogue is only used with k-major operands)
-    if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
-  }
-  if (ak && bk) hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, dim3(256), shmem, st, p);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, dim3(256), shmem, st, p);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_dma_kernel<false, true>), grid, dim3(256), shmem, st, p);
-  else hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, dim3(256), shmem, st, p);
-  return check_launch("peneo_gemm");
-}
 
 }  // namespace peneo
 
@@ -1246,29 +928,21 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
   auto dma_ok = [](const void* ptr, int64_t ld, bool kmajor, int rows, int k) {
     return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (ld % 8) == 0 && ((kmajor ? k : rows) % 8) == 0 && rows >= 8;
   };
-  static const bool legacy = getenv("PENEO_GEMM_LEGACY") != nullptr;
   int rc = PENEO_OK;
   bool launched = false;
-  if (dtype == PENEO_BF16 && !legacy && a_kmajor && dma_ok(A, lda, true, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K)) {
-    // large forward / dgrad problems: one 8-wave workgroup per CU (gemm_p8.hip: 256 x 256, staggered wave groups, any split;
-    // gemm_big.hip: 384 x 192 / 256 x 128, split_k == 1)
+  if (dtype == PENEO_BF16 && a_kmajor && dma_ok(A, lda, true, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K)) {
+    // large forward problems: one 8-wave workgroup per CU on 256 x 256 / 384 x 192 / 256 x 128 tiles (gemm_big.hip, split_k == 1)
     const int big = launch_gemm_big(p, b_kmajor != 0, st);
     if (big < 0) return big;
     launched = big == 1;
   }
   if (launched) {
-  } else if (dtype == PENEO_BF16 && !legacy && dma_ok(A, lda, a_kmajor != 0, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K))
+  } else if (dtype == PENEO_BF16 && dma_ok(A, lda, a_kmajor != 0, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K))
   {
-    // measured (tools/run_blas_ref.py, run_gemm_shapes.py): the 4-stage pipeline wins for wgrad (both operands mn-major,
-    // +4-8 %), the 2-stage one for the k-major forward shapes (FFN2 fwd 49 vs 56 us, 4096^3 945 vs 768 TFLOP/s)
-    static const int forced = getenv("PENEO_GEMM_STAGES") ? atoi(getenv("PENEO_GEMM_STAGES")) : 0;
-    // 3 = the two-stage kernel with hand-scheduled fragment reads: >= both others on every measured shape
-    // (4096^3: 980 TN / 964 NN TFLOP/s against 945 / 831 for the compiler-scheduled two-stage kernel)
-    const int stages = forced ? forced : 3;
-    rc = stages == 2 ? launch_gemm_dma(p, a_kmajor != 0, b_kmajor != 0, grid, st)
-         : stages == 3 ? launch_gemm_dma_pipe(p, a_kmajor != 0, b_kmajor != 0, grid, st)   // 3 = two stages, hand-scheduled reads
-                       : launch_gemm_dma4(p, a_kmajor != 0, b_kmajor != 0, grid, st);
-    cs_fused = stages == 3 && !a_kmajor && !b_kmajor;       // the (mn-major, mn-major) instantiation sums A's columns itself
+    // the two-stage LDS-DMA kernel with hand-scheduled fragment reads (the compiler-scheduled two-stage form and a four-stage
+    // k-tile-32 form were measured behind it on every shape and removed in round 4)
+    rc = launch_gemm_dma_pipe(p, a_kmajor != 0, b_kmajor != 0, grid, st);
+    cs_fused = !a_kmajor && !b_kmajor;       // the (mn-major, mn-major) instantiation sums A's columns itself
   }
   else
     rc = dtype == PENEO_BF16 ? launch_gemm<bf16_t>(p, a_kmajor != 0, b_kmajor != 0, grid, st)

@@ -268,22 +268,14 @@ static double small_cost(int M, int N) {
 }
 
 static int g_big_mode = -1;   // PENEO_GEMM_BIG: 0 = off, 1 = auto (default), 256 / 384 / 128 = force that tile where it applies
-static int g_p8_mode = -1;    // PENEO_GEMM_P8: 0 = off, 1 = the staggered 256 x 256 kernel (gemm_p8.hip) wherever 256 x 256 is picked, 2 = forced
-int launch_gemm_p8(const GemmParams& p, bool b_kmajor, hipStream_t st);
 
 int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   if (g_big_mode < 0) { const char* e = getenv("PENEO_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
-  if (g_p8_mode < 0) { const char* e = getenv("PENEO_GEMM_P8"); g_p8_mode = e ? atoi(e) : 0; }
-  if (g_p8_mode == 2) {   // forced (tools): every aligned problem, any split
-    if (((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) || (p.lda * 2) % 16 != 0 || (p.ldb * 2) % 16 != 0) return 0;
-    return launch_gemm_p8(p, b_kmajor, st);
-  }
   if (g_big_mode == 0) return 0;
   // mn-major B = the dgrad GEMMs of the backward: in the step they run beside the weight-gradient stream, and a workgroup that
   // needs a CU's whole LDS cannot share it (measured: d_zi on 384 x 192 tiles 50 us alone, 166 us in the step; the step is
-  // 0.2 ms FASTER with the 128 x 128 kernel there).  PENEO_GEMM_BIG_NN=1 for stand-alone measurements.
-  static const bool nn_ok = getenv("PENEO_GEMM_BIG_NN") && atoi(getenv("PENEO_GEMM_BIG_NN")) != 0;
-  if (!b_kmajor && !nn_ok && g_big_mode == 1) return 0;
+  // 0.2 ms FASTER with the 128 x 128 kernel there).  A forced tile (tools) still runs them.
+  if (!b_kmajor && g_big_mode == 1) return 0;
   if (p.split_k > 1 || p.dz_on || p.K % 64 != 0 || p.K < 128 || p.N % 8 != 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) return 0;
   if ((p.lda * 2) % 16 != 0 || (p.ldb * 2) % 16 != 0) return 0;
@@ -306,8 +298,7 @@ int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
     double best = c256;
     if (c384 < best) { best = c384; pick = 384; }
     if (c128 < best) { best = c128; pick = 128; }
-    static const double margin = getenv("PENEO_GEMM_BIG_MARGIN") ? atof(getenv("PENEO_GEMM_BIG_MARGIN")) : 0.95;
-    if (best > margin * small_cost(p.M, p.N)) return 0;
+    if (best > 0.95 * small_cost(p.M, p.N)) return 0;      // how much better than the 128 x 128 kernel the model must predict
   }
   if (b_kmajor) {
     if (pick == 384) return launch_big<Big384<true>>(p, st);
@@ -323,4 +314,3 @@ int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st) {
 
 /* tools/ only (not in the header): 0 = off, 1 = choose by the cost model, 256 / 384 / 128 = force that tile shape */
 extern "C" void peneo_gemm_set_big_mode(int mode) { peneo::g_big_mode = mode; }
-extern "C" void peneo_gemm_set_p8_mode(int mode) { peneo::g_p8_mode = mode; }

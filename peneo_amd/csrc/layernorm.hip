@@ -395,7 +395,7 @@ static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const voi
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                             int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2,
                             float* partial = nullptr, int64_t partial_rows = 0, float* dcol = nullptr) {
-  static const int64_t cap = [] { const char* e = getenv("PENEO_LN_BWD_BLOCKS"); return (int64_t)(e ? atoi(e) : 256); }();   // 256: fewer same-address atomics on dgamma / dbeta (measured 64..1024)
+  constexpr int64_t cap = 256;   // fewer same-address atomics on dgamma / dbeta (measured 64..1024)
   int64_t blocks = (rows + 7) / 8;
   if (partial) blocks = partial_rows;          // one partial row per block: the caller sized the buffer (ln_partial_rows)
   else if (blocks > cap) blocks = cap;
@@ -409,7 +409,7 @@ static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const voi
 }
 // blocks of the partial-sum form: one row per half-wave up to 1024 blocks (4 per CU), then a grid-stride loop
 static int64_t ln_partial_rows(int64_t rows) {
-  static const int64_t cap = [] { const char* e = getenv("PENEO_LN_BWD_PBLOCKS"); return (int64_t)(e ? atoi(e) : 1024); }();
+  constexpr int64_t cap = 1024;
   int64_t blocks = (rows + 7) / 8;
   return blocks > cap ? cap : blocks;
 }

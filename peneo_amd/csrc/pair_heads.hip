@@ -81,7 +81,6 @@ __global__ void pack_weights_kernel(PackSrc s, T* out) {
 }
 
 struct PairFwdParams {
-  unsigned long long* dbg;   // optional [gridDim][4] s_memtime stamps (tools/ only)
   const void* ab; int B, N, D; int64_t P;
   int num_heads; int classes[PENEO_MAX_HEADS]; int total_classes;
   const void* wp; const float* b1; const float* b2;
@@ -246,7 +245,6 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
   int pi, pj;
   pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
   const int nslab = p.num_heads * D / 32;
-  const unsigned long long t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
 
   for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
 
@@ -323,7 +321,6 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
             (__attribute__((address_space(3))) void*)(wdst_p + buf_ * SLAB_BYTES + u * 1024), 16, 0, 0);
     }
   };
-  const unsigned long long t1 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   // prologue: NSTAGE-1 slabs in flight
 #pragma unroll
   for (int s0 = 0; s0 < (G2 ? 2 : NSTAGE - 1); ++s0)
@@ -425,12 +422,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_he
   }
   if constexpr (PIPE_EPI) second_layer(zp, nslab - 1, w2p0, w2p1);
   if constexpr (!ASM_DMA) __syncthreads();
-  const unsigned long long t2 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
   pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
-  if (p.dbg && tid == 0) {
-    unsigned long long* d = p.dbg + ((int64_t)b * gridDim.x + blockIdx.x) * 4;
-    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = __builtin_amdgcn_s_memtime();
-  }
 }
 
 // ================================================================================================
@@ -1161,7 +1153,6 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
   PENEO_REQUIRE((reinterpret_cast<uintptr_t>(desc->w_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(ab) & 15) == 0,
                 "peneo_pair_heads_fwd: ab / packed weights must be 16-byte aligned");
   PairFwdParams p = {};
-  if (const char* dv = getenv("PENEO_PAIR_DBG_PTR")) p.dbg = reinterpret_cast<unsigned long long*>(strtoull(dv, nullptr, 0));
   p.ab = ab; p.B = B; p.N = N; p.D = desc->D; p.P = (int64_t)N * (N + 1) / 2; p.num_heads = desc->num_heads;
   p.total_classes = total_classes(desc->classes, desc->num_heads);
   PENEO_REQUIRE(p.total_classes <= NCP, "peneo_pair_heads_fwd: more than %d classes in total", NCP);

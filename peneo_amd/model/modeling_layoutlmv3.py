@@ -104,11 +104,10 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, embed_dim, kernel_size=16, stride=16)
 
 
-# PENEO_LN_BIAS_FOLD=1: the output / FFN2 bias gradients come out of the LayerNorm backward (peneo_layernorm_bwd's dx_colsum)
-# instead of two column-sum launches per layer on the weight-gradient stream.  Measured at 8 documents: 24 launches and 0.6 ms of
-# side-stream kernel time less, and the step 0.1 ms SLOWER (interleaved A/B 18.83 / 18.91 / 18.52 against 18.70 / 18.80 / 18.67):
-# the extra reduction sits on the main stream, the column sums ran beside it - so the default is off.
-LN_BIAS_FOLD = os.environ.get("PENEO_LN_BIAS_FOLD", "0") == "1"
+# Bias gradients are column sums on the weight-gradient stream.  Two fusions were built, measured slower and removed from the
+# model: out of the LayerNorm backward (peneo_layernorm_bwd's dx_colsum; round 3: 24 launches fewer, step +0.1 ms: the extra
+# reduction sits on the main stream) and out of the weight-gradient GEMM (peneo_gemm's a_colsum; round 4: 53 launches fewer,
+# step +0.1 .. +0.3 ms: HBM-bound side work became MFMA work beside the main stream -- profiles/r04_bias_gradient_fusion_ab.txt).
 
 
 class _FwdState:
@@ -294,8 +293,7 @@ def _layer_ws_bytes(rows: int, H: int, I: int, which: int) -> int:
 
 
 def _use_stage_calls(model, st, H: int, I: int) -> bool:
-    return (STAGE_CALLS and st.dtype == torch.bfloat16 and H % 8 == 0 and I % 8 == 0 and not model.ln_partials and not LN_BIAS_FOLD
-            and (model.wgrad_late or not model.wgrad_on_side_stream) and model.rel_after_dgrad)
+    return STAGE_CALLS and st.dtype == torch.bfloat16 and H % 8 == 0 and I % 8 == 0
 
 
 class _LayerBuffers:
@@ -529,19 +527,6 @@ class _LayerStage(torch.autograd.Function):
                 side.wait_event(ev)
                 return fn()
 
-        # PENEO_WGRAD_LATE: the FFN / output-projection weight gradients do not start beside the dgrad GEMMs that produce
-        # their operands (two MFMA-bound kernels then share the CUs and both take longer) but when the attention backward
-        # starts: its second, thin round of workgroups leaves most CUs idle
-        late = model.wgrad_late and side is not None
-        held = []
-
-        def on_side_late(fn):
-            if not late:
-                return on_side(fn)
-            box = [None, None]
-            held.append((fn, box))
-            return box
-
         def wgrad(dy, xin):
             return ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
         # all small fp32 accumulators of the stage (LayerNorm and bias gradients) carved from ONE zero-filled buffer:
@@ -555,40 +540,22 @@ class _LayerStage(torch.autograd.Function):
         dg2, db2, dg1, db1 = pool[:H], pool[H:2 * H], pool[2 * H:3 * H], pool[3 * H:4 * H]
         o_ = 4 * H
         dbo2, dbi, dbo, dbqkv = pool[o_:o_ + H], pool[o_ + H:o_ + H + I], pool[o_ + H + I:o_ + 2 * H + I], pool[o_ + 2 * H + I:]
+
         # LayerNorm backward writes d_h (for the residual branch) and, in the same pass, d_h through the dropout mask of
         # the dense layer that fed the LayerNorm (for that layer's dgrad / wgrad)
-        # LayerNorm parameter gradients: per-workgroup partial sums from the backward kernel (no same-address atomics at its
-        # end, one row per half-wave), column-summed on the weight-gradient stream (model.ln_partials; dg | db are adjacent)
-        side_keep = []
-
-        # ... and, with LN_BIAS_FOLD, the column sums of that second output = the dense layer's bias gradient
-        def ln_bwd(dy, hx, g, m, r, dgb, dxd, seed_, dbias):
-            if model.ln_partials and side is not None:
-                dxo, part = ops.layernorm_bwd_partial(dy, hx, g, m, r, dx_dropped=dxd, drop2_p=seeds.p_hidden, drop2_seed=seed_)
-                if part is not None:
-                    side_keep.append(part)       # read by the side stream: stays referenced until the join
-                    return dxo, (lambda: (ops.colsum(part, out=dgb, accumulate=True),
-                                          ops.colsum(dxd if dxd is not None else dxo, out=dbias, accumulate=True)))
-            if not LN_BIAS_FOLD:   # default: the bias gradient as a column sum on the weight-gradient stream (see LN_BIAS_FOLD)
-                dxo = ops.layernorm_bwd(dy, hx, g, m, r, dgb[:H], dgb[H:], dx_dropped=dxd, drop2_p=seeds.p_hidden, drop2_seed=seed_)
-                return dxo, (lambda: ops.colsum(dxd if dxd is not None else dxo, out=dbias, accumulate=True))
-            return ops.layernorm_bwd(dy, hx, g, m, r, dgb[:H], dgb[H:], dx_dropped=dxd, drop2_p=seeds.p_hidden,
-                                     drop2_seed=seed_, dx_colsum=dbias), (lambda: None)
+        def ln_bwd(dy, hx, g, m, r, dg, db, dxd, seed_):
+            return ops.layernorm_bwd(dy, hx, g, m, r, dg, db, dx_dropped=dxd, drop2_p=seeds.p_hidden, drop2_seed=seed_)
 
         d_dense2 = torch.empty_like(h2) if seeds.p_hidden > 0 else None
-        d_h2, red2 = ln_bwd(d_out, h2, g2, m2, r2, pool[:2 * H], d_dense2, seeds.seed(site + 3), dbo2)
+        d_h2 = ln_bwd(d_out, h2, g2, m2, r2, dg2, db2, d_dense2, seeds.seed(site + 3))
         if d_dense2 is None:
             d_dense2 = d_h2
-        r_o2 = on_side_late(lambda: (red2(), wgrad(d_dense2, inter)))
         d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
-        r_i = on_side_late(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)))
         d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
-
         d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
-        d_h1, red1 = ln_bwd(d_a, h1, g1, m1, r1, pool[2 * H:4 * H], d_dense1, seeds.seed(site + 2), dbo)
+        d_h1 = ln_bwd(d_a, h1, g1, m1, r1, dg1, db1, d_dense1, seeds.seed(site + 2))
         if d_dense1 is None:
             d_dense1 = d_h1
-        r_o = on_side_late(lambda: (red1(), wgrad(d_dense1, att)))
         d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
 
         dqkv = torch.empty_like(qkv)
@@ -604,40 +571,31 @@ class _LayerStage(torch.autograd.Function):
                 ds_out = st.ds_layers[idx]
             elif st.g_bias is None:
                 st.g_bias = torch.zeros(st.bias.shape, dtype=torch.float32, device=dev)
-        if held:
-            def run_held():
-                for fn, box in held:
-                    box[0], box[1] = fn()
-            on_side(run_held)          # the event sits behind the d_att GEMM: they start with the attention backward
-        dwo2, dwi, dwo = r_o2[1], r_i[1], r_o[1]
+        # The FFN / output-projection weight gradients and bias column sums do not start beside the dgrad GEMMs that produce
+        # their operands (two MFMA-bound kernels then share the CUs and both take longer) but when the attention backward
+        # starts: its second, thin round of workgroups leaves most CUs idle (+0.7 %; the event sits behind the d_att GEMM)
+        _, dwo2, _, dwi, _, dwo = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter),
+                                                   ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a),
+                                                   ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)))
         ops.attn_bwd(q, k, v, att, d_att, lse, B, nh, T, d, 1.0 / math.sqrt(d), st.bias, st.key_bias, dqkv,
                      st.g_bias if ds_out is None else None, drop_p=seeds.p_attn,
                      drop_words=seeds.attn_words(idx, cfg.num_hidden_layers, B, nh, T, q.device), ds_out=ds_out)
         _, dwqkv = on_side(lambda: (ops.colsum(dqkv, out=dbqkv, accumulate=True), wgrad(dqkv, x)))
-        def launch_rel():
-            if ds_out is not None and idx == 0:
-                # the bias-table gradient of all layers (their dS^T slabs are complete), on its own stream (joined only by
-                # _EmbedStage.backward): LDS-atomic and HBM bound
-                hi = cfg.num_hidden_layers
-                rel_stream = model.side_stream(dev, "rel")
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(rel_stream):
-                    rel_stream.wait_event(ev)
-                    model.reduce_rel_group(st, idx, hi, B, T)
-
-        # The reduction goes out BEHIND this stage's last dgrad GEMM (PENEO_REL_AFTER_DGRAD=0: in front of it): started first,
-        # the 277 us reduction stretched that GEMM from 54 to 247 us at the tail of the step; behind it, it runs beside the
-        # embedding stage's small kernels
-        if not model.rel_after_dgrad:
-            launch_rel()
         d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_h1)
-        if model.rel_after_dgrad:
-            launch_rel()
+        if ds_out is not None and idx == 0:
+            # the bias-table gradient of all layers (their dS^T slabs are complete), on its own stream (joined only by
+            # _EmbedStage.backward): LDS-atomic and HBM bound.  It goes out BEHIND this stage's last dgrad GEMM: started in front
+            # of it, the 277 us reduction stretched that GEMM from 54 to 247 us at the tail of the step
+            rel_stream = model.side_stream(dev, "rel")
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(rel_stream):
+                rel_stream.wait_event(ev)
+                model.reduce_rel_group(st, idx, cfg.num_hidden_layers, B, T)
         if side is not None:
             if model.defer_wgrad_join and can_defer(ctx.params):
                 # joined one stage later (engine.py): the critical path does not wait for dW_qkv
-                defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x, *side_keep))
+                defer_join(side, keep=(d_dense2, inter, d_zi, a, d_dense1, att, dqkv, x))
             else:
                 main.wait_stream(side)    # gradients are accumulated into existing .grad tensors on main right after this
         grads = (dwqkv[:H], dbqkv[:H], dwqkv[H:2 * H], dbqkv[H:2 * H], dwqkv[2 * H:], dbqkv[2 * H:], dwo, dbo, dg1, db1,
@@ -682,9 +640,6 @@ class LayoutLMv3Model(nn.Module):
         self.compute_dtype = torch.float32
         self.wgrad_on_side_stream = os.environ.get("PENEO_WGRAD_STREAM", "1") != "0"
         self.defer_wgrad_join = os.environ.get("PENEO_DEFER_JOIN", "1") != "0"
-        self.ln_partials = os.environ.get("PENEO_LN_PARTIALS", "0") != "0"   # measured +-0 in the step; gives order-independent dgamma / dbeta
-        self.wgrad_late = os.environ.get("PENEO_WGRAD_LATE", "1") != "0"   # +0.7 % (17.72 -> 17.59 ms per step)
-        self.rel_after_dgrad = os.environ.get("PENEO_REL_AFTER_DGRAD", "1") != "0"
         self._luts = {}
 
     # ---- small host-side constants ---------------------------------------------------------

@@ -128,22 +128,21 @@ def _post_attn_bwd(wc: WeightCache, key: str, dt, seeds: DropoutSeeds, site: int
     dg2, db2, dg1, db1 = pool[:Hs], pool[Hs:2 * Hs], pool[2 * Hs:3 * Hs], pool[3 * Hs:4 * Hs]
     dbo2, dbi, dbo = pool[4 * Hs:5 * Hs], pool[5 * Hs:5 * Hs + Is], pool[5 * Hs + Is:]
     d_dense2 = torch.empty_like(h2) if seeds.p_hidden > 0 else None
-    from .modeling_layoutlmv3 import LN_BIAS_FOLD   # the bias gradients out of the LayerNorm backward, or as column sums (default)
     d_h2 = ops.layernorm_bwd(d_out.contiguous(), h2, g2, m2, r2, dg2, db2, dx_dropped=d_dense2, drop2_p=seeds.p_hidden,
-                             drop2_seed=seeds.seed(site + 1), dx_colsum=dbo2 if LN_BIAS_FOLD else None)
+                             drop2_seed=seeds.seed(site + 1))
     if d_dense2 is None:
         d_dense2 = d_h2
-    _, dwo2 = on_side(lambda: (None if LN_BIAS_FOLD else ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)),
+    _, dwo2 = on_side(lambda: (ops.colsum(d_dense2, out=dbo2, accumulate=True), wgrad(d_dense2, inter)),
                       (d_dense2, inter))
     d_zi = ops.gemm(d_dense2, Wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)
     _, dwi = on_side(lambda: (ops.colsum(d_zi, out=dbi, accumulate=True), wgrad(d_zi, a)), (d_zi, a))
     d_a = ops.gemm(d_zi, Wi, b_kmajor=False, residual=d_h2)
     d_dense1 = torch.empty_like(h1) if seeds.p_hidden > 0 else None
     d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1, dx_dropped=d_dense1, drop2_p=seeds.p_hidden,
-                             drop2_seed=seeds.seed(site), dx_colsum=dbo if LN_BIAS_FOLD else None)
+                             drop2_seed=seeds.seed(site))
     if d_dense1 is None:
         d_dense1 = d_h1
-    _, dwo = on_side(lambda: (None if LN_BIAS_FOLD else ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)),
+    _, dwo = on_side(lambda: (ops.colsum(d_dense1, out=dbo, accumulate=True), wgrad(d_dense1, att)),
                      (d_dense1, att))
     d_att = ops.gemm(d_dense1, Wo, b_kmajor=False)
     return d_att, d_h1, (dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2)

@@ -488,10 +488,10 @@ def test_fused_adamw_training_steps_reduce_the_loss():
     assert losses[1] < losses[0] and losses[3] < losses[1], losses
 
 
-@pytest.mark.parametrize("env", [{"PENEO_STAGE_CALLS": "0"}, {"PENEO_WGRAD_STREAM": "0"}, {"PENEO_BWD_FUSED": "0", "PENEO_BWD_CHUNK_PAIRS": "300"},
+@pytest.mark.parametrize("env", [{"PENEO_STAGE_CALLS": "0"}, {"PENEO_WGRAD_STREAM": "0"}, {"PENEO_STAGE_CALLS": "0", "PENEO_WGRAD_STREAM": "0"},
+                                 {"PENEO_BWD_FUSED": "0", "PENEO_BWD_CHUNK_PAIRS": "300"},
                                  {"PENEO_BWD_FUSED": "0", "PENEO_DZ_FUSED": "0"}, {"PENEO_DEFER_JOIN": "0", "PENEO_DW1_HOLD": "0"},
-                                 {"PENEO_DW1_SIDE": "0"}, {"PENEO_LN_PARTIALS": "1", "PENEO_WGRAD_LATE": "0"},
-                                 {"PENEO_LN_BIAS_FOLD": "1"}])
+                                 {"PENEO_DW1_SIDE": "0"}])
 def test_optional_execution_modes_keep_the_gradients(env):
     """The remaining stream / chunking options (weight gradients on the main stream, the chunked decoder backward with and
     without the fused dz kernel, immediate joins, dW1 on the main stream) are read at construction time: run the bf16

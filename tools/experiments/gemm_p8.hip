@@ -1,3 +1,9 @@
+// NOT BUILT INTO libpeneo_hip.so.  Round-4 experiment kept for reference (profiles/r04_gemm_p8_*.txt): a 256 x 256
+// GEMM whose two wave groups run half a phase apart.  Correct on every layout / split at the first run and +6 .. +16 % over the
+// lock-step 256 x 256 kernel at 4096^3, but behind the 128 x 128 kernel on every shape the model has (QKV forward 38.7 vs 35.3
+// us): both 256 x 256 forms sit at the same ~2 us per k-tile, the rate at which ONE CU turns LDS-DMA requests into LDS lines
+// while its matrix cores run (ablations: MFMA only 1.24, LDS-DMA only 1.07, both 1.91 us per k-tile).  To build it again:
+// copy to peneo_amd/csrc/, declare launch_gemm_p8 in gemm_big.hip and call it where a 256 x 256 tile is picked.
 // bf16 GEMM, 256 x 256 workgroup tile, ONE 8-wave workgroup per CU, two wave groups running half a phase apart (gfx950).
 //
 // Why: in gemm_big.hip all eight waves of the CU walk the k-tile in lock step behind one barrier -- they
