@@ -465,9 +465,11 @@ int peneo_adamw_step(const peneo_adamw_tensor* table_dev, const int32_t* chunk_t
                      int n_chunks, float beta1, float beta2, float eps, int step, peneo_stream_t stream);
 /* Global gradient-norm clipping inside the step (the reference trains through HF Trainer.train(), start/run_rfund.py:307-321,
  * whose default max_grad_norm = 1.0 clips every step with torch.nn.utils.clip_grad_norm_): peneo_grad_sqnorm leaves
- * sum_t |grad_t|^2 over all tensors of the table in *sqnorm_dev (device fp64, zeroed by the call, stream-ordered, no host
- * sync); peneo_adamw_step_clip then uses grad * min(1, max_grad_norm / (sqrt(*sqnorm_dev) + 1e-6)) in place of grad.  The
- * gradient tensors are not modified.  sqnorm_dev == NULL: no clipping (== peneo_adamw_step). */
+ * sum_t |grad_t|^2 over all tensors of the table as peneo_grad_sqnorm_slots() partial sums in sqnorm_dev (device fp64 array,
+ * zeroed by the call, stream-ordered, no host sync; their sum is the squared norm); peneo_adamw_step_clip then uses
+ * grad * min(1, max_grad_norm / (sqrt(sum) + 1e-6)) in place of grad.  The gradient tensors are not modified.
+ * sqnorm_dev == NULL: no clipping (== peneo_adamw_step). */
+int peneo_grad_sqnorm_slots(void);
 int peneo_grad_sqnorm(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,
                       int n_chunks, double* sqnorm_dev, peneo_stream_t stream);
 int peneo_adamw_step_clip(const peneo_adamw_tensor* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_index_dev,

@@ -154,6 +154,7 @@ SIGNATURES = {
     "peneo_adamw_chunk_elems": (_i, []),
     "peneo_adamw_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
     "peneo_grad_sqnorm": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "peneo_grad_sqnorm_slots": (_i, []),
     "peneo_adamw_step_clip": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp, _f, _vp]),
     "peneo_struct_bytes": (C.c_size_t, [_i]),
     "peneo_encoder_layer_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),

@@ -149,7 +149,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def last_grad_norm(self):
         """Global L2 norm of the gradients the last step saw (before clipping); None without max_grad_norm."""
-        return None if self._sqnorm is None else self._sqnorm.sqrt().to(torch.float32)
+        return None if self._sqnorm is None else self._sqnorm.sum().sqrt().to(torch.float32).reshape(1)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -166,7 +166,7 @@ class FusedAdamW(torch.optim.Optimizer):
         sq = None
         if self.max_grad_norm is not None:
             if self._sqnorm is None or self._sqnorm.device != self._table.device:
-                self._sqnorm = torch.zeros(1, dtype=torch.float64, device=self._table.device)
+                self._sqnorm = torch.zeros(int(lib().peneo_grad_sqnorm_slots()), dtype=torch.float64, device=self._table.device)
             sq = self._sqnorm
             check(lib().peneo_grad_sqnorm(ptr(self._table), ptr(self._chunk_t), ptr(self._chunk_i), self._chunk_t.numel(),
                                           ptr(sq), stream()), "peneo_grad_sqnorm")
