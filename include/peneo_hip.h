@@ -102,6 +102,10 @@ typedef struct peneo_gemm_problem {
   const void* B; int64_t ldb;
   void* C; int64_t ldc;
   int accumulate;           /* C += A B (c_dtype must be PENEO_F32) */
+  const peneo_gemm_epilogue* ep;   /* optional fused epilogue of THIS problem (bias, activation, pre-activation store, x act'(src),
+                                    * dropout, residual: as for peneo_gemm; no pair_dz, no a_colsum); NULL = none.  Round 4: LiLT's
+                                    * text and layout streams (modeling_lilt.py:269-429, H = 768 and H / 4 = 192) run each pair of
+                                    * same-role Linear layers as one launch -- a [4096, 192] x [192, 576] GEMM alone is all fixed cost */
 } peneo_gemm_problem;
 int peneo_gemm_group(int dtype, int a_kmajor, int b_kmajor, int c_dtype, const peneo_gemm_problem* problems, int n,
                      peneo_stream_t stream);

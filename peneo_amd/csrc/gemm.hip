@@ -852,7 +852,14 @@ extern "C" int peneo_gemm_group(int dtype, int a_kmajor, int b_kmajor, int c_dty
     p.A = q.A; p.B = q.B; p.C = q.C; p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.M = q.M; p.N = q.N; p.K = q.K;
     p.c_dtype = c_dtype;
     peneo_gemm_epilogue z = {};
-    p.ep = z; p.ep.alpha = 1.f; p.ep.accumulate = q.accumulate;
+    p.ep = (i < n && q.ep) ? *q.ep : z;
+    if (i < n && q.ep) {
+      PENEO_REQUIRE(!q.ep->pair_dz && !q.ep->a_colsum, "peneo_gemm_group: problem %d: pair_dz / a_colsum are not available in a group", i);
+      PENEO_REQUIRE(q.ep->drop_p >= 0.f && q.ep->drop_p < 1.f, "peneo_gemm_group: problem %d: drop_p out of range", i);
+      PENEO_REQUIRE(!q.ep->accumulate || c_dtype == PENEO_F32, "peneo_gemm_group: accumulate needs an fp32 C");
+    }
+    if (p.ep.alpha == 0.f) p.ep.alpha = 1.f;
+    if (q.accumulate) p.ep.accumulate = 1;
     p.split_k = 1; p.ws = nullptr; p.kt_per_split = (q.K + 63) / 64; p.dz_on = 0; p.dz_ws = nullptr;
     peneo_pair_dz_args za = {};
     p.dz = za;

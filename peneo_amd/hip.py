@@ -51,7 +51,7 @@ class EncoderLayerGrads(C.Structure):
 
 class GemmProblem(C.Structure):
     _fields_ = [("M", _i), ("N", _i), ("K", _i), ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
-                ("accumulate", _i)]
+                ("accumulate", _i), ("ep", _vp)]
 
 
 class CastItem(C.Structure):

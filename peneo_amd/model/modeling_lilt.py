@@ -226,6 +226,97 @@ class _LiltEmbedStage(torch.autograd.Function):
         return (None, None, None, None) + grads
 
 
+# ------------------------------------------------------------------------------------------------
+# bf16: the two streams in lock step, every pair of same-role Linear layers as ONE grouped launch (ops.gemm_group with
+# per-problem epilogues).  The layout stream's GEMMs ([4096, 192] x [192, 576] ...) are all fixed cost on their own (11-18 us
+# for 1-2 us of MFMA work), and a LiLT step issued launch by launch is host-bound (18.5 ms of host against 20 ms of device time).
+# ------------------------------------------------------------------------------------------------
+def _use_groups(dt, *dims) -> bool:
+    return dt == torch.bfloat16 and all(d % 8 == 0 for d in dims) and os.environ.get("PENEO_LILT_GROUPS", "1") != "0"
+
+
+def _post_attn_fwd2(wc, idx, dt, eps, seeds, site_t, site_l, x, att, tp, l, latt, lp):
+    (wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2), (lwo, lbo, lg1, lb1, lwi, lbi, lwo2, lbo2, lg2, lb2) = tp, lp
+    kt, kl = f"L{idx}.t", f"L{idx}.l"
+    Wo, Wi, Wo2 = wc.cast(kt + ".o", wo, dt), wc.cast(kt + ".i", wi, dt), wc.cast(kt + ".o2", wo2, dt)
+    lWo, lWi, lWo2 = wc.cast(kl + ".o", lwo, dt), wc.cast(kl + ".i", lwi, dt), wc.cast(kl + ".o2", lwo2, dt)
+    h1, lh1 = ops.gemm_group([(att, Wo, None, dict(bias=bo, residual=x, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site_t))),
+                              (latt, lWo, None, dict(bias=lbo, residual=l, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site_l)))])
+    a, m1, r1 = ops.layernorm_fwd(h1, g1, b1, eps)
+    la, lm1, lr1 = ops.layernorm_fwd(lh1, lg1, lb1, eps)
+    zi = torch.empty((x.shape[0], wi.shape[0]), dtype=dt, device=x.device)
+    lzi = torch.empty((l.shape[0], lwi.shape[0]), dtype=dt, device=x.device)
+    inter, linter = ops.gemm_group([(a, Wi, None, dict(bias=bi, act=ACT_GELU, preact=zi)),
+                                    (la, lWi, None, dict(bias=lbi, act=ACT_GELU, preact=lzi))])
+    h2, lh2 = ops.gemm_group([(inter, Wo2, None, dict(bias=bo2, residual=a, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site_t + 1))),
+                              (linter, lWo2, None, dict(bias=lbo2, residual=la, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site_l + 1)))])
+    out, m2, r2 = ops.layernorm_fwd(h2, g2, b2, eps)
+    lout, lm2, lr2 = ops.layernorm_fwd(lh2, lg2, lb2, eps)
+    return out, lout, (att, h1, m1, r1, a, zi, inter, h2, m2, r2), (latt, lh1, lm1, lr1, la, lzi, linter, lh2, lm2, lr2)
+
+
+def _post_attn_bwd2(wc, idx, dt, seeds, site_t, site_l, d_out, d_lout, sv_t, sv_l, tp, lp, on_side):
+    """Both streams' post-attention backward in lock step: the three dgrad GEMM pairs as grouped launches on the main stream, the
+    text weight gradients one by one (split-k) and the FOUR layout weight gradients of this half as one grouped launch (each tile
+    with its full K = tokens: 38 long workgroups instead of four split-k launches + four reductions) on the side stream."""
+    (wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2), (lwo, lbo, lg1, lb1, lwi, lbi, lwo2, lbo2, lg2, lb2) = tp, lp
+    att, h1, m1, r1, a, zi, inter, h2, m2, r2 = sv_t
+    latt, lh1, lm1, lr1, la, lzi, linter, lh2, lm2, lr2 = sv_l
+    kt, kl = f"L{idx}.t", f"L{idx}.l"
+    Wo, Wi, Wo2 = wc.cast(kt + ".o", wo, dt), wc.cast(kt + ".i", wi, dt), wc.cast(kt + ".o2", wo2, dt)
+    lWo, lWi, lWo2 = wc.cast(kl + ".o", lwo, dt), wc.cast(kl + ".i", lwi, dt), wc.cast(kl + ".o2", lwo2, dt)
+    dev = d_out.device
+    Hs, Is, Hl, Il = wo.shape[0], wi.shape[0], lwo.shape[0], lwi.shape[0]
+    wgrad = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
+    pool = torch.zeros(4 * Hs + (Hs + Is + Hs) + 4 * Hl + (Hl + Il + Hl), dtype=torch.float32, device=dev)   # one fill for all small accumulators
+    dg2, db2, dg1, db1 = pool[:Hs], pool[Hs:2 * Hs], pool[2 * Hs:3 * Hs], pool[3 * Hs:4 * Hs]
+    o = 4 * Hs
+    dbo2, dbi, dbo = pool[o:o + Hs], pool[o + Hs:o + Hs + Is], pool[o + Hs + Is:o + 2 * Hs + Is]
+    o += 2 * Hs + Is
+    ldg2, ldb2, ldg1, ldb1 = pool[o:o + Hl], pool[o + Hl:o + 2 * Hl], pool[o + 2 * Hl:o + 3 * Hl], pool[o + 3 * Hl:o + 4 * Hl]
+    o += 4 * Hl
+    ldbo2, ldbi, ldbo = pool[o:o + Hl], pool[o + Hl:o + Hl + Il], pool[o + Hl + Il:]
+    drop = seeds.p_hidden > 0
+    d_dense2 = torch.empty_like(h2) if drop else None
+    d_ldense2 = torch.empty_like(lh2) if drop else None
+    d_h2 = ops.layernorm_bwd(d_out.contiguous(), h2, g2, m2, r2, dg2, db2, dx_dropped=d_dense2, drop2_p=seeds.p_hidden,
+                             drop2_seed=seeds.seed(site_t + 1))
+    d_lh2 = ops.layernorm_bwd(d_lout.contiguous(), lh2, lg2, lm2, lr2, ldg2, ldb2, dx_dropped=d_ldense2, drop2_p=seeds.p_hidden,
+                              drop2_seed=seeds.seed(site_l + 1))
+    if not drop:
+        d_dense2, d_ldense2 = d_h2, d_lh2
+    d_zi, d_lzi = ops.gemm_group([(d_dense2, Wo2, None, dict(grad_src=zi, grad_act=ACT_GELU)),
+                                  (d_ldense2, lWo2, None, dict(grad_src=lzi, grad_act=ACT_GELU))], b_kmajor=False)
+    d_a, d_la = ops.gemm_group([(d_zi, Wi, None, dict(residual=d_h2)), (d_lzi, lWi, None, dict(residual=d_lh2))], b_kmajor=False)
+    d_dense1 = torch.empty_like(h1) if drop else None
+    d_ldense1 = torch.empty_like(lh1) if drop else None
+    d_h1 = ops.layernorm_bwd(d_a, h1, g1, m1, r1, dg1, db1, dx_dropped=d_dense1, drop2_p=seeds.p_hidden, drop2_seed=seeds.seed(site_t))
+    d_lh1 = ops.layernorm_bwd(d_la, lh1, lg1, lm1, lr1, ldg1, ldb1, dx_dropped=d_ldense1, drop2_p=seeds.p_hidden,
+                              drop2_seed=seeds.seed(site_l))
+    if not drop:
+        d_dense1, d_ldense1 = d_h1, d_lh1
+    d_att, d_latt = ops.gemm_group([(d_dense1, Wo, None), (d_ldense1, lWo, None)], b_kmajor=False)
+
+    def side_work():
+        ops.colsum(d_dense2, out=dbo2, accumulate=True)
+        dwo2 = wgrad(d_dense2, inter)
+        ops.colsum(d_zi, out=dbi, accumulate=True)
+        dwi = wgrad(d_zi, a)
+        ops.colsum(d_dense1, out=dbo, accumulate=True)
+        dwo = wgrad(d_dense1, att)
+        ops.colsum(d_ldense2, out=ldbo2, accumulate=True)
+        ops.colsum(d_lzi, out=ldbi, accumulate=True)
+        ops.colsum(d_ldense1, out=ldbo, accumulate=True)
+        ldwo2, ldwi, ldwo = ops.gemm_group([(d_ldense2, linter, None), (d_lzi, la, None), (d_ldense1, latt, None)], a_kmajor=False,
+                                           b_kmajor=False, out_dtype=torch.float32)
+        return dwo2, dwi, dwo, ldwo2, ldwi, ldwo
+    dwo2, dwi, dwo, ldwo2, ldwi, ldwo = on_side(side_work, (d_dense2, inter, d_zi, a, d_dense1, att, d_ldense2, linter, d_lzi, la,
+                                                            d_ldense1, latt))
+    gt = (dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2)
+    gl = (ldwo, ldbo, ldg1, ldb1, ldwi, ldbi, ldwo2, ldbo2, ldg2, ldb2)
+    return d_att, d_h1, gt, d_latt, d_lh1, gl
+
+
 class _LiltLayerStage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, st, idx, x, l, *params):
@@ -244,8 +335,12 @@ class _LiltLayerStage(torch.autograd.Function):
         bqkv = wc.get((f"L{idx}.bqkv",), [bq, bk, bv], lambda: torch.cat([bq.detach(), bk.detach(), bv.detach()]))
         Wlqkv = wc.cat_rows(f"L{idx}.lqkv", [lwq, lwk, lwv], dt)
         blqkv = wc.get((f"L{idx}.blqkv",), [lbq, lbk, lbv], lambda: torch.cat([lbq.detach(), lbk.detach(), lbv.detach()]))
-        qkv = ops.gemm(x, Wqkv, bias=bqkv)          # [R, 3H]
-        lqkv = ops.gemm(l, Wlqkv, bias=blqkv)       # [R, 3Hl]
+        grouped = _use_groups(dt, H, Hl, tp[4].shape[0], lp[4].shape[0])
+        if grouped:
+            qkv, lqkv = ops.gemm_group([(x, Wqkv, None, dict(bias=bqkv)), (l, Wlqkv, None, dict(bias=blqkv))])
+        else:
+            qkv = ops.gemm(x, Wqkv, bias=bqkv)          # [R, 3H]
+            lqkv = ops.gemm(l, Wlqkv, bias=blqkv)       # [R, 3Hl]
         R = x.shape[0]
         cat = torch.empty((R, 3 * nh * dc), dtype=dt, device=dev)
         ops.head_concat(qkv[:, :H], lqkv[:, :Hl], nh, cat[:, :nh * dc], 1.0 / math.sqrt(d), 1.0 / math.sqrt(dl))
@@ -256,8 +351,12 @@ class _LiltLayerStage(torch.autograd.Function):
         att = torch.empty((R, H), dtype=dt, device=dev)
         latt = torch.empty((R, Hl), dtype=dt, device=dev)
         ops.head_split(attc, nh, att, latt)
-        xo, sv_t = _post_attn_fwd(wc, f"L{idx}.t", dt, cfg.layer_norm_eps, seeds, site + 2, x, att, tp)
-        lo, sv_l = _post_attn_fwd(wc, f"L{idx}.l", dt, cfg.layer_norm_eps, seeds, site + 6, l, latt, lp)
+        if grouped:
+            xo, lo, sv_t, sv_l = _post_attn_fwd2(wc, idx, dt, cfg.layer_norm_eps, seeds, site + 2, site + 6, x, att, tp, l, latt, lp)
+        else:
+            xo, sv_t = _post_attn_fwd(wc, f"L{idx}.t", dt, cfg.layer_norm_eps, seeds, site + 2, x, att, tp)
+            lo, sv_l = _post_attn_fwd(wc, f"L{idx}.l", dt, cfg.layer_norm_eps, seeds, site + 6, l, latt, lp)
+        ctx.grouped = grouped
         ctx.model, ctx.st, ctx.idx = model, st, idx
         ctx.saved = (x, l, cat, attc, lse, sv_t, sv_l)
         ctx.params = params
@@ -296,8 +395,11 @@ class _LiltLayerStage(torch.autograd.Function):
                 side.wait_event(ev)
                 return fn()
 
-        d_att, d_x_res, gt = _post_attn_bwd(wc, f"L{idx}.t", dt, seeds, site + 2, d_xo, sv_t, tp, on_side)
-        d_latt, d_l_res, gl = _post_attn_bwd(wc, f"L{idx}.l", dt, seeds, site + 6, d_lo, sv_l, lp, on_side)
+        if ctx.grouped:
+            d_att, d_x_res, gt, d_latt, d_l_res, gl = _post_attn_bwd2(wc, idx, dt, seeds, site + 2, site + 6, d_xo, d_lo, sv_t, sv_l, tp, lp, on_side)
+        else:
+            d_att, d_x_res, gt = _post_attn_bwd(wc, f"L{idx}.t", dt, seeds, site + 2, d_xo, sv_t, tp, on_side)
+            d_latt, d_l_res, gl = _post_attn_bwd(wc, f"L{idx}.l", dt, seeds, site + 6, d_lo, sv_l, lp, on_side)
         d_attc = torch.empty((R, nh * dc), dtype=dt, device=dev)
         ops.head_concat(d_att, d_latt, nh, d_attc)
         qc, kc, vc = cat[:, :nh * dc], cat[:, nh * dc:2 * nh * dc], cat[:, 2 * nh * dc:]
@@ -313,8 +415,11 @@ class _LiltLayerStage(torch.autograd.Function):
         wg = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
         dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)),
                                                (dqkv, dlqkv, x, l))
-        d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_x_res)
-        d_l = ops.gemm(dlqkv, Wlqkv, b_kmajor=False, residual=d_l_res)
+        if ctx.grouped:
+            d_x, d_l = ops.gemm_group([(dqkv, Wqkv, None, dict(residual=d_x_res)), (dlqkv, Wlqkv, None, dict(residual=d_l_res))], b_kmajor=False)
+        else:
+            d_x = ops.gemm(dqkv, Wqkv, b_kmajor=False, residual=d_x_res)
+            d_l = ops.gemm(dlqkv, Wlqkv, b_kmajor=False, residual=d_l_res)
         if os.environ.get("PENEO_DEFER_JOIN", "1") != "0" and can_defer(ctx.params):
             defer_join(side, keep=kept)   # joined one stage later: the critical path does not wait for the QKV wgrads (engine.py)
         else:

@@ -63,23 +63,55 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------------------------
-def gemm_group(problems: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], *, a_kmajor: bool = True,
-               b_kmajor: bool = True, accumulate: bool = False) -> None:
-    """Up to 4 independent bf16 GEMMs out_i = op(A_i) op(B_i) (one operand layout) in ONE launch, each tile with its full K.
-    problems: (A, B, out) with out preallocated [M, N] (fp32 or bf16, all the same dtype)."""
+def _fill_epilogue(ep, out: torch.Tensor, *, bias=None, act=ACT_NONE, residual=None, preact=None, grad_src=None, grad_act=ACT_NONE,
+                   alpha: float = 1.0, accumulate: bool = False, drop_p: float = 0.0, drop_seed: int = 0) -> None:
+    ep.bias = ptr(bias)
+    ep.act = act
+    if preact is not None:
+        assert preact.dtype == out.dtype and preact.shape == out.shape
+        ep.preact, ep.ld_preact = ptr(preact), preact.stride(0)
+    if grad_src is not None:
+        assert grad_src.dtype == out.dtype and grad_src.shape == out.shape
+        ep.grad_src, ep.ld_grad, ep.grad_act = ptr(grad_src), grad_src.stride(0), grad_act
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape == out.shape
+        ep.residual, ep.ld_res = ptr(residual), residual.stride(0)
+    ep.alpha = alpha
+    ep.accumulate = 1 if accumulate else 0
+    ep.drop_p, ep.drop_seed = drop_p, drop_seed & 0xFFFFFFFF
+
+
+def gemm_group(problems: Sequence, *, a_kmajor: bool = True, b_kmajor: bool = True, accumulate: bool = False,
+               out_dtype: Optional[torch.dtype] = None) -> List[torch.Tensor]:
+    """Up to 4 independent bf16 GEMMs out_i = epilogue_i(op(A_i) op(B_i)) (one operand layout) in ONE launch, each tile with its
+    full K.  A problem is (A, B, out) or (A, B, out, epilogue-dict) with out = None to allocate [M, N] of `out_dtype` (default
+    bf16; all outputs share the dtype) and the epilogue keys of `gemm` (bias, act, residual, preact, grad_src, grad_act, drop_p,
+    drop_seed, alpha).  Returns the outputs."""
     n = len(problems)
     arr = (hip.GemmProblem * n)()
-    for q, (A, B, out) in zip(arr, problems):
+    eps, outs = [], []
+    for q, prob in zip(arr, problems):
+        A, B, out = prob[0], prob[1], prob[2]
+        kw = prob[3] if len(prob) > 3 else None
         M = A.shape[0] if a_kmajor else A.shape[1]
         K = A.shape[1] if a_kmajor else A.shape[0]
         N = B.shape[0] if b_kmajor else B.shape[1]
+        if out is None:
+            out = torch.empty((M, N), dtype=out_dtype or torch.bfloat16, device=A.device)
         assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and out.shape == (M, N)
         q.M, q.N, q.K = M, N, K
         q.A, q.lda, q.B, q.ldb, q.C, q.ldc = ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0)
         q.accumulate = int(accumulate)
+        if kw:
+            ep = hip.GemmEpilogue()
+            _fill_epilogue(ep, out, **kw)
+            eps.append(ep)                            # (alive until the call has returned)
+            q.ep = C.cast(C.pointer(ep), C.c_void_p)
+        outs.append(out)
     with kernel_timer("gemm_group"):
-        check(lib().peneo_gemm_group(dtype_code(torch.bfloat16), int(a_kmajor), int(b_kmajor), dtype_code(problems[0][2].dtype),
+        check(lib().peneo_gemm_group(dtype_code(torch.bfloat16), int(a_kmajor), int(b_kmajor), dtype_code(outs[0].dtype),
                                      arr, n, stream()), "peneo_gemm_group")
+    return outs
 
 
 def choose_split_k(M: int, N: int, K: int, dtype: torch.dtype) -> int:

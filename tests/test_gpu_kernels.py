@@ -1023,6 +1023,34 @@ def test_gemm_group_matches_single_launches(ops, layout):
         ops.gemm_group(probs + probs[:1], **kw)             # more than 4 problems
 
 
+def test_gemm_group_with_per_problem_epilogues(ops):
+    """Two Linear layers of different width in ONE launch, each with its own fused epilogue (LiLT's text + layout streams,
+    modeling_lilt.py:269-429): bias + GELU + pre-activation store on one, bias + dropout + residual on the other; then the
+    dgrad pair with x GELU'(src) / + residual.  Each problem must equal its single peneo_gemm launch (to one bf16 step)."""
+    from peneo_amd.hip import ACT_GELU
+    g = torch.Generator().manual_seed(12)
+    dt = torch.bfloat16
+    R = 1000
+    x = torch.randn(R, 768, generator=g).to(DEV).to(dt); l = torch.randn(R, 192, generator=g).to(DEV).to(dt)
+    wi = (torch.randn(3072, 768, generator=g) * 0.05).to(DEV).to(dt); lwi = (torch.randn(768, 192, generator=g) * 0.05).to(DEV).to(dt)
+    bi = torch.randn(3072, generator=g).to(DEV); lbi = torch.randn(768, generator=g).to(DEV)
+    res = torch.randn(R, 768, generator=g).to(DEV).to(dt)
+    zi, lzi = torch.empty(R, 3072, device=DEV, dtype=dt), torch.empty(R, 768, device=DEV, dtype=dt)
+    o1, o2 = ops.gemm_group([(x, wi, None, dict(bias=bi, act=ACT_GELU, preact=zi)),
+                             (l, lwi, None, dict(bias=lbi, residual=res, drop_p=0.1, drop_seed=77))])
+    zi1 = torch.empty_like(zi)
+    s1 = ops.gemm(x, wi, bias=bi, act=ACT_GELU, preact=zi1)
+    s2 = ops.gemm(l, lwi, bias=lbi, residual=res, drop_p=0.1, drop_seed=77)
+    assert rel_err(o1, s1) < 4e-3 and rel_err(zi, zi1) < 4e-3 and rel_err(o2, s2) < 4e-3     # (one bf16 step: the single launch may pick another tile shape)
+    assert rel_err(o1, F.gelu(x.float() @ wi.float().t() + bi)) < 2e-2
+    # dgrad pair (B stored [K, N]): d_zi = (dy Wo2) * GELU'(zi), d_l = dly lWo2 + residual
+    dy = torch.randn(R, 768, generator=g).to(DEV).to(dt); dly = torch.randn(R, 192, generator=g).to(DEV).to(dt)
+    wo2 = (torch.randn(768, 3072, generator=g) * 0.05).to(DEV).to(dt); lwo2 = (torch.randn(192, 768, generator=g) * 0.05).to(DEV).to(dt)
+    d1, d2 = ops.gemm_group([(dy, wo2, None, dict(grad_src=zi, grad_act=ACT_GELU)), (dly, lwo2, None, dict(residual=res))], b_kmajor=False)
+    assert rel_err(d1, ops.gemm(dy, wo2, b_kmajor=False, grad_src=zi, grad_act=ACT_GELU)) < 4e-3
+    assert rel_err(d2, ops.gemm(dly, lwo2, b_kmajor=False, residual=res)) < 4e-3
+
+
 def test_weighted_ce_and_spots(ops):
     from oracle import peneo_oracle as O
     N = 40

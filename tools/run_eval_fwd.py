@@ -1,13 +1,14 @@
 """Eval forward only (B = 8, bf16): the 'encoder + pair-head forward' target of BASELINE.md.  For rocprofv3 --kernel-trace."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-from seeded import layoutlmv3_config, peneo_config
+from seeded import layoutlmv3_config, lilt_config, peneo_config
 from peneo_amd.model import PEneoConfig, PEneoModel
 from peneo_amd.data import synthetic_rfund_batch
-pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
+LILT = os.environ.get("BACKBONE", "layoutlmv3") == "lilt"
+pcfg = peneo_config("lilt-roberta-en-base", lilt_config("base")) if LILT else peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
 m = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"})).cuda().set_compute_dtype(torch.bfloat16).eval()
 m.backbone.check_inputs = False
-bs = [{k: v.cuda() for k, v in synthetic_rfund_batch(8, 512, 128, 50265, seed=s).items()} for s in range(3)]
+bs = [{k: v.cuda() for k, v in synthetic_rfund_batch(8, 512, 128, 50265, seed=s).items() if not (LILT and k == "image")} for s in range(3)]
 with torch.no_grad():
     for i in range(3): m(**bs[i])
     torch.cuda.synchronize(); t0 = time.perf_counter()
