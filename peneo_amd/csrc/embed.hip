@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const T* d_out, int
 // (left, top, right, bottom, height, width) a token's slot is the FIRST token of the chunk with the same index; the chunk's
 // d_out rows are added into an LDS image [slot][H] (a thread owns its columns: no LDS atomics), and only first occurrences go to the
 // table with global atomics.
-constexpr int EBX_TOK = 32;
+constexpr int EBX_TOK = 16;   // tokens per workgroup: 256 workgroups at 8 x 512 tokens (32: 128 workgroups = half the CUs, 57 us)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_box_bwd_kernel(const T* d_out, int64_t rpb, int64_t bstride, const int64_t* bbox,
                                                             peneo_embed_grads g, int cs, int ss, int max_2d, int64_t rows, int H,
