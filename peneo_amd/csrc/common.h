@@ -255,6 +255,15 @@ __device__ __forceinline__ void lds_dma_1k(const char* gsrc_lane, uint32_t lds_b
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_base_uniform), "n"(OFF) : "memory");
 }
+// The same piece addressed as UNIFORM 64-bit base (SGPR pair) + per-lane 32-bit byte offset (global "saddr" form): the issue
+// reads one address VGPR per lane instead of two, and a kernel that walks k keeps its per-lane offsets constant and advances
+// the base with scalar adds (no 64-bit VALU pointer arithmetic per piece and k-tile).
+template <int OFF>
+__device__ __forceinline__ void lds_dma_1k_s(uint32_t voff_lane, const char* base_uniform, uint32_t lds_base_uniform) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff_lane), "s"(base_uniform), "s"(lds_base_uniform), "n"(OFF) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // UPW consecutive 1 KiB pieces (this wave's share of a weight slab).  Hidden in asm, the DMA is ours to order: counted
 // s_waitcnt vmcnt + s_barrier before the slab is read (cdna guide §5.7).

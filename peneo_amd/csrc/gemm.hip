@@ -554,21 +554,66 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
     if (BK) dma_src_kmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
     else dma_src_mnmajor(sb, B, p.ldb, n0, p.N, p.K, kt, wave, lane, guard);
   };
+  // Operand addressing of the k loop: per-lane 32-bit byte offsets inside the tile (constant over k) + a uniform 64-bit base
+  // per operand that walks k with scalar adds.  (The ragged last k-tile keeps the per-lane pointer form: its guard swaps
+  // single lanes' sources for a zero line.)
+  uint32_t oa[4], ob[4];
+  {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (AK) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int sg = (lane & 7) ^ ((row >> 1) & 7);
+        oa[j] = (uint32_t)(((int64_t)(min(m0 + row, p.M - 1) - m0) * p.lda + sg * 8) * 2);
+      } else {
+        const int pc = wave * 4 + j, kr = lane >> 3;
+        const int cg = (lane & 7) ^ (((kr >> 1) & 1) << 2);
+        oa[j] = (uint32_t)(((int64_t)((pc >> 1) * 8 + kr) * p.lda + (min(m0 + (pc & 1) * 64 + cg * 8, p.M - 8) - m0)) * 2);
+      }
+      if (BK) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int sg = (lane & 7) ^ ((row >> 1) & 7);
+        ob[j] = (uint32_t)(((int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldb + sg * 8) * 2);
+      } else {
+        const int pc = wave * 4 + j, kr = lane >> 3;
+        const int cg = (lane & 7) ^ (((kr >> 1) & 1) << 2);
+        ob[j] = (uint32_t)(((int64_t)((pc >> 1) * 8 + kr) * p.ldb + (min(n0 + (pc & 1) * 64 + cg * 8, p.N - 8) - n0)) * 2);
+      }
+    }
+  }
+  // uniform tile bases at k-tile kt (AK: row m0, column kt * 64; mn-major: row kt * 64, column m0)
+  auto base_of = [&](const bf16_t* X, int64_t ld, int r0, bool kmaj, int kt) -> const char* {
+    const char* q = reinterpret_cast<const char*>(kmaj ? X + (int64_t)r0 * ld + (int64_t)kt * 64 : X + (int64_t)kt * 64 * ld + r0);
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  const char* bA = base_of(A, p.lda, m0, AK, kt_begin);
+  const char* bB = base_of(B, p.ldb, n0, BK, kt_begin);
+  bool by_pointer = false;       // the tile about to be issued is the guarded (ragged) one: sa / sb hold per-lane pointers
   auto issue = [&](int buf) {
     const uint32_t d = lbase + buf * STAGE;
-    lds_dma_1k<0>(sa.p[0], d);
-    lds_dma_1k<0>(sa.p[1], d + 1024);
-    lds_dma_1k<0>(sa.p[2], d + 2048);
-    lds_dma_1k<0>(sa.p[3], d + 3072);
-    lds_dma_1k<0>(sb.p[0], d + TILE_BYTES);
-    lds_dma_1k<0>(sb.p[1], d + TILE_BYTES + 1024);
-    lds_dma_1k<0>(sb.p[2], d + TILE_BYTES + 2048);
-    lds_dma_1k<0>(sb.p[3], d + TILE_BYTES + 3072);
+    if (by_pointer) {
+      lds_dma_1k<0>(sa.p[0], d);
+      lds_dma_1k<0>(sa.p[1], d + 1024);
+      lds_dma_1k<0>(sa.p[2], d + 2048);
+      lds_dma_1k<0>(sa.p[3], d + 3072);
+      lds_dma_1k<0>(sb.p[0], d + TILE_BYTES);
+      lds_dma_1k<0>(sb.p[1], d + TILE_BYTES + 1024);
+      lds_dma_1k<0>(sb.p[2], d + TILE_BYTES + 2048);
+      lds_dma_1k<0>(sb.p[3], d + TILE_BYTES + 3072);
+    } else {
+      lds_dma_1k_s<0>(oa[0], bA, d);
+      lds_dma_1k_s<0>(oa[1], bA, d + 1024);
+      lds_dma_1k_s<0>(oa[2], bA, d + 2048);
+      lds_dma_1k_s<0>(oa[3], bA, d + 3072);
+      lds_dma_1k_s<0>(ob[0], bB, d + TILE_BYTES);
+      lds_dma_1k_s<0>(ob[1], bB, d + TILE_BYTES + 1024);
+      lds_dma_1k_s<0>(ob[2], bB, d + TILE_BYTES + 2048);
+      lds_dma_1k_s<0>(ob[3], bB, d + TILE_BYTES + 3072);
+    }
   };
-  auto advance = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sa.p[j] += stepA; sb.p[j] += stepB; }
-  };
+  auto advance = [&]() { bA += stepA; bB += stepB; };
 
   // LDS byte addresses of the fragments inside stage 0 (the stage and the second 32-row block are immediates):
   //   k-major : one address per k-step (the XOR swizzle depends on ks), second row block = +4096
@@ -668,14 +713,16 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
   }
 
   if (kt_begin < kt_end) {
-    sources(kt_begin);
+    by_pointer = ragged_k && kt_begin == ktiles - 1;
+    if (by_pointer) sources(kt_begin);
     issue(0);
   }
   wait_vm<0>();
   __syncthreads();
   for (int kt = kt_begin; kt < kt_end; kt += 2) {
     if (kt + 1 < kt_end) {
-      if (ragged_k && kt + 1 == ktiles - 1) sources(kt + 1); else advance();
+      by_pointer = ragged_k && kt + 1 == ktiles - 1;
+      if (by_pointer) sources(kt + 1); else advance();
       issue(1);
     }
     if constexpr (CS) cs_now = cs_on && (kt % cs_mod) == cs_col;
@@ -684,7 +731,8 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
     __syncthreads();
     if (kt + 1 < kt_end) {
       if (kt + 2 < kt_end) {
-        if (ragged_k && kt + 2 == ktiles - 1) sources(kt + 2); else advance();
+        by_pointer = ragged_k && kt + 2 == ktiles - 1;
+        if (by_pointer) sources(kt + 2); else advance();
         issue(0);
       }
       if constexpr (CS) cs_now = cs_on && ((kt + 1) % cs_mod) == cs_col;

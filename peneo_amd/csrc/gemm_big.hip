@@ -58,14 +58,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_n
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
   const int ktiles = p.K / 64;
 
-  // ---- LDS-DMA sources of this wave's pieces (piece g = wave + 8 u of the A tile / of the B tile) ----
-  const char* srcA[C::APW];
-  const char* srcB[C::BPW];
+  // ---- LDS-DMA sources of this wave's pieces (piece g = wave + 8 u of the A tile / of the B tile): per-lane 32-bit byte
+  //      offsets inside the tile (constant over k) + one uniform 64-bit base per operand that walks k with scalar adds ----
+  uint32_t offA[C::APW], offB[C::BPW];
 #pragma unroll
   for (int u = 0; u < C::APW; ++u) {
     const int row = (wave + 8 * u) * 8 + (lane >> 3);
     const int sg = (lane & 7) ^ ((row >> 1) & 7);
-    srcA[u] = reinterpret_cast<const char*>(A + (int64_t)min(m0 + row, p.M - 1) * p.lda + sg * 8);
+    offA[u] = (uint32_t)(((int64_t)(min(m0 + row, p.M - 1) - m0) * p.lda + sg * 8) * 2);
   }
 #pragma unroll
   for (int u = 0; u < C::BPW; ++u) {
@@ -73,15 +73,21 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_n
     if constexpr (C::BK) {
       const int row = g * 8 + (lane >> 3);
       const int sg = (lane & 7) ^ ((row >> 1) & 7);
-      srcB[u] = reinterpret_cast<const char*>(B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + sg * 8);
+      offB[u] = (uint32_t)(((int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldb + sg * 8) * 2);
     } else {
       constexpr int NQ = C::BN / 64;
       const int kb = g / NQ, nq = g % NQ, kr = lane >> 3;
       const int cg = (lane & 7) ^ (((kr >> 1) & 1) << 2);
-      const int col = min(n0 + nq * 64 + cg * 8, p.N - 8);
-      srcB[u] = reinterpret_cast<const char*>(B + (int64_t)(kb * 8 + kr) * p.ldb + col);
+      offB[u] = (uint32_t)(((int64_t)(kb * 8 + kr) * p.ldb + (min(n0 + nq * 64 + cg * 8, p.N - 8) - n0)) * 2);
     }
   }
+  auto uniform_ptr = [](const void* q) -> const char* {
+    const uint64_t v = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  const char* bA = uniform_ptr(A + (int64_t)m0 * p.lda);
+  const char* bB = uniform_ptr(C::BK ? B + (int64_t)n0 * p.ldb : B + n0);
   const int64_t stepB = C::BK ? 128 : (int64_t)64 * p.ldb * 2;
   const uint32_t lds0 = lds_addr(smem);
   // The pieces of a k-tile are issued in four groups, one between the MFMA clusters of each k-step: a wave that issues
@@ -93,9 +99,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_n
 #pragma unroll
     for (int u = 0; u < C::PPW; ++u) {
       if (u * 4 / C::PPW != G) continue;
-      if (u < C::APW) { lds_dma_1k<0>(srcA[u], dbase + u * 8192); srcA[u] += 128; }
-      else { lds_dma_1k<0>(srcB[u - C::APW], dbase + C::A_BYTES + (u - C::APW) * 8192); srcB[u - C::APW] += stepB; }
+      if (u < C::APW) lds_dma_1k_s<0>(offA[u], bA, dbase + u * 8192);
+      else lds_dma_1k_s<0>(offB[u - C::APW], bB, dbase + C::A_BYTES + (u - C::APW) * 8192);
     }
+    if constexpr (G == 3) { bA += 128; bB += stepB; }      // the k-tile is complete: the bases move on
   };
   auto issue = [&](int stage) {
     dbase = __builtin_amdgcn_readfirstlane(lds0 + stage * C::STAGE + wave * 1024);
