@@ -614,6 +614,17 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
     }
   };
   auto advance = [&]() { bA += stepA; bB += stepB; };
+  // one quarter of the next k-tile's pieces (A piece q, B piece q): issued BETWEEN the MFMA steps of the current k-tile, not as
+  // a block of eight in front of its first fragment reads (each issue holds the wave for 60+ cycles while MFMAs run)
+  bool nxt_on = false;
+  uint32_t nxt_d = 0;
+  auto issue_q = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if (nxt_on) {
+      lds_dma_1k_s<0>(oa[q], bA, nxt_d + q * 1024);
+      lds_dma_1k_s<0>(ob[q], bB, nxt_d + TILE_BYTES + q * 1024);
+    }
+  };
 
   // LDS byte addresses of the fragments inside stage 0 (the stage and the second 32-row block are immediates):
   //   k-major : one address per k-step (the XOR swizzle depends on ks), second row block = +4096
@@ -700,14 +711,18 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
   {                                      \
     PENEO_READ_STEP(0, 0, BUFOFF_)       \
     PENEO_READ_STEP(1, 1, BUFOFF_)       \
+    issue_q(std::integral_constant<int, 0>{}); \
     PENEO_WAIT_NEWER()                   \
     PENEO_MMA_STEP(0)                    \
     PENEO_READ_STEP(0, 2, BUFOFF_)       \
+    issue_q(std::integral_constant<int, 1>{}); \
     PENEO_WAIT_NEWER()                   \
     PENEO_MMA_STEP(1)                    \
     PENEO_READ_STEP(1, 3, BUFOFF_)       \
+    issue_q(std::integral_constant<int, 2>{}); \
     PENEO_WAIT_NEWER()                   \
     PENEO_MMA_STEP(0)                    \
+    issue_q(std::integral_constant<int, 3>{}); \
     PENEO_LGKM(0)                        \
     PENEO_MMA_STEP(1)                    \
   }
@@ -720,20 +735,22 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
   wait_vm<0>();
   __syncthreads();
   for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    nxt_on = false;
     if (kt + 1 < kt_end) {
       by_pointer = ragged_k && kt + 1 == ktiles - 1;
-      if (by_pointer) sources(kt + 1); else advance();
-      issue(1);
+      if (by_pointer) { sources(kt + 1); issue(1); }
+      else { advance(); nxt_on = true; nxt_d = lbase + STAGE; }
     }
     if constexpr (CS) cs_now = cs_on && (kt % cs_mod) == cs_col;
     PENEO_KTILE(0)
     wait_vm<0>();
     __syncthreads();
     if (kt + 1 < kt_end) {
+      nxt_on = false;
       if (kt + 2 < kt_end) {
         by_pointer = ragged_k && kt + 2 == ktiles - 1;
-        if (by_pointer) sources(kt + 2); else advance();
-        issue(0);
+        if (by_pointer) { sources(kt + 2); issue(0); }
+        else { advance(); nxt_on = true; nxt_d = lbase; }
       }
       if constexpr (CS) cs_now = cs_on && ((kt + 1) % cs_mod) == cs_col;
       PENEO_KTILE(32768)
