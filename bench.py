@@ -339,7 +339,8 @@ def main():
                     "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
                     "avg_launch_ms": round(ph_ms, 4), "launches": len(ph)}
         if pb_ms > 0:
-            dom_roof = {"bound": "mfma", "kernel": f"pair_bwd_ws_kernel<{pcfg['backbone_config']['hidden_size'] // 32}> (+ pair_bwd_reduce_kernel)",
+            ks = pcfg['backbone_config']['hidden_size'] // 32       # D / 16: 24 -> the wave-specialised kernel, 32 -> the one-wave kernel
+            dom_roof = {"bound": "mfma", "kernel": f"pair_bwd_{'one' if ks == 32 else 'ws'}_kernel<{ks}> (+ pair_bwd_reduce_kernel)",
                         "achieved": round(pb_achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(pb_achieved / PEAK_BF16_TFLOPS, 4),
                         "traffic": pmc_traffic_bytes("pair_bwd_fused_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,

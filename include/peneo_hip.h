@@ -391,7 +391,7 @@ int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int
                         void* x_out /* optional [npairs, D]: what peneo_pair_x_fwd would write */,
                         void* pre_out /* given together with x_out */, peneo_stream_t stream);
 
-/* Decoder backward through the pair space in ONE kernel (bf16; D / 16 in {2, 4, 8, 24}): for all pairs (i, j), i <= j, of
+/* Decoder backward through the pair space in ONE kernel (bf16; D / 16 in {2, 4, 8, 24, 32}): for all pairs (i, j), i <= j, of
  * all B documents it rebuilds x = SiLU(a_i + b_j) in registers, computes z = x W1cat^T + b1 and dz (as peneo_pair_dz_fused),
  * du = dz W1cat on the matrix cores with the accumulator kept in registers over all hidden units, and
  *   d_ab[b, i, :D] = sum_j du * SiLU'(a_i + b_j),  d_ab[b, j, D:] = sum_i du * SiLU'(a_i + b_j)   (fp32, overwritten; per-block

@@ -859,6 +859,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 // Every operand that needs the reduction index strided comes from the hardware transpose read ds_read_b64_tr_b16 on
 // the plain row-major tiles, so no transposed copies of Q / K / dO are made.
 // ================================================================================================
+#ifdef ATTN_PROF
+// tools/attn_cycles.py: per-phase s_memtime ticks of the single-pass backward, summed over all waves (a -DATTN_PROF build only)
+__device__ unsigned long long g_attn_prof[16];
+#define AP_DECL unsigned long long ap_t = __builtin_amdgcn_s_memtime(), ap_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ap_t0 = ap_t;
+#define AP_MARK(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ap_acc[i] += n_ - ap_t; ap_t = n_; }
+#define AP_FLUSH { if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 10; ++i) atomicAdd(&g_attn_prof[i], ap_acc[i]); atomicAdd(&g_attn_prof[10], __builtin_amdgcn_s_memtime() - ap_t0); atomicAdd(&g_attn_prof[11], 1ull); } }
+#else
+#define AP_DECL
+#define AP_MARK(i)
+#define AP_FLUSH
+#endif
 constexpr int FQ = 64;     // queries per step
 constexpr int FKEYS = 128; // keys per workgroup
 // bias tile [FQ queries][FKEYS keys] of bf16: 16-byte vector i of thread tid (4 per thread).  Kept as four named
@@ -953,9 +964,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
     }                                                                                    \
   }
   FUSED_PREFETCH(0)
+  AP_DECL
   for (int t = 0; t < ntile; ++t) {
     const int q0 = t * FQ;
+    AP_MARK(9)
     __syncthreads();
+    AP_MARK(0)
     tile_store<T, FQ, DP>(rq, sQ, tid);
     tile_store<T, FQ, DP>(rdo, sdO, tid);
     if (tid < FQ) {
@@ -971,8 +985,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
       fused_bias_store<PB>(rb2, sB, tid, 2);
       fused_bias_store<PB>(rb3, sB, tid, 3);
     }
+    AP_MARK(1)
     __syncthreads();
+    AP_MARK(2)
     FUSED_PREFETCH(t + 1 < ntile ? t + 1 : t)
+    AP_MARK(3)
 
     float* Gt = G ? G + (int64_t)q0 * p.bias_ld + key0 : nullptr;   // uniform tile base; lanes add 32-bit offsets
     // a query block that lies entirely past T (T = 709: the second half of the twelfth tile) contributes nothing: skipped
@@ -991,6 +1008,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
         Frag<T> a2 = FragReader<T, DP>::straight(sdO, qt * 32 + (lane & 31), 16 * ks + 8 * half);
         mma_step(a2, vf[ks], dp);
       }
+      AP_MARK(4)
       f32x16_t pr;
       const uint32_t cw = qt ? cw1 : cw0;
 #pragma unroll
@@ -1032,6 +1050,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
         *reinterpret_cast<uint2*>(sS + keyl * PS + qb * 2) = make_uint2(pack_bf16x2(ds4[0], ds4[1]), pack_bf16x2(ds4[2], ds4[3]));
         __builtin_amdgcn_sched_barrier(0);   // one group's loads and temporaries at a time (register pressure)
       }
+      AP_MARK(5)
       // dV^T[d, key] += dO^T[d, q] . P[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -1048,13 +1067,16 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
           mma_step(qtf, dsf, dk[t2]);
         }
       }
+      AP_MARK(6)
     }
     if (nqt == 1 && half == 0) {   // the skipped query block: its dS^T columns are zero (the padding columns of the slab stay 0)
       const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sS + keyl * PS + 64 + 16 * i) = z4;
     }
+    AP_MARK(9)
     __syncthreads();   // dS^T tile complete
+    AP_MARK(7)
     if (p.ds_out) {    // this layer's dS^T rows (key-major, 128 B per key and step): the bias-table gradient is reduced from
                        // the per-layer bf16 copies once per step (peneo_relpos_bias_bwd_layers) instead of a fp32 RMW per layer
       T* dsg = reinterpret_cast<T*>(p.ds_out) + (((int64_t)b * p.nh + h) * Tn + key0) * (int64_t)Tp + q0;
@@ -1066,6 +1088,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
           *reinterpret_cast<uint4*>(dsg + (int64_t)kr * Tp + ch * 8) = *reinterpret_cast<const uint4*>(sS + kr * PS + ch * 16);
       }
     }
+    AP_MARK(8)
     // dQ[q, dcol] += dS[q, keys] . K[keys, dcol]: 2 x DT output tiles of 32 x 32 over the 4 waves
     for (int tile = wave; tile < 2 * DT && dq_acc != nullptr; tile += 4) {   // (no accumulator: dQ comes from the stored dS^T)
       const int qt = tile / DT, dt = tile % DT;
@@ -1091,6 +1114,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnParams p, 
     }
   }
 #undef FUSED_PREFETCH
+  AP_FLUSH
 
   __syncthreads();
   float* myO = reinterpret_cast<float*>(smem) + wave * 32 * (DP + 1);
@@ -1358,6 +1382,13 @@ static int dispatch(const AttnParams& p, bool bwd, hipStream_t st, float* dq_acc
 }  // namespace peneo
 using namespace peneo;
 
+#ifdef ATTN_PROF
+extern "C" int peneo_attn_prof_read(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 extern "C" int peneo_attn_padded_len(int T) { return (T + 63) / 64 * 64; }
 extern "C" int peneo_attn_padded_dim(int d) { return (d + 31) / 32 * 32; }
 

@@ -657,6 +657,504 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   }
 }
 
+// ================================================================================================
+// One-wave form (D = 512, KS = 32): the du tile of a wave's 32 pairs is 32 x 512 fp32 = 256 accumulator registers, a wave's
+// whole share of a SIMD's register file at two waves per SIMD.  Here ONE wave per SIMD (four per workgroup, 512 registers
+// each) does both roles: du lives in the 256 AGPRs (its MFMAs are inline asm with "+a" operands: the compiler would
+// otherwise pick the register class of every MFMA of the kernel at once; this file is built with -amdgpu-mfma-vgpr-form so
+// that the builtin MFMAs - z, dy, the dW2 sums - keep VGPR results the VALU can read), x / z / everything else in the 256
+// VGPRs.  Per slab s:   Z(s): 32 MFMAs into z (pure matrix phase, operand reads three chunks deep),
+//                       E(s) (VALU: dz from z) interleaved with U(s-1) (du += dz(s-1) W1, the matrix cores): the VALU work of
+//                       one slab hides behind the MFMAs of the previous slab's du product,
+// same data layout, weight packing, LDS tiles and dropout stream as the wave-specialised kernel above (its rows, partial
+// sums and workspace are interchangeable).  The weight ring has three slots (slab s+1 lands while Z(s) / U(s-1) read).
+// ================================================================================================
+template <int N, int I = 0, typename F> __device__ __forceinline__ void pb_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); pb_static_for<N, I + 1>(f); }
+}
+typedef __attribute__((ext_vector_type(2))) unsigned int pb_u32x2;
+template <int OFF> __device__ __forceinline__ void pb_trd(pb_u32x2& d, uint32_t a) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void pb_dsw16(uint32_t a, uint32_t v) {
+  asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
+}
+constexpr int pb_uoff(int f) { return (f >> 1) * 2048 + (f & 1) * 256; }
+constexpr int pb_mask_steps(int nz, int j) { return j * 16 / nz; }   // mask steps done before chunk j of nz
+// registers an inline-asm read fills are pinned behind the wait that covers it
+template <int C, typename V> __device__ __forceinline__ void pb_pin(V (&d)[C]) {
+#pragma unroll
+  for (int i = 0; i < C; ++i) asm volatile("" : "+v"(d[i]));
+}
+__device__ __forceinline__ void pb_lgkm0(pb_u32x4& a, pb_u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) :: "memory"); }
+__device__ __forceinline__ void pb_mma_acc(const pb_u32x4& a, const pb_u32x4& b, f32x16_t& acc) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <int KS, bool DROP>
+__global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdParams p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF_BYTES = KS * 1024;
+  constexpr int NDT = KS / 2;
+  static_assert(KS == 32, "one-wave form: built and scheduled for D = 512 (16 Z chunks, 16 U sub-chunks, 16 mask steps)");
+  constexpr int PPW = KS / PB_WAVES;                         // 1 KiB weight pieces per wave and slab
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave;
+  const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
+  char* sA = smem;                                                          // [3][HALF_BYTES] weight ring: slab s in slot s % 3
+  uint2* sW2p = reinterpret_cast<uint2*>(smem + 3 * HALF_BYTES);            // [ncol]
+  float* sB1 = reinterpret_cast<float*>(sW2p + ncol);                       // [ncol]
+  float4* sG = reinterpret_cast<float4*>(sB1 + ncol);                       // [4][32]
+  float4* sPart = sG + 4 * 32;                                              // [2][4][32]
+  char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
+  _Float16* sMask = reinterpret_cast<_Float16*>(sT + 2 * 4 * 2048);         // [4 groups][32 units][2 halves][16 registers]
+
+  int ti = 0;
+  {
+    const int nti = pb_row_tiles(N);
+    while (ti + 1 < nti && pb_tiles_before(ti + 1, N) <= (int)blockIdx.x) ++ti;
+  }
+  const int tj = (ti >> 1) + ((int)blockIdx.x - pb_tiles_before(ti, N));
+  const int b = blockIdx.y;
+  const int i0 = ti * PB_TI + 2 * grp, j0 = tj * PB_TJ;
+  const int pi = i0 + (r32 >> 4), pj = j0 + (r32 & 15);
+  const bool pair_ok = pi < N && pj < N && pi <= pj;
+  const int ci = min(pi, N - 1), cj = min(pj, N - 1);
+  const int64_t mypair = pair_row_start(ci, N) + (cj - ci);
+  const int64_t rows_per_doc = (int64_t)p.ntiles * PB_ROWS;
+  const int64_t row = (int64_t)b * rows_per_doc + (int64_t)blockIdx.x * PB_ROWS + grp * 32 + r32;
+  const int nslab = ncol / 32, spb = D / 32;
+  const T* abd = p.ab + (int64_t)b * N * 2 * D;
+
+  for (int n = tid; n < ncol; n += PB_WAVES * 64) {
+    const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
+    const float ds = DROP ? p.drop_scale : 1.f;
+    sW2p[n] = make_uint2(pack_bf16x2(ds * p.a.w2[h][k], Cn > 1 ? ds * p.a.w2[h][(int64_t)D + k] : 0.f),
+                         pack_bf16x2(Cn > 2 ? ds * p.a.w2[h][(int64_t)2 * D + k] : 0.f, 0.f));
+    sB1[n] = p.b1[n];
+  }
+
+  const char* wbase = reinterpret_cast<const char*>(p.wp) + lane * 16;
+  const uint32_t ring = lds_addr(sA);
+  auto dma_slab = [&](int slab) {       // wave w carries pieces w, w + 4, ...
+    const int slot = slab % 3;
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+      const int q = wave + k * PB_WAVES;
+      lds_dma_1k<0>(wbase + (int64_t)slab * (3 * HALF_BYTES) + 2 * HALF_BYTES + q * 1024, __builtin_amdgcn_readfirstlane(ring + slot * HALF_BYTES + q * 1024));
+    }
+  };
+  dma_slab(0);
+
+  struct f2 {
+    float x, y;
+    __device__ f2 operator+(const f2& o) const { return f2{x + o.x, y + o.y}; }
+    __device__ f2 operator*(const f2& o) const { return f2{x * o.x, y * o.y}; }
+  };
+  auto fma2 = [](const f2& a, const f2& b, const f2& c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; };
+
+  // ---- x = SiLU(a_i + b_j): operand fragments of z, and what the dW1 GEMM reads ----
+  Frag<T> xf[KS];
+  {
+    const T* arow = abd + (int64_t)ci * 2 * D;
+    const T* brow = abd + (int64_t)cj * 2 * D + D;
+    T* x_row = p.x + row * D + 8 * half;
+    constexpr int G = 4;
+    uint4 ra[2][G], rb[2][G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
+      rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
+    }
+#pragma unroll
+    for (int g = 0; g < KS / G; ++g) {
+      if (g + 1 < KS / G) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (G * (g + 1) + i) + 8 * half);
+          rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (G * (g + 1) + i) + 8 * half);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        float a[8], bb[8];
+        unpack16<T>(ra[g & 1][i], a);
+        unpack16<T>(rb[g & 1][i], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+        xf[G * g + i] = pack_frag8<T>(a);
+        asm volatile("" : "+v"(xf[G * g + i].v.x), "+v"(xf[G * g + i].v.y), "+v"(xf[G * g + i].v.z), "+v"(xf[G * g + i].v.w) :: "memory");
+        *reinterpret_cast<uint4*>(x_row + 16 * (G * g + i)) = xf[G * g + i].v;
+      }
+    }
+  }
+
+  f32x16_t du[NDT];
+#pragma unroll
+  for (int t = 0; t < NDT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
+    asm volatile("" : "+a"(du[t]));
+  }
+
+  float* slot_ws = p.ws + (int64_t)(blockIdx.x % PB_SLOTS) * 4 * ncol;
+  auto flush = [&](int s) {
+    if (wave == (s & 3) && lane < 32) {
+      const float4* src = sPart + (s & 1) * (4 * 32) + lane;
+      float4 t = src[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const float4 u = src[w * 32]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      float* dst = slot_ws + s * 32 + lane;
+      atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
+    }
+  };
+  // operands built per head from scale_h * dlogits_h of the wave's 32 pairs (see the wave-specialised kernel)
+  pb_u32x4 gA = pb_u32x4{0u, 0u, 0u, 0u};
+  float* const gt = reinterpret_cast<float*>(sG + grp * 32);       // [3][32] floats: g_c of the wave's pairs (this head)
+  auto stage_g = [&](int h) {
+    const int Cn = p.a.classes[h];
+    float gx = 0.f, gy = 0.f, gz = 0.f, sc = 0.f;
+    if (lane < 32 && pair_ok) {
+      sc = p.a.scale[h];
+      const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
+      gx = dl[0];
+      if (Cn > 1) gy = dl[1];
+      if (Cn > 2) gz = dl[2];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx), "+v"(gy), "+v"(gz), "+v"(sc) :: "memory");
+    gx *= sc; gy *= sc; gz *= sc;
+    gA = pb_u32x4{pack_bf16x2(gx, gy), pack_bf16x2(gz, 0.f), 0u, 0u};
+    if (lane < 32) { gt[lane] = gx; gt[32 + lane] = gy; gt[64 + lane] = gz; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto build_gT = [&](pb_u32x4& gT0, pb_u32x4& gT1) {
+    const int c = r32;
+    float v[16];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int e4 = 0; e4 < 2; ++e4) {
+        const float4 q = c < 3 ? *reinterpret_cast<const float4*>(gt + c * 32 + 16 * kk + 8 * e4 + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[8 * kk + 4 * e4 + 0] = q.x; v[8 * kk + 4 * e4 + 1] = q.y; v[8 * kk + 4 * e4 + 2] = q.z; v[8 * kk + 4 * e4 + 3] = q.w;
+      }
+    gT0 = pb_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    gT1 = pb_u32x4{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+  };
+  const f2 nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
+  const bool odd = (lane & 1) != 0;
+  const int t_swz = (r32 >> 2) & 3;
+  T* dz_row = p.dz + row * ncol + 8 * half;
+  const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
+  const uint32_t drop_base = (uint32_t)(mypair * nslab * 2) + (uint32_t)half;
+  const int mreg = (r32 & 3) + 4 * (r32 >> 3), mhp = (r32 >> 2) & 1;
+
+  // tools/pb_cycles.py (a -DPB_PROF build, debug buffer set): ticks per phase, summed over the iterations: 0 wait + barrier at the top, 1 weight
+  // stream issue / column-sum flush / dlogits staging, 2 Z, 3 E | U, 4 dW2 sums.  A mark drains the LDS queue.
+#ifdef PB_PROF
+  unsigned long long t_ph[5] = {0, 0, 0, 0, 0}, t_last = 0;
+  auto mark = [&](int k) {
+    if (p.dbg) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (k >= 0) t_ph[k] += t - t_last;
+      t_last = t;
+    }
+  };
+#else
+  auto mark = [](int) {};
+#endif
+  auto top = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mark(0);
+  };
+
+  // one iteration: Z(s) (DOZ), then E(s) (DOZ) interleaved with U(s - 1) (DOU)
+  auto iteration = [&](auto z_c, auto u_c, int s) {
+    constexpr bool DOZ = decltype(z_c)::value, DOU = decltype(u_c)::value;
+    f32x16_t z, dy;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    uint2 cw2 = make_uint2(0u, 0u);
+    float cb1 = 0.f;
+    if constexpr (DOZ) {
+      if (s % spb == 0) stage_g(s / spb);
+      cw2 = sW2p[s * 32 + r32]; cb1 = sB1[s * 32 + r32];
+      // (the compiler's own wait for these two belongs HERE: it cannot see the hand-issued reads below and would drain the
+      // LDS queue at their first use, in the middle of the interleaved phase)
+      asm volatile("" : "+v"(cw2.x), "+v"(cw2.y), "+v"(cb1));
+      mark(1);
+      // ---- Z(s): pure matrix phase; a chunk's fragments are requested two chunks ahead, into the set read three chunks ago
+      const uint32_t zs = ring + (s % 3) * HALF_BYTES + half * 512;
+      const uint32_t za0 = zs + ((r32 ^ (4 * half)) << 4), za1 = zs + ((r32 ^ (4 * half + 8)) << 4);
+      // chunks of two fragments, requested three chunks ahead into the set read four chunks ago
+      constexpr int NZ = KS / 2;
+      pb_u32x4 fs[4][2];
+      f32x16_t zb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zb[r] = 0.f;
+      auto zissue = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        pb_dsr<(2 * J) * 1024>(fs[J & 3][0], za0);
+        pb_dsr<(2 * J + 1) * 1024>(fs[J & 3][1], za1);
+      };
+      // K12 dropout: the keep / drop addends of this slab are made under the matrix phase.  Lane = (pair r32, half) walks the
+      // forward's chain of 16 fields (units 8g + 4 half + e) and leaves one f16 per unit where the lane that owns (unit, half
+      // of the pair's register) reads its 16 registers; chunk J takes steps 16 J / NZ .. 16 (J + 1) / NZ - 1
+      const uint32_t mwa = lds_addr(sMask + ((grp * 32 * 2 + mhp) * 16) + mreg) + half * (4 * 32 * 2);
+      uint32_t mst = DROP ? pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)s) : 0u;
+      auto zchunk = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if constexpr (J + 3 < NZ) zissue(std::integral_constant<int, J + 3>{});
+        if constexpr (DROP) {
+          pb_static_for<pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J)>([&](auto ic) {
+            constexpr int I = pb_mask_steps(NZ, J) + decltype(ic)::value;
+            mst = pair_drop_step(mst);
+            const uint32_t v = (mst >> 16) >= p.drop_thr16 ? 0u : 0xF753u;   // f16 0 / -30000
+            pb_dsw16<(8 * (I >> 2) + (I & 3)) * 32 * 2>(mwa, v);
+          });
+        }
+        // the fragments of chunk J: everything but the (at most) three younger chunks and the mask stores behind them has landed
+        constexpr int younger = (NZ - 1 - J) < 3 ? (NZ - 1 - J) : 3;
+        constexpr int ywr = DROP ? pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J >= 3 ? J - 3 : 0) : 0;
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(2 * younger + ywr) : "memory");
+        pb_pin<2>(fs[J & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        // two accumulators: a dependent MFMA does not start before its predecessor has written back
+        pb_mma(xf[2 * J], fs[J & 3][0], z);
+        pb_mma(xf[2 * J + 1], fs[J & 3][1], zb);
+        // anchor: the builtin MFMAs carry no ordering of their own against the hand-issued reads around them (instruction
+        // selection would sink the whole chain behind the last wait); an empty volatile statement on their result does
+        asm volatile("" : "+v"(z), "+v"(zb));
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the counted waits below count only the fragment reads
+      zissue(std::integral_constant<int, 0>{});
+      zissue(std::integral_constant<int, 1>{});
+      zissue(std::integral_constant<int, 2>{});
+      pb_static_for<NZ>([&](auto jc) { zchunk(jc); });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { z[r] += zb[r]; dy[r] = 0.f; }
+      const pb_u32x4 w2f = pb_u32x4{half ? 0u : cw2.x, half ? 0u : cw2.y, 0u, 0u};
+      pb_mma(gA, w2f, dy);
+      mark(2);
+    }
+    const f2 b1 = f2{cb1, cb1};
+    char* myT = sT + ((s & 1) * 4 + grp) * 2048;
+    float sbx = 0.f, sby = 0.f;
+    uint32_t yp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) yp[i] = 0u;
+    // K12 dropout: the f16 addends (0 / -30000) of accumulator registers 2J, 2J + 1 = dword J of this lane's 16, read one
+    // chunk ahead
+    const uint32_t mka = lds_addr(sMask + ((grp * 32 + r32) * 2 + half) * 16);
+    uint32_t mk[2] = {0u, 0u};
+    constexpr bool MK = DOZ && DROP;
+
+    // ---- U(s - 1): A operand = the dz tile of slab s - 1 (written by this wave during the previous iteration), B operand =
+    // that slab's z fragments read transposed (see the consumer waves of the wave-specialised kernel).  Sub-chunk q = the two
+    // fragments of du tile q; two register sets: the reads of sub-chunk q + 2 go out right behind the MFMAs of sub-chunk q.
+    // LDS operations complete in order, so the waits count what may still be in flight (reads: 4 per sub-chunk, the mask
+    // dword, the dz tile store of the E part).
+    pb_u32x4 a0 = pb_u32x4{0u, 0u, 0u, 0u}, a1 = a0;
+    pb_u32x2 ul[2][2], uh[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ul[0][i] = pb_u32x2{0u, 0u}; ul[1][i] = ul[0][i]; uh[0][i] = ul[0][i]; uh[1][i] = ul[0][i]; }
+    uint32_t ua0 = 0u, ua1 = 0u;
+    auto uissue = [&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      // sub-chunk Q = the kk = Q & 1 fragments of du tiles 2 (Q >> 1), 2 (Q >> 1) + 1: its two MFMAs are independent
+      if constexpr (DOU && Q < NDT) {
+        constexpr int F0 = 4 * (Q >> 1) + (Q & 1);
+        pb_trd<pb_uoff(F0)>(ul[Q & 1][0], ua0); pb_trd<pb_uoff(F0)>(uh[Q & 1][0], ua1);
+        pb_trd<pb_uoff(F0 + 2)>(ul[Q & 1][1], ua0); pb_trd<pb_uoff(F0 + 2)>(uh[Q & 1][1], ua1);
+      }
+    };
+    auto umma = [&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      if constexpr (DOU) {
+        pb_pin<2>(ul[Q & 1]); pb_pin<2>(uh[Q & 1]);
+        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q & 1][0].x, ul[Q & 1][0].y, uh[Q & 1][0].x, uh[Q & 1][0].y}, du[2 * (Q >> 1)]);
+        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q & 1][1].x, ul[Q & 1][1].y, uh[Q & 1][1].x, uh[Q & 1][1].y}, du[2 * (Q >> 1) + 1]);
+      }
+    };
+    if constexpr (MK) asm volatile("ds_read_b32 %0, %1" : "=v"(mk[0]) : "v"(mka));
+    if constexpr (DOU) {
+      const int u = s - 1;
+      const uint32_t ta = lds_addr(sT + ((u & 1) * 4 + grp) * 2048) + r32 * 64;
+      const int g_ = lane >> 4, hh_ = g_ >> 1, rr_ = (lane & 15) >> 2, cc_ = lane & 3, h_ = cc_ >> 1;
+      const uint32_t ub = ring + (u % 3) * HALF_BYTES + (g_ & 1) * 1024 + ((h_ * 32 + 8 * (hh_ ^ (g_ & 1)) + rr_) << 4) + (cc_ & 1) * 8;
+      ua0 = ub + (h_ ? 64 : 0); ua1 = ub + (h_ ? 0 : 64);
+      pb_dsr<0>(a0, ta + (((0 + half) ^ t_swz) << 4));
+      pb_dsr<0>(a1, ta + (((2 + half) ^ t_swz) << 4));
+      uissue(std::integral_constant<int, 0>{});
+      uissue(std::integral_constant<int, 1>{});
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(mk[0]) :: "memory");   // all but sub-chunk 1
+      *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
+      *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[0]) :: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto chunk = [&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
+      const int row0 = rowc + 4 * half;
+      f2 zz = f2{0.f, 0.f}, sg = zz, y = zz, dzv = zz;
+      umma(std::integral_constant<int, 2 * J>{});
+      uissue(std::integral_constant<int, 2 * J + 2>{});
+      if constexpr (MK && J + 1 < 8) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(mk[(J + 1) & 1]) : "v"(mka), "n"(4 * (J + 1)));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DOZ) {
+        float zx = z[r0], zy = z[r0 + 1];
+        asm volatile("" : "+v"(zx), "+v"(zy));                 // anchor behind the MFMAs above
+        zz = f2{zx, zy} + b1;
+        if constexpr (DROP) {
+          asm volatile("v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                       "v_fma_mix_f32 %1, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                       : "+v"(zz.x), "+v"(zz.y) : "v"(mk[J & 1]));
+        }
+        const f2 t = zz * nl2e;
+        sg = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        sg = f2{__builtin_amdgcn_rcpf(sg.x + 1.f), __builtin_amdgcn_rcpf(sg.y + 1.f)};
+        y = zz * sg;
+        asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(sg.x), "+v"(sg.y));   // anchor in front of the next MFMAs
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DOU) {
+        // sub-chunk 2J + 1: younger = this chunk's reads of sub-chunk 2J + 2 and mask dword; the previous chunk's tile store
+        if constexpr (J + 1 < 8) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 + (DOZ ? 1 : 0) + (MK ? 1 : 0)) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      umma(std::integral_constant<int, 2 * J + 1>{});
+      uissue(std::integral_constant<int, 2 * J + 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DOZ) {
+        // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
+        dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
+        yp[J] = pack_bf16x2(y.x, y.y);
+        sbx += dzv.x; sby += dzv.y;
+        const float give = odd ? dzv.x : dzv.y;
+        const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
+        const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
+        const int trow = row0 + (lane & 1);
+        const int boff = (r32 & ~1) * 2;
+        const int f = ((rowc >> 2) + half) & 3;
+        *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (J + 1 < 8) {
+        // sub-chunk 2J + 2 and the next mask dword: younger = the reads of sub-chunk 2J + 3 and this chunk's tile store
+        if constexpr (DOU) asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(mk[(J + 1) & 1]) : [n] "n"(4 + (DOZ ? 1 : 0)) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[(J + 1) & 1]) :: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    pb_static_for<8>([&](auto jc) { chunk(jc); });
+    mark(3);
+    if constexpr (DOZ) {
+      // dW2 sums out[c, hid] = sum_pair g[pair, c] y[pair, hid] (y straight from its accumulator-layout registers; the A
+      // operand, the head's g transposed, is rebuilt from the wave's staging rows: 8 registers less across the loop) and db1
+      pb_u32x4 gT0, gT1;
+      build_gT(gT0, gT1);
+      f32x16_t acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      pb_mma(gT0, pb_u32x4{yp[0], yp[1], yp[2], yp[3]}, acc);
+      pb_mma(gT1, pb_u32x4{yp[4], yp[5], yp[6], yp[7]}, acc);
+      float sbt = sbx + sby;
+      sbt += __shfl_xor(sbt, 32);
+      const float ys = DROP ? p.drop_scale : 1.f;
+      if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = make_float4(acc[0] * ys, acc[1] * ys, acc[2] * ys, sbt);
+      mark(4);
+    }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  __syncthreads();                                            // sW2p / sB1 visible
+  mark(-1);
+#ifdef PB_PROF
+  const unsigned long long t_begin = t_last;
+#endif
+  top();                                                      // slab 0 has landed
+  if (nslab > 1) dma_slab(1);
+  iteration(yes{}, no{}, 0);
+  for (int s = 1; s < nslab; ++s) {
+    top();
+    if (s + 1 < nslab) dma_slab(s + 1);
+    flush(s - 1);
+    iteration(yes{}, yes{}, s);
+  }
+  top();
+  flush(nslab - 1);
+  iteration(no{}, yes{}, nslab);
+#ifdef PB_PROF
+  if (p.dbg && blockIdx.y == 0 && blockIdx.x < 256 && lane == 0) {
+    unsigned long long* d = p.dbg + ((int64_t)blockIdx.x * PB_WAVES + wave) * 8;
+    d[0] = t_last - t_begin;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[1 + k] = t_ph[k];
+  }
+#endif
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last du MFMAs (inline asm: unknown to the compiler's hazard pass)
+  __syncthreads();                                            // every wave is done with the rings
+  // ---- du * SiLU'(a_i + b_j): sums over j stay in the wave, sums over i meet in LDS (everything above is dead) ----
+  float* red = reinterpret_cast<float*>(smem);                // [4][NDT][16][32]
+  const int ia = min(i0, N - 1), ib = min(i0 + 1, N - 1);
+  float* pa = p.part_a + (((int64_t)b * p.ntiles + blockIdx.x) * PB_TI + 2 * grp + half) * D;
+#pragma unroll
+  for (int t = 0; t < NDT; ++t) {
+    const int d = 32 * t + r32;
+    const float a_lo = bf16_to_f32(abd[(int64_t)ia * 2 * D + d]), a_hi = bf16_to_f32(abd[(int64_t)ib * 2 * D + d]);
+    float bj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = min(j0 + 8 * (q >> 2) + 4 * half + (q & 3), N - 1);
+      bj[q] = bf16_to_f32(abd[(int64_t)j * 2 * D + D + d]);
+    }
+    float sa0 = 0.f, sa1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v0 = du[t][q] * silu_grad_f(a_lo + bj[q]);
+      const float v1 = du[t][8 + q] * silu_grad_f(a_hi + bj[q]);
+      sa0 += v0; sa1 += v1;
+      red[((grp * NDT + t) * 16 + 8 * (q >> 2) + 4 * half + (q & 3)) * 32 + r32] = v0 + v1;
+    }
+    sa0 += __shfl_xor(sa0, 32);
+    sa1 += __shfl_xor(sa1, 32);
+    pa[d] = half ? sa1 : sa0;
+  }
+  __syncthreads();
+  float* pb = p.part_b + ((int64_t)b * p.ntiles + blockIdx.x) * PB_TJ * D;
+  for (int e = tid; e < NDT * 16 * 32; e += PB_WAVES * 64) {
+    const int c = e & 31, jl = (e >> 5) & 15, t = e >> 9;
+    float v = red[e];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += red[w * NDT * 512 + e];
+    pb[(int64_t)jl * D + 32 * t + c] = v;
+  }
+}
+
+template <int KS, bool DROP>
+static int launch_pair_bwd_one(const PairBwdParams& p, hipStream_t st) {
+  const int ncol = p.a.num_heads * p.D;
+  size_t sh = (size_t)3 * KS * 1024 + (size_t)ncol * 12 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)4 * 32 * 32 * 2;
+  const size_t red = (size_t)4 * (KS / 2) * 16 * 32 * sizeof(float);
+  if (sh < red) sh = red;
+  if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_one_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_error("peneo_pair_bwd_fused: cannot raise dynamic LDS to %zu bytes", sh);
+    return PENEO_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((pair_bwd_one_kernel<KS, DROP>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PB_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_bwd_fused");
+}
+
 template <int KS, bool DROP>
 static int launch_pair_bwd_ws(const PairBwdParams& p, hipStream_t st) {
   const int ncol = p.a.num_heads * p.D;
@@ -675,6 +1173,10 @@ template <int KS>
 static int launch_pair_bwd(const PairBwdParams& p, hipStream_t st) {
   return p.drop_thr16 ? launch_pair_bwd_ws<KS, true>(p, st) : launch_pair_bwd_ws<KS, false>(p, st);
 }
+template <int KS>
+static int launch_pair_bwd_1w(const PairBwdParams& p, hipStream_t st) {
+  return p.drop_thr16 ? launch_pair_bwd_one<KS, true>(p, st) : launch_pair_bwd_one<KS, false>(p, st);
+}
 
 }  // namespace peneo
 using namespace peneo;
@@ -686,7 +1188,7 @@ extern "C" void peneo_pair_bwd_debug_buffer(unsigned long long* dev) { g_pb_dbg 
 
 extern "C" int peneo_pair_bwd_supported(int dtype, int D) {
   const int ks = D / 16;
-  return dtype == PENEO_BF16 && D % 32 == 0 && (ks == 2 || ks == 4 || ks == 8 || ks == 24);
+  return dtype == PENEO_BF16 && D % 32 == 0 && (ks == 2 || ks == 4 || ks == 8 || ks == 24 || ks == 32);
 }
 
 extern "C" int64_t peneo_pair_bwd_rows(int N) { return N > 0 ? (int64_t)pb_num_tiles(N) * PB_ROWS : 0; }
@@ -709,7 +1211,7 @@ extern "C" size_t peneo_pair_bwd_partial_bytes(int B, int N, int D) {
 extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int D, const void* w_packed, const float* b1,
                                     const peneo_pair_dz_args* args, void* dz, void* x, float* d_ab, float* workspace,
                                     float* partials, peneo_stream_t stream) {
-  PENEO_REQUIRE(peneo_pair_bwd_supported(dtype, D), "peneo_pair_bwd_fused: bf16 and D/16 in {2, 4, 8, 24} only (got D=%d)", D);
+  PENEO_REQUIRE(peneo_pair_bwd_supported(dtype, D), "peneo_pair_bwd_fused: bf16 and D/16 in {2, 4, 8, 24, 32} only (got D=%d)", D);
   PENEO_REQUIRE(ab && w_packed && b1 && args && dz && x && d_ab && workspace && partials && B > 0 && N > 0, "peneo_pair_bwd_fused: bad arguments");
   PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D == D && args->scale, "peneo_pair_bwd_fused: bad head description");
   PENEO_REQUIRE(args->num_heads * D >= 64, "peneo_pair_bwd_fused: needs at least two 32-unit slabs of hidden units");
@@ -733,6 +1235,7 @@ extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int
     case 4: rc = launch_pair_bwd<4>(p, st); break;
     case 8: rc = launch_pair_bwd<8>(p, st); break;
     case 24: rc = launch_pair_bwd<24>(p, st); break;
+    case 32: rc = launch_pair_bwd_1w<32>(p, st); break;
   }
   if (rc != PENEO_OK) return rc;
   hipLaunchKernelGGL(pair_bwd_reduce_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, st, p.part_a, p.part_b, N, D, p.ntiles, d_ab);

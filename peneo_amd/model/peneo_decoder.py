@@ -319,8 +319,12 @@ class _DecoderStage(torch.autograd.Function):
                     # 18.79 / 18.34 / 18.16 / 18.10 ms per step on one box).
                     # Only when the join can wait for the end of the backward (fresh .grad tensors, no DDP hooks reading them).
                     can_hold = dec.dw1_hold and can_defer(params)
+                    # (D = 512: 80 tiles, i.e. ONE workgroup per tile from that target, would run 23 ms - longer than the 24-layer
+                    # encoder backward it hides behind; no workgroup gets more than dw1_side_rows rows of K: split 2 / 3 / 4 / 6 at
+                    # config 4: 30.5 / 31.1 / 32.8 / 32.7 ms per step)
                     split = None if not can_hold else \
-                        dec.dw1_side_split or max(1, dec.dw1_side_wgs // (-(-nh * D // 128) * -(-D // 128)))
+                        dec.dw1_side_split or max(1, dec.dw1_side_wgs // (-(-nh * D // 128) * -(-D // 128)),
+                                                  -(-B * rows // dec.dw1_side_rows))
                     ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat, split_k=split)
                 ctx.side_work = (side, (dzbuf, xbuf1, dW1cat, ab), can_hold)
             else:
@@ -613,7 +617,8 @@ class PEneoDecoder(nn.Module):
         self.fused_bwd = os.environ.get("PENEO_BWD_FUSED", "1") != "0"          # bf16: the whole pair-space backward in one kernel
         self.dw1_on_side = os.environ.get("PENEO_DW1_SIDE", "1") != "0"          # its dW1 GEMM beside the following stages
         self.dw1_hold = os.environ.get("PENEO_DW1_HOLD", "1") != "0"             # ... joined at the end of the backward only
-        self.dw1_side_split = 0          # fixed split-k of that GEMM; 0: from the target
+        self.dw1_side_split = int(os.environ.get("PENEO_DW1_SPLIT", "0"))   # fixed split-k of that GEMM; 0: from the targets below
+        self.dw1_side_rows = 600_000     # ... none of them with more rows of K than this
         self.dw1_side_wgs = 144          # ... of about this many long workgroups (measured 18.10 ms per step against 18.56 at 495)
         self._ratio = {}
 

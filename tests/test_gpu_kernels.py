@@ -1210,7 +1210,8 @@ def test_ohem_ce_matches_reference_cases_and_oracle(ops):
 
 @pytest.mark.parametrize("B,N,D,p_drop", [(2, 45, 128, 0.0), (1, 70, 384, 0.0), (3, 23, 32, 0.0), (1, 130, 64, 0.0),
                                           (2, 16, 384, 0.0), (1, 9, 128, 0.0), (2, 45, 128, 0.1), (1, 70, 384, 0.1),
-                                          (3, 23, 32, 0.25), (2, 511, 384, 0.0), (2, 511, 384, 0.1)])
+                                          (3, 23, 32, 0.25), (2, 511, 384, 0.0), (2, 511, 384, 0.1),
+                                          (2, 37, 512, 0.0), (1, 70, 512, 0.1), (1, 1023, 512, 0.1)])
 def test_pair_bwd_fused_matches_autograd(ops, B, N, D, p_drop):
     """peneo_pair_bwd_fused: dz / x in block order, d_ab (= d_a | d_b), dW2 / db1 sums and (through the one GEMM it leaves)
     dW1, against fp32 autograd through x = SiLU(a_i + b_j) -> z = x W1^T + b1 -> SiLU -> W2 with given dlogits."""
@@ -1248,13 +1249,12 @@ def test_pair_bwd_fused_matches_autograd(ops, B, N, D, p_drop):
     w1r = [w.to(dtype).float().clone().requires_grad_(True) for w in w1]
     w2r = [w.clone().requires_grad_(True) for w in w2]
     b1r = b1cat.clone().requires_grad_(True)
-    tot = 0
+    keep_all = torch.stack([k12_keep(seed, b, 0, P, nh * D, p_drop) for b in range(B)]).to(DEV) if p_drop > 0 else None
     for h in range(nh):                                                          # head by head: [B, P, D] temporaries only
         z = xq @ w1r[h].t() + b1r[h * D:(h + 1) * D]
         y = F.silu(z)
         if p_drop > 0:
-            keep = torch.stack([k12_keep(seed, b, 0, P, nh * D, p_drop)[:, h * D:(h + 1) * D] for b in range(B)]).to(DEV)
-            y = y * keep * k12_scale(p_drop)
+            y = y * keep_all[:, :, h * D:(h + 1) * D] * k12_scale(p_drop)
         (((y @ w2r[h].t()) * dl[h] * scale[h]).sum()).backward(retain_graph=h + 1 < nh)
         del z, y
     t = 3e-2

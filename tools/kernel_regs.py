@@ -5,7 +5,7 @@ import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "peneo_amd", "csrc", sys.argv[1])
 want = sys.argv[2] if len(sys.argv) > 2 else ""
-extra = ["-fno-slp-vectorize"] if "pair_bwd" in src else []
+extra = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] if "pair_bwd" in src else []
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage",
                     "--cuda-device-only", "-c", src, "-o", "/dev/null"] + extra, capture_output=True, text=True)
 cur = None
