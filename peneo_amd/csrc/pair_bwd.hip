@@ -687,6 +687,18 @@ template <int C, typename V> __device__ __forceinline__ void pb_pin(V (&d)[C]) {
   for (int i = 0; i < C; ++i) asm volatile("" : "+v"(d[i]));
 }
 __device__ __forceinline__ void pb_lgkm0(pb_u32x4& a, pb_u32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) :: "memory"); }
+__device__ __forceinline__ void pb_mma_v(const uint4& a, const pb_u32x4& b, f32x16_t& acc) {
+  const pb_u32x4 av = pb_u32x4{a.x, a.y, a.z, a.w};
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(b));
+}
+__device__ __forceinline__ void pb_mma_v0(const uint4& a, const pb_u32x4& b, f32x16_t& acc) {   // acc = a b (no accumulator read)
+  const pb_u32x4 av = pb_u32x4{a.x, a.y, a.z, a.w};
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(av), "v"(b));
+}
+// one LDS-DMA piece, uniform 64-bit base + per-lane offset; M0 is this kernel's to clobber (nothing else in it reads M0)
+__device__ __forceinline__ void pb_dma_piece(uint32_t voff_lane, const char* base_uniform, uint32_t lds_uniform) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff_lane), "s"(base_uniform), "s"(lds_uniform) : "memory", "m0");
+}
 __device__ __forceinline__ void pb_mma_acc(const pb_u32x4& a, const pb_u32x4& b, f32x16_t& acc) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
@@ -736,15 +748,19 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
     sB1[n] = p.b1[n];
   }
 
-  const char* wbase = reinterpret_cast<const char*>(p.wp) + lane * 16;
   const uint32_t ring = lds_addr(sA);
-  auto dma_slab = [&](int slab) {       // wave w carries pieces w, w + 4, ...
-    const int slot = slab % 3;
+  // weight stream: wave w carries pieces w, w + 4, ... of a slab.  Slab s + 1 is requested piece by piece from inside the Z
+  // phase of iteration s (an LDS-DMA instruction holds its issuer for tens to hundreds of cycles once a few are in flight:
+  // as a block at the top of the iteration that was 15 % of the kernel; between two chunks of queued MFMAs it is free)
+  const char* const wuni = reinterpret_cast<const char*>(p.wp) + 2 * HALF_BYTES + wave * 1024;   // uniform: this wave's first piece of slab 0
+  const uint32_t wlane = lane * 16;
+  auto dma_piece = [&](int slab, int k) {
+    lds_dma_1k_s<0>(wlane, wuni + (int64_t)slab * (3 * HALF_BYTES) + k * (PB_WAVES * 1024),
+                    __builtin_amdgcn_readfirstlane(ring + (slab % 3) * HALF_BYTES + (wave + k * PB_WAVES) * 1024));
+  };
+  auto dma_slab = [&](int slab) {
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) {
-      const int q = wave + k * PB_WAVES;
-      lds_dma_1k<0>(wbase + (int64_t)slab * (3 * HALF_BYTES) + 2 * HALF_BYTES + q * 1024, __builtin_amdgcn_readfirstlane(ring + slot * HALF_BYTES + q * 1024));
-    }
+    for (int k = 0; k < PPW; ++k) dma_piece(slab, k);
   };
   dma_slab(0);
 
@@ -878,8 +894,10 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
   auto iteration = [&](auto z_c, auto u_c, int s) {
     constexpr bool DOZ = decltype(z_c)::value, DOU = decltype(u_c)::value;
     f32x16_t z, dy;
+    if constexpr (!DOZ) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { z[r] = 0.f; dy[r] = 0.f; }
+    }
     uint2 cw2 = make_uint2(0u, 0u);
     float cb1 = 0.f;
     if constexpr (DOZ) {
@@ -896,8 +914,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       constexpr int NZ = KS / 2;
       pb_u32x4 fs[4][2];
       f32x16_t zb;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) zb[r] = 0.f;
       auto zissue = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
         pb_dsr<(2 * J) * 1024>(fs[J & 3][0], za0);
@@ -906,31 +922,35 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       // K12 dropout: the keep / drop addends of this slab are made under the matrix phase.  Lane = (pair r32, half) walks the
       // forward's chain of 16 fields (units 8g + 4 half + e) and leaves one f16 per unit where the lane that owns (unit, half
       // of the pair's register) reads its 16 registers; chunk J takes steps 16 J / NZ .. 16 (J + 1) / NZ - 1
+      // the next slab's weights (the last iteration requests its own slab once more, into the free slot: no branch)
+      const int nslot = (s + 1) % 3, nsl = min(s + 1, nslab - 1);
+      const char* const nsrc = wuni + (int64_t)nsl * (3 * HALF_BYTES);
+      const uint32_t ndst = __builtin_amdgcn_readfirstlane(ring + nslot * HALF_BYTES + wave * 1024);
       const uint32_t mwa = lds_addr(sMask + ((grp * 32 * 2 + mhp) * 16) + mreg) + half * (4 * 32 * 2);
       uint32_t mst = DROP ? pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)s) : 0u;
+      const uint32_t thr32 = p.drop_thr16 << 16;
       auto zchunk = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
         if constexpr (J + 3 < NZ) zissue(std::integral_constant<int, J + 3>{});
+        if constexpr (J % 2 == 1 && J / 2 < PPW) pb_dma_piece(wlane, nsrc + (J / 2) * (PB_WAVES * 1024), ndst + (J / 2) * (PB_WAVES * 1024));
         if constexpr (DROP) {
           pb_static_for<pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J)>([&](auto ic) {
             constexpr int I = pb_mask_steps(NZ, J) + decltype(ic)::value;
             mst = pair_drop_step(mst);
-            const uint32_t v = (mst >> 16) >= p.drop_thr16 ? 0u : 0xF753u;   // f16 0 / -30000
+            const uint32_t v = mst >= thr32 ? 0u : 0xF753u;   // field = bits 16.. of the state; f16 0 / -30000
             pb_dsw16<(8 * (I >> 2) + (I & 3)) * 32 * 2>(mwa, v);
           });
         }
         // the fragments of chunk J: everything but the (at most) three younger chunks and the mask stores behind them has landed
         constexpr int younger = (NZ - 1 - J) < 3 ? (NZ - 1 - J) : 3;
         constexpr int ywr = DROP ? pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J >= 3 ? J - 3 : 0) : 0;
-        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(2 * younger + ywr) : "memory");
-        pb_pin<2>(fs[J & 3]);
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[J & 3][0]), "+v"(fs[J & 3][1]) : [n] "n"(2 * younger + ywr) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         // two accumulators: a dependent MFMA does not start before its predecessor has written back
-        pb_mma(xf[2 * J], fs[J & 3][0], z);
-        pb_mma(xf[2 * J + 1], fs[J & 3][1], zb);
-        // anchor: the builtin MFMAs carry no ordering of their own against the hand-issued reads around them (instruction
-        // selection would sink the whole chain behind the last wait); an empty volatile statement on their result does
-        asm volatile("" : "+v"(z), "+v"(zb));
+        // (volatile statements: builtin MFMAs carry no ordering of their own against the hand-issued reads around them -
+        // instruction selection sank the whole chain behind the last wait)
+        if constexpr (J == 0) { pb_mma_v0(xf[0].v, fs[0][0], z); pb_mma_v0(xf[1].v, fs[0][1], zb); }
+        else { pb_mma_v(xf[2 * J].v, fs[J & 3][0], z); pb_mma_v(xf[2 * J + 1].v, fs[J & 3][1], zb); }
         __builtin_amdgcn_sched_barrier(0);
       };
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the counted waits below count only the fragment reads
@@ -938,6 +958,9 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       zissue(std::integral_constant<int, 1>{});
       zissue(std::integral_constant<int, 2>{});
       pb_static_for<NZ>([&](auto jc) { zchunk(jc); });
+      // the compiler does not know that the statements above are MFMAs: the wait states between an 8-pass MFMA and a VALU read
+      // of its result are ours (the dy MFMA and these nops)
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(z), "+v"(zb));
 #pragma unroll
       for (int r = 0; r < 16; ++r) { z[r] += zb[r]; dy[r] = 0.f; }
       const pb_u32x4 w2f = pb_u32x4{half ? 0u : cw2.x, half ? 0u : cw2.y, 0u, 0u};
@@ -962,25 +985,27 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
     // LDS operations complete in order, so the waits count what may still be in flight (reads: 4 per sub-chunk, the mask
     // dword, the dz tile store of the E part).
     pb_u32x4 a0 = pb_u32x4{0u, 0u, 0u, 0u}, a1 = a0;
-    pb_u32x2 ul[2][2], uh[2][2];
+    pb_u32x2 ul[3][2], uh[3][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { ul[0][i] = pb_u32x2{0u, 0u}; ul[1][i] = ul[0][i]; uh[0][i] = ul[0][i]; uh[1][i] = ul[0][i]; }
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ul[k][i] = pb_u32x2{0u, 0u}; uh[k][i] = ul[k][i]; }
     uint32_t ua0 = 0u, ua1 = 0u;
     auto uissue = [&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       // sub-chunk Q = the kk = Q & 1 fragments of du tiles 2 (Q >> 1), 2 (Q >> 1) + 1: its two MFMAs are independent
       if constexpr (DOU && Q < NDT) {
         constexpr int F0 = 4 * (Q >> 1) + (Q & 1);
-        pb_trd<pb_uoff(F0)>(ul[Q & 1][0], ua0); pb_trd<pb_uoff(F0)>(uh[Q & 1][0], ua1);
-        pb_trd<pb_uoff(F0 + 2)>(ul[Q & 1][1], ua0); pb_trd<pb_uoff(F0 + 2)>(uh[Q & 1][1], ua1);
+        pb_trd<pb_uoff(F0)>(ul[Q % 3][0], ua0); pb_trd<pb_uoff(F0)>(uh[Q % 3][0], ua1);
+        pb_trd<pb_uoff(F0 + 2)>(ul[Q % 3][1], ua0); pb_trd<pb_uoff(F0 + 2)>(uh[Q % 3][1], ua1);
       }
     };
     auto umma = [&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       if constexpr (DOU) {
-        pb_pin<2>(ul[Q & 1]); pb_pin<2>(uh[Q & 1]);
-        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q & 1][0].x, ul[Q & 1][0].y, uh[Q & 1][0].x, uh[Q & 1][0].y}, du[2 * (Q >> 1)]);
-        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q & 1][1].x, ul[Q & 1][1].y, uh[Q & 1][1].x, uh[Q & 1][1].y}, du[2 * (Q >> 1) + 1]);
+        pb_pin<2>(ul[Q % 3]); pb_pin<2>(uh[Q % 3]);
+        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q % 3][0].x, ul[Q % 3][0].y, uh[Q % 3][0].x, uh[Q % 3][0].y}, du[2 * (Q >> 1)]);
+        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q % 3][1].x, ul[Q % 3][1].y, uh[Q % 3][1].x, uh[Q % 3][1].y}, du[2 * (Q >> 1) + 1]);
       }
     };
     if constexpr (MK) asm volatile("ds_read_b32 %0, %1" : "=v"(mk[0]) : "v"(mka));
@@ -994,21 +1019,31 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       pb_dsr<0>(a1, ta + (((2 + half) ^ t_swz) << 4));
       uissue(std::integral_constant<int, 0>{});
       uissue(std::integral_constant<int, 1>{});
-      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(mk[0]) :: "memory");   // all but sub-chunk 1
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0), "+v"(a1), "+v"(mk[0]) :: "memory");   // all but the two sub-chunks
       *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
       *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[0]) :: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
+    // chunk J = sub-chunks 2J, 2J + 1 of U and accumulator registers 2J, 2J + 1 of E.  Order of the wave's LDS operations:
+    //   R(2J+2) MK(J+1) [wait a] ... R(2J+3) [wait b] ... W(J)        R = 4 transposed reads, MK = mask dword, W = tile store
+    // wait a: sub-chunk 2J and MK(J) complete = at most R(2J+1) W(J-1) R(2J+2) MK(J+1) outstanding
+    // wait b: sub-chunk 2J+1 complete         = at most W(J-1) R(2J+2) MK(J+1) R(2J+3) outstanding
     auto chunk = [&](auto jc) {
       constexpr int J = decltype(jc)::value;
       constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
+      constexpr int NW = DOZ ? 1 : 0, NM = MK ? 1 : 0;
       const int row0 = rowc + 4 * half;
       f2 zz = f2{0.f, 0.f}, sg = zz, y = zz, dzv = zz;
-      umma(std::integral_constant<int, 2 * J>{});
       uissue(std::integral_constant<int, 2 * J + 2>{});
       if constexpr (MK && J + 1 < 8) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(mk[(J + 1) & 1]) : "v"(mka), "n"(4 * (J + 1)));
+      if constexpr (DOU || MK) {
+        constexpr int RA = DOU ? 4 : 0;
+        constexpr int na = J + 1 < 8 ? RA + (J > 0 ? NW : 0) + RA + NM : RA + NW;
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(mk[J & 1]) : [n] "n"(na) : "memory");
+      }
+      umma(std::integral_constant<int, 2 * J>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DOZ) {
         float zx = z[r0], zy = z[r0 + 1];
@@ -1026,13 +1061,12 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
         asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(sg.x), "+v"(sg.y));   // anchor in front of the next MFMAs
       }
       __builtin_amdgcn_sched_barrier(0);
+      uissue(std::integral_constant<int, 2 * J + 3>{});
       if constexpr (DOU) {
-        // sub-chunk 2J + 1: younger = this chunk's reads of sub-chunk 2J + 2 and mask dword; the previous chunk's tile store
-        if constexpr (J + 1 < 8) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 + (DOZ ? 1 : 0) + (MK ? 1 : 0)) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int nb = J + 1 < 8 ? (J > 0 ? NW : 0) + 4 + NM + 4 : NW;
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(nb) : "memory");
       }
       umma(std::integral_constant<int, 2 * J + 1>{});
-      uissue(std::integral_constant<int, 2 * J + 3>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DOZ) {
         // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
@@ -1045,13 +1079,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
         const int trow = row0 + (lane & 1);
         const int boff = (r32 & ~1) * 2;
         const int f = ((rowc >> 2) + half) & 3;
-        *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (J + 1 < 8) {
-        // sub-chunk 2J + 2 and the next mask dword: younger = the reads of sub-chunk 2J + 3 and this chunk's tile store
-        if constexpr (DOU) asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(mk[(J + 1) & 1]) : [n] "n"(4 + (DOZ ? 1 : 0)) : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[(J + 1) & 1]) :: "memory");
+        asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15)))), "v"(packed) : "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -1062,10 +1090,8 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       // operand, the head's g transposed, is rebuilt from the wave's staging rows: 8 registers less across the loop) and db1
       pb_u32x4 gT0, gT1;
       build_gT(gT0, gT1);
-      f32x16_t acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      pb_mma(gT0, pb_u32x4{yp[0], yp[1], yp[2], yp[3]}, acc);
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, gT0), __builtin_bit_cast(bf16x8_t, pb_u32x4{yp[0], yp[1], yp[2], yp[3]}), zero, 0, 0, 0);
       pb_mma(gT1, pb_u32x4{yp[4], yp[5], yp[6], yp[7]}, acc);
       float sbt = sbx + sby;
       sbt += __shfl_xor(sbt, 32);
@@ -1082,11 +1108,9 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
   const unsigned long long t_begin = t_last;
 #endif
   top();                                                      // slab 0 has landed
-  if (nslab > 1) dma_slab(1);
   iteration(yes{}, no{}, 0);
   for (int s = 1; s < nslab; ++s) {
     top();
-    if (s + 1 < nslab) dma_slab(s + 1);
     flush(s - 1);
     iteration(yes{}, yes{}, s);
   }
