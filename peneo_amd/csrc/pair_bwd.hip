@@ -721,7 +721,10 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
   float4* sG = reinterpret_cast<float4*>(sB1 + ncol);                       // [4][32]
   float4* sPart = sG + 4 * 32;                                              // [2][4][32]
   char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
-  _Float16* sMask = reinterpret_cast<_Float16*>(sT + 2 * 4 * 2048);         // [4 groups][32 units][2 halves][16 registers]
+  // [4 groups][32 units][80 B: 2 halves x 16 registers of f16, padded so that units u and u + 4 (what the two halves of a
+  // wave write in one instruction) sit in different banks]
+  char* sMask = sT + 2 * 4 * 2048;
+  constexpr int MROW = 80;
 
   int ti = 0;
   {
@@ -926,31 +929,34 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       const int nslot = (s + 1) % 3, nsl = min(s + 1, nslab - 1);
       const char* const nsrc = wuni + (int64_t)nsl * (3 * HALF_BYTES);
       const uint32_t ndst = __builtin_amdgcn_readfirstlane(ring + nslot * HALF_BYTES + wave * 1024);
-      const uint32_t mwa = lds_addr(sMask + ((grp * 32 * 2 + mhp) * 16) + mreg) + half * (4 * 32 * 2);
+      const uint32_t mwa = lds_addr(sMask) + grp * (32 * MROW) + half * (4 * MROW) + mhp * 32 + mreg * 2;
       uint32_t mst = DROP ? pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)s) : 0u;
       const uint32_t thr32 = p.drop_thr16 << 16;
+      // A wave has ONE MFMA in flight: the next one holds the wave until the matrix pipe is free, and only what stands
+      // BETWEEN two MFMAs issues in the first one's shadow.  So: wait, MFMA, [next reads + a weight piece], MFMA, [mask steps].
+      // LDS operations of the phase, in order:   R0 R1 R2 | chunk k: R(k+3) W(k)      (R = 2 reads, W = the chunk's mask stores)
       auto zchunk = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
+        // the fragments of chunk J have landed: at most the two younger chunks' reads and the mask stores issued since then
+        constexpr int yrd = (NZ - 1 - J) < 2 ? (NZ - 1 - J) : 2;
+        constexpr int ywr = DROP ? pb_mask_steps(NZ, J) - pb_mask_steps(NZ, J >= 3 ? J - 3 : 0) : 0;
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[J & 3][0]), "+v"(fs[J & 3][1]) : [n] "n"(2 * yrd + ywr) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // (volatile statements, two accumulators: builtin MFMAs carry no ordering of their own against the hand-issued reads
+        // around them - instruction selection sank the whole chain behind the last wait)
+        if constexpr (J == 0) pb_mma_v0(xf[0].v, fs[0][0], z); else pb_mma_v(xf[2 * J].v, fs[J & 3][0], z);
         if constexpr (J + 3 < NZ) zissue(std::integral_constant<int, J + 3>{});
         if constexpr (J % 2 == 1 && J / 2 < PPW) pb_dma_piece(wlane, nsrc + (J / 2) * (PB_WAVES * 1024), ndst + (J / 2) * (PB_WAVES * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (J == 0) pb_mma_v0(xf[1].v, fs[0][1], zb); else pb_mma_v(xf[2 * J + 1].v, fs[J & 3][1], zb);
         if constexpr (DROP) {
           pb_static_for<pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J)>([&](auto ic) {
             constexpr int I = pb_mask_steps(NZ, J) + decltype(ic)::value;
             mst = pair_drop_step(mst);
             const uint32_t v = mst >= thr32 ? 0u : 0xF753u;   // field = bits 16.. of the state; f16 0 / -30000
-            pb_dsw16<(8 * (I >> 2) + (I & 3)) * 32 * 2>(mwa, v);
+            pb_dsw16<(8 * (I >> 2) + (I & 3)) * MROW>(mwa, v);
           });
         }
-        // the fragments of chunk J: everything but the (at most) three younger chunks and the mask stores behind them has landed
-        constexpr int younger = (NZ - 1 - J) < 3 ? (NZ - 1 - J) : 3;
-        constexpr int ywr = DROP ? pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J >= 3 ? J - 3 : 0) : 0;
-        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[J & 3][0]), "+v"(fs[J & 3][1]) : [n] "n"(2 * younger + ywr) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // two accumulators: a dependent MFMA does not start before its predecessor has written back
-        // (volatile statements: builtin MFMAs carry no ordering of their own against the hand-issued reads around them -
-        // instruction selection sank the whole chain behind the last wait)
-        if constexpr (J == 0) { pb_mma_v0(xf[0].v, fs[0][0], z); pb_mma_v0(xf[1].v, fs[0][1], zb); }
-        else { pb_mma_v(xf[2 * J].v, fs[J & 3][0], z); pb_mma_v(xf[2 * J + 1].v, fs[J & 3][1], zb); }
         __builtin_amdgcn_sched_barrier(0);
       };
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the counted waits below count only the fragment reads
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
     for (int i = 0; i < 8; ++i) yp[i] = 0u;
     // K12 dropout: the f16 addends (0 / -30000) of accumulator registers 2J, 2J + 1 = dword J of this lane's 16, read one
     // chunk ahead
-    const uint32_t mka = lds_addr(sMask + ((grp * 32 + r32) * 2 + half) * 16);
+    const uint32_t mka = lds_addr(sMask) + (grp * 32 + r32) * MROW + half * 32;
     uint32_t mk[2] = {0u, 0u};
     constexpr bool MK = DOZ && DROP;
 
@@ -1000,14 +1006,6 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
         pb_trd<pb_uoff(F0 + 2)>(ul[Q % 3][1], ua0); pb_trd<pb_uoff(F0 + 2)>(uh[Q % 3][1], ua1);
       }
     };
-    auto umma = [&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      if constexpr (DOU) {
-        pb_pin<2>(ul[Q % 3]); pb_pin<2>(uh[Q % 3]);
-        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q % 3][0].x, ul[Q % 3][0].y, uh[Q % 3][0].x, uh[Q % 3][0].y}, du[2 * (Q >> 1)]);
-        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q % 3][1].x, ul[Q % 3][1].y, uh[Q % 3][1].x, uh[Q % 3][1].y}, du[2 * (Q >> 1) + 1]);
-      }
-    };
     if constexpr (MK) asm volatile("ds_read_b32 %0, %1" : "=v"(mk[0]) : "v"(mka));
     if constexpr (DOU) {
       const int u = s - 1;
@@ -1026,28 +1024,34 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[0]) :: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
-    // chunk J = sub-chunks 2J, 2J + 1 of U and accumulator registers 2J, 2J + 1 of E.  Order of the wave's LDS operations:
-    //   R(2J+2) MK(J+1) [wait a] ... R(2J+3) [wait b] ... W(J)        R = 4 transposed reads, MK = mask dword, W = tile store
-    // wait a: sub-chunk 2J and MK(J) complete = at most R(2J+1) W(J-1) R(2J+2) MK(J+1) outstanding
-    // wait b: sub-chunk 2J+1 complete         = at most W(J-1) R(2J+2) MK(J+1) R(2J+3) outstanding
+    // chunk J = sub-chunks 2J, 2J + 1 of U (two MFMAs each) and accumulator registers 2J, 2J + 1 of E.  Every MFMA is followed by
+    // a quarter of the chunk's E arithmetic (what issues in its shadow, see Z).  LDS operations of the wave, in order:
+    //   [wait a] R(2J+2) MK(J+1) ... R(2J+3) [wait b] ... W(J)       R = 4 transposed reads, MK = mask dword, W = tile store
+    // wait a: sub-chunk 2J and MK(J) complete   = at most R(2J+1) W(J-1) outstanding
+    // wait b: sub-chunk 2J+1 complete           = at most W(J-1) R(2J+2) MK(J+1) R(2J+3) outstanding
+    auto umma1 = [&](auto qc, auto ic) {
+      constexpr int Q = decltype(qc)::value, I = decltype(ic)::value;
+      if constexpr (DOU)
+        pb_mma_acc((Q & 1) ? a1 : a0, pb_u32x4{ul[Q % 3][I].x, ul[Q % 3][I].y, uh[Q % 3][I].x, uh[Q % 3][I].y}, du[2 * (Q >> 1) + I]);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     auto chunk = [&](auto jc) {
       constexpr int J = decltype(jc)::value;
       constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
-      constexpr int NW = DOZ ? 1 : 0, NM = MK ? 1 : 0;
+      constexpr int NW = DOZ ? 1 : 0, NM = MK ? 1 : 0, RA = DOU ? 4 : 0;
       const int row0 = rowc + 4 * half;
       f2 zz = f2{0.f, 0.f}, sg = zz, y = zz, dzv = zz;
+      if constexpr (DOU || MK) {
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(mk[J & 1]) : [n] "n"(RA + (J > 0 ? NW : 0)) : "memory");
+        if constexpr (DOU) { pb_pin<2>(ul[(2 * J) % 3]); pb_pin<2>(uh[(2 * J) % 3]); }
+      }
+      umma1(std::integral_constant<int, 2 * J>{}, I0{});
       uissue(std::integral_constant<int, 2 * J + 2>{});
       if constexpr (MK && J + 1 < 8) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(mk[(J + 1) & 1]) : "v"(mka), "n"(4 * (J + 1)));
-      if constexpr (DOU || MK) {
-        constexpr int RA = DOU ? 4 : 0;
-        constexpr int na = J + 1 < 8 ? RA + (J > 0 ? NW : 0) + RA + NM : RA + NW;
-        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(mk[J & 1]) : [n] "n"(na) : "memory");
-      }
-      umma(std::integral_constant<int, 2 * J>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DOZ) {
         float zx = z[r0], zy = z[r0 + 1];
-        asm volatile("" : "+v"(zx), "+v"(zy));                 // anchor behind the MFMAs above
+        asm volatile("" : "+v"(zx), "+v"(zy));                 // anchor behind the MFMA above
         zz = f2{zx, zy} + b1;
         if constexpr (DROP) {
           asm volatile("v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -1056,22 +1060,35 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
         }
         const f2 t = zz * nl2e;
         sg = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-        sg = f2{__builtin_amdgcn_rcpf(sg.x + 1.f), __builtin_amdgcn_rcpf(sg.y + 1.f)};
-        y = zz * sg;
-        asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(sg.x), "+v"(sg.y));   // anchor in front of the next MFMAs
+        asm volatile("" : "+v"(sg.x), "+v"(sg.y));             // anchor in front of the next MFMA
       }
       __builtin_amdgcn_sched_barrier(0);
+      umma1(std::integral_constant<int, 2 * J>{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DOZ) {
+        sg = f2{__builtin_amdgcn_rcpf(sg.x + 1.f), __builtin_amdgcn_rcpf(sg.y + 1.f)};
+        y = zz * sg;
+        asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(sg.x), "+v"(sg.y));
+      }
       uissue(std::integral_constant<int, 2 * J + 3>{});
       if constexpr (DOU) {
         constexpr int nb = J + 1 < 8 ? (J > 0 ? NW : 0) + 4 + NM + 4 : NW;
         asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(nb) : "memory");
+        pb_pin<2>(ul[(2 * J + 1) % 3]); pb_pin<2>(uh[(2 * J + 1) % 3]);
       }
-      umma(std::integral_constant<int, 2 * J + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      umma1(std::integral_constant<int, 2 * J + 1>{}, I0{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DOZ) {
         // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
         dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
         yp[J] = pack_bf16x2(y.x, y.y);
+        asm volatile("" : "+v"(dzv.x), "+v"(dzv.y), "+v"(yp[J]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      umma1(std::integral_constant<int, 2 * J + 1>{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DOZ) {
         sbx += dzv.x; sby += dzv.y;
         const float give = odd ? dzv.x : dzv.y;
         const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
@@ -1167,7 +1184,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
 template <int KS, bool DROP>
 static int launch_pair_bwd_one(const PairBwdParams& p, hipStream_t st) {
   const int ncol = p.a.num_heads * p.D;
-  size_t sh = (size_t)3 * KS * 1024 + (size_t)ncol * 12 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)4 * 32 * 32 * 2;
+  size_t sh = (size_t)3 * KS * 1024 + (size_t)ncol * 12 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)4 * 32 * 80;
   const size_t red = (size_t)4 * (KS / 2) * 16 * 32 * sizeof(float);
   if (sh < red) sh = red;
   if (sh > 160 * 1024) { set_error("peneo_pair_bwd_fused: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
