@@ -767,13 +767,15 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
   };
   dma_slab(0);
 
+  // scalar pairs: the packed forms (v_pk_add / mul / fma_f32) were tried here - exact with one wave per SIMD, but every one of
+  // them wants a wait state after a transcendental or before its consumer, and a lone wave pays an issue slot for each s_nop
+  // (8.0 against 7.25 ms); two scalar chains interleaved fill those slots with work
   struct f2 {
     float x, y;
     __device__ f2 operator+(const f2& o) const { return f2{x + o.x, y + o.y}; }
     __device__ f2 operator*(const f2& o) const { return f2{x * o.x, y * o.y}; }
   };
   auto fma2 = [](const f2& a, const f2& b, const f2& c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; };
-
   // ---- x = SiLU(a_i + b_j): operand fragments of z, and what the dW1 GEMM reads ----
   Frag<T> xf[KS];
   {
@@ -863,7 +865,8 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
     gT1 = pb_u32x4{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
   };
   const f2 nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
-  const bool odd = (lane & 1) != 0;
+  // 16-bit selectors of the dz tile's dword: even lanes (own.lo, partner.lo), odd lanes (partner.hi, own.hi)
+  const uint32_t psel = (lane & 1) ? 0x03020706u : 0x05040100u;
   const int t_swz = (r32 >> 2) & 3;
   T* dz_row = p.dz + row * ncol + 8 * half;
   const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
     }
     const f2 b1 = f2{cb1, cb1};
     char* myT = sT + ((s & 1) * 4 + grp) * 2048;
-    float sbx = 0.f, sby = 0.f;
+    f2 sb = f2{0.f, 0.f};
     uint32_t yp[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) yp[i] = 0u;
@@ -1066,7 +1069,8 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       umma1(std::integral_constant<int, 2 * J>{}, I1{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DOZ) {
-        sg = f2{__builtin_amdgcn_rcpf(sg.x + 1.f), __builtin_amdgcn_rcpf(sg.y + 1.f)};
+        const f2 den = sg + f2{1.f, 1.f};
+        sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
         y = zz * sg;
         asm volatile("" : "+v"(y.x), "+v"(y.y), "+v"(sg.x), "+v"(sg.y));
       }
@@ -1089,10 +1093,12 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       umma1(std::integral_constant<int, 2 * J + 1>{}, I1{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DOZ) {
-        sbx += dzv.x; sby += dzv.y;
-        const float give = odd ? dzv.x : dzv.y;
-        const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
-        const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
+        sb = sb + dzv;
+        // the lane's two values are rows (pairs) r, r + 1 of ONE hidden unit; the tile wants units c, c + 1 of one pair per
+        // dword: round both, fetch the neighbour lane's dword, pick the halves
+        const uint32_t own = pack_bf16x2(dzv.x, dzv.y);
+        const uint32_t oth = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true);
+        const uint32_t packed = __builtin_amdgcn_perm(oth, own, psel);
         const int trow = row0 + (lane & 1);
         const int boff = (r32 & ~1) * 2;
         const int f = ((rowc >> 2) + half) & 3;
@@ -1110,7 +1116,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, gT0), __builtin_bit_cast(bf16x8_t, pb_u32x4{yp[0], yp[1], yp[2], yp[3]}), zero, 0, 0, 0);
       pb_mma(gT1, pb_u32x4{yp[4], yp[5], yp[6], yp[7]}, acc);
-      float sbt = sbx + sby;
+      float sbt = sb.x + sb.y;
       sbt += __shfl_xor(sbt, 32);
       const float ys = DROP ? p.drop_scale : 1.f;
       if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = make_float4(acc[0] * ys, acc[1] * ys, acc[2] * ys, sbt);
