@@ -1,4 +1,4 @@
-"""Where the waves of attn_bwd_fused_kernel spend their cycles (s_memtime, -DATTN_PROF build: tools/attn_cycles.sh)."""
+"""Where the waves of attn_bwd_fused_kernel spend their cycles (s_memtime, -DATTN_PROF build: bash tools/prof_build.sh attn, then run with PENEO_HIP_LIB=$PWD/peneo_amd/lib/libpeneo_attnprof.so)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
