@@ -752,6 +752,247 @@ __global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits
   if (threadIdx.x == 0) *count = base;
 }
 
+// ================================================================================================
+// Hand-interleaved form (bf16, D = 384 / 512; round 4).  The generic kernel above runs a slab as [24 first-layer MFMAs] then
+// [bias + SiLU + dropout + second layer: ~200 VALU slots]; its eight waves meet at the slab's barrier, so the two waves of a
+// SIMD do the same phase at the same time and neither the matrix pipe nor the VALU ever works beside the other (4400 cycles per
+// slab for 1664 of MFMA and ~2000 of VALU per SIMD).  Here the epilogue of slab s-1 is cut into 24 pieces and ONE piece stands
+// behind every first-layer MFMA of slab s (a wave has one MFMA in flight; what stands between two MFMAs issues in the first one's
+// shadow).  MFMAs, fragment reads and waits are ordered statements: the compiler moves builtin MFMAs wherever its scheduler
+// likes (round 4 found the whole chain sunk behind the last wait in the pair backward).  LDS operations of a slab, in order:
+//   bias x 4 (previous slab) | R0 R1 R2 | slot k: [wait: <= min(2, KS-1-k) reads outstanding] MFMA(k) R(k+3) piece(s) | W2 x 2
+// An accumulator is read by the VALU one whole slab (a barrier) after the chain that wrote it (two waves share the matrix pipe: the
+// wait states a compiler would insert assume an MFMA starts when it is issued).
+// ================================================================================================
+typedef unsigned int ph_u32x4 __attribute__((ext_vector_type(4)));
+// ("+v": the destination counts as live before the read, so the register allocator cannot fold two of the rotating fragment sets
+// into one - a set is re-loaded only after the NEXT slot's MFMA has been issued behind the one that read it)
+template <int OFF> __device__ __forceinline__ void ph_dsr(ph_u32x4& d, uint32_t a) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(d) : "v"(a), "n"(OFF));
+}
+__device__ __forceinline__ void ph_mma(const ph_u32x4& a, const uint4& b, f32x16_t& acc) {
+  const ph_u32x4 bv = ph_u32x4{b.x, b.y, b.z, b.w};
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bv));
+}
+__device__ __forceinline__ void ph_mma0(const ph_u32x4& a, const uint4& b, f32x16_t& acc) {   // acc = a b
+  const ph_u32x4 bv = ph_u32x4{b.x, b.y, b.z, b.w};
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(bv));
+}
+// second layer: the B operand was written by the VALU just before (the compiler does not know this statement is an MFMA)
+__device__ __forceinline__ void ph_mma_late(const ph_u32x4& a, const ph_u32x4& b, f32x16_t& acc) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// ... and the LAST one of the kernel: the compiler copies the accumulator as soon as the statement is over, and does not know that
+// the result takes 8 passes (+ whatever a partner wave has queued in front) to arrive: the wait states are part of the statement
+__device__ __forceinline__ void ph_mma_late_final(const ph_u32x4& a, const ph_u32x4& b, f32x16_t& acc) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+               : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int N, int I = 0, typename F> __device__ __forceinline__ void ph_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); ph_static_for<N, I + 1>(f); }
+}
+
+template <int KS, bool DROP>
+__global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(PairFwdParams p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NSTAGE = 3, NF = KS + 2;
+  constexpr int UPW = (NF + PH_WAVES - 1) / PH_WAVES;               // 1 KiB DMA pieces per wave per slab
+  constexpr int SLAB_BYTES = UPW * PH_WAVES * 1024;                 // == packed slab stride
+  static_assert(KS % 4 == 0 && KS >= 8 && UPW <= 12, "hand form: D = 128 .. 512 in steps of 64");
+  char* sW = smem;                                                   // [NSTAGE][SLAB_BYTES]
+  float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES); // [nh * D]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D, N = p.N;
+  const int b = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
+  const int64_t mypair = p0 + wave * 32 + (lane & 31);
+  const bool pair_ok = mypair < p.P;
+  int pi, pj;
+  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
+  const int nslab = p.num_heads * D / 32;
+
+  for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
+
+  // ---- x = SiLU(a_i + b_j) as B-operand fragments (k = decoder dim), kept in registers (as in the generic kernel) ----
+  const T* abd = reinterpret_cast<const T*>(p.ab) + (int64_t)b * N * 2 * D;
+  const T* arow = abd + (int64_t)pi * 2 * D;
+  const T* brow = abd + (int64_t)pj * 2 * D + D;
+  Frag<T> xf[KS];
+  {
+    uint4 ra[2][4], rb[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[0][i] = *reinterpret_cast<const uint4*>(arow + 16 * i + 8 * half);
+      rb[0][i] = *reinterpret_cast<const uint4*>(brow + 16 * i + 8 * half);
+    }
+#pragma unroll
+    for (int g = 0; g < KS / 4; ++g) {
+      if (g + 1 < KS / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ra[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(arow + 16 * (4 * (g + 1) + i) + 8 * half);
+          rb[(g + 1) & 1][i] = *reinterpret_cast<const uint4*>(brow + 16 * (4 * (g + 1) + i) + 8 * half);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a[8], bb[8];
+        unpack16<T>(ra[g & 1][i], a);
+        unpack16<T>(rb[g & 1][i], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
+        xf[4 * g + i] = pack_frag8<T>(a);
+        asm volatile("" : "+v"(xf[4 * g + i].v.x), "+v"(xf[4 * g + i].v.y), "+v"(xf[4 * g + i].v.z), "+v"(xf[4 * g + i].v.w) :: "memory");
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // from here on the vm counter only sees the DMA pieces
+  __syncthreads();                                          // sB1 visible
+
+  const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
+  const uint32_t wdst = lds_addr(sW) + wave * (UPW * 1024);
+  auto dma = [&](int slab_, int buf_) { lds_dma_units<0, UPW>(wsrc + (int64_t)slab_ * SLAB_BYTES, wdst + buf_ * SLAB_BYTES); };
+  dma(0, 0);
+  if (nslab > 1) dma(1, 1);
+
+  f32x16_t lg, z0, z1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { lg[r] = 0.f; z0[r] = 0.f; z1[r] = 0.f; }
+  ph_u32x4 w2a = ph_u32x4{0u, 0u, 0u, 0u}, w2b = w2a;        // second-layer fragments of the slab whose epilogue is pending
+  const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
+  const uint32_t drop_base = (uint32_t)(mypair * nslab * 2) + (uint32_t)half;
+  const uint32_t thr32 = p.drop_thr16 << 16;                // field = bits 16.. of the chain state
+  const uint32_t sW_l = lds_addr(sW) + lane * 16, sB1_l = lds_addr(sB1) + half * 16;
+
+  // one slab: DOM = first-layer MFMAs of `slab` into zw; DOE = epilogue of slab - 1 (its accumulator: zr)
+  auto body = [&](auto m_c, auto e_c, int slab, f32x16_t& zw, const f32x16_t& zr) {
+    constexpr bool DOM = decltype(m_c)::value, DOE = decltype(e_c)::value;
+    const uint32_t wb = sW_l + (slab % NSTAGE) * SLAB_BYTES;
+    ph_u32x4 bv[4], fs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bv[i] = ph_u32x4{0u, 0u, 0u, 0u}; fs[i] = bv[i]; }
+    uint32_t st = 0u;
+    float t[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t yp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) yp[i] = 0u;
+    if constexpr (DOE) {
+      // accumulator registers 4g .. 4g+3 = hidden rows 8g + 4 half + 0..3 of the slab: one 16-byte bias read per group
+      const uint32_t ba = sB1_l + (uint32_t)(slab - 1) * 128;
+      ph_dsr<0>(bv[0], ba); ph_dsr<32>(bv[1], ba); ph_dsr<64>(bv[2], ba); ph_dsr<96>(bv[3], ba);
+      if constexpr (DROP) st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1));
+    }
+    if constexpr (DOM) { ph_dsr<0>(fs[0], wb); ph_dsr<1024>(fs[1], wb); ph_dsr<2048>(fs[2], wb); }
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) :: "memory");
+    // piece q of the epilogue: group g = q / 6 (accumulator registers 4g .. 4g+3), step q % 6
+    auto piece = [&](auto qc) {
+      constexpr int Q = decltype(qc)::value, G = Q / 6, S = Q % 6;
+      if constexpr (S == 0) {
+        const float bb[4] = {__uint_as_float(bv[G].x), __uint_as_float(bv[G].y), __uint_as_float(bv[G].z), __uint_as_float(bv[G].w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t[e] = zr[4 * G + e] + bb[e]; u[e] = t[e] * -1.4426950408889634f; }
+      } else if constexpr (S == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = __builtin_amdgcn_exp2f(u[e]);
+      } else if constexpr (S == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = u[e] + 1.f;
+        u[0] = __builtin_amdgcn_rcpf(u[0]); u[1] = __builtin_amdgcn_rcpf(u[1]);
+      } else if constexpr (S == 3) {
+        u[2] = __builtin_amdgcn_rcpf(u[2]); u[3] = __builtin_amdgcn_rcpf(u[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = t[e] * u[e];          // y = z sigmoid(z)
+      } else if constexpr (S == 4) {
+        if constexpr (DROP) {
+          // K12 dropout: the lane's 16 hidden units of the slab are the 16 fields of ONE chain, in register order
+#pragma unroll
+          for (int e = 0; e < 3; ++e) { st = pair_drop_step(st); t[e] = st >= thr32 ? t[e] : 0.f; }
+        }
+      } else {
+        if constexpr (DROP) { st = pair_drop_step(st); t[3] = st >= thr32 ? t[3] : 0.f; }
+        yp[2 * G] = pack_bf16x2(t[0], t[1]); yp[2 * G + 1] = pack_bf16x2(t[2], t[3]);
+      }
+      // anchor: the piece stays between the MFMAs it was written between
+      asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(st));
+      if constexpr (S == 5) asm volatile("" : "+v"(yp[2 * G]), "+v"(yp[2 * G + 1]));
+      // groups 0, 1 done: y rows 0..15 of the slab are complete -> the first second-layer MFMA
+      if constexpr (Q == 11) ph_mma_late(w2a, ph_u32x4{yp[0], yp[1], yp[2], yp[3]}, lg);
+      if constexpr (Q == 23) {
+        if constexpr (DOM) ph_mma_late(w2b, ph_u32x4{yp[4], yp[5], yp[6], yp[7]}, lg);
+        else ph_mma_late_final(w2b, ph_u32x4{yp[4], yp[5], yp[6], yp[7]}, lg);
+      }
+    };
+    if constexpr (DOM) {
+      ph_static_for<KS>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        constexpr int younger = (KS - 1 - K) < 2 ? (KS - 1 - K) : 2;
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[K & 3]) : [n] "n"(younger) : "memory");
+        // (the bias rows were requested in front of the fragments: they have landed with the first of these waits; the empty
+        // statement keeps the compiler from using their registers any earlier)
+        if constexpr (K == 0 && DOE) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+        if constexpr (K == 0) ph_mma0(fs[0], xf[0].v, zw); else ph_mma(fs[K & 3], xf[K].v, zw);
+        if constexpr (K + 3 < KS) {
+          if constexpr (((K + 3) & 3) == 0) ph_dsr<(K + 3) * 1024>(fs[0], wb);
+          else if constexpr (((K + 3) & 3) == 1) ph_dsr<(K + 3) * 1024>(fs[1], wb);
+          else if constexpr (((K + 3) & 3) == 2) ph_dsr<(K + 3) * 1024>(fs[2], wb);
+          else ph_dsr<(K + 3) * 1024>(fs[3], wb);
+        }
+        if constexpr (DOE) {
+          ph_static_for<(K + 1) * 24 / KS - K * 24 / KS>([&](auto ic) { piece(std::integral_constant<int, K * 24 / KS + decltype(ic)::value>{}); });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // this slab's second-layer fragments, for its epilogue one iteration later
+      ph_u32x4 na = ph_u32x4{0u, 0u, 0u, 0u}, nb = na;
+      ph_dsr<KS * 1024>(na, wb); ph_dsr<(KS + 1) * 1024>(nb, wb);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na), "+v"(nb) :: "memory");
+      w2a = na; w2b = nb;
+    } else {
+      ph_static_for<24>([&](auto qc) { piece(qc); });
+    }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  auto top = [&](int slab) {
+    // slabs slab, slab + 1 are in flight (only `slab` itself at the very end): wait for the older one, meet, request slab + 2
+    if (slab + 1 < nslab) wait_vm<UPW>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (slab + 2 < nslab) dma(slab + 2, (slab + 2) % NSTAGE);
+  };
+  top(0); body(yes{}, no{}, 0, z0, z1);
+  int slab = 1;
+  for (; slab + 1 < nslab; slab += 2) {
+    top(slab); body(yes{}, yes{}, slab, z1, z0);
+    top(slab + 1); body(yes{}, yes{}, slab + 1, z0, z1);
+  }
+  if (slab < nslab) {                                       // nslab even: one more slab, its accumulator is z1
+    top(slab); body(yes{}, yes{}, slab, z1, z0);
+    __builtin_amdgcn_s_barrier();                           // (a slab's distance between the MFMAs and the VALU reads of z1)
+    body(no{}, yes{}, nslab, z0, z1);
+  } else {
+    __builtin_amdgcn_s_barrier();
+    body(no{}, yes{}, nslab, z1, z0);
+  }
+  pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
+}
+
+template <int KS, bool DROP>
+static int launch_pair_fwd_hand(const PairFwdParams& p, hipStream_t st) {
+  const size_t slab = (size_t)slab_stride_bytes(KS * 16, 2);
+  size_t sh = 3 * slab + (size_t)p.num_heads * p.D * sizeof(float);
+  if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_hand_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
+    return PENEO_ERR_LAUNCH;
+  }
+  dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
+  hipLaunchKernelGGL((pair_heads_fwd_hand_kernel<KS, DROP>), grid, dim3(PH_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_heads_fwd");
+}
+
 template <typename T, int KS, int VARIANT, bool DROP>
 static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
   constexpr int NSTAGE = (VARIANT & 128) ? 4 : (sizeof(T) == 2 ? 3 : 2);
@@ -773,9 +1014,15 @@ static int launch_pair_fwd_v(const PairFwdParams& p, hipStream_t st) {
 // bf16: LDS-DMA from inline asm with counted vmcnt (variant 1): 1761 us against 1838 us for the builtin at B = 8
 // (the compiler drains the whole vm counter in front of every ds_read while a DMA it knows about is in flight)
 constexpr int PH_DEFAULT_VARIANT = 1;
+// tools/: PENEO_PAIR_FWD_HAND=0 selects the generic kernel at D = 384 / 512 too
+static bool pair_fwd_hand() { static const bool v = [] { const char* e = getenv("PENEO_PAIR_FWD_HAND"); return !e || atoi(e) != 0; }(); return v; }
 template <typename T, int KS>
 static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
   constexpr int V = sizeof(T) == 2 ? PH_DEFAULT_VARIANT : 0;
+  if constexpr (sizeof(T) == 2 && (KS == 24 || KS == 32)) {
+    if (pair_fwd_hand() && p.num_heads * p.D / 32 >= 2)
+      return p.drop_thr16 ? launch_pair_fwd_hand<KS, true>(p, st) : launch_pair_fwd_hand<KS, false>(p, st);
+  }
   return p.drop_thr16 ? launch_pair_fwd_v<T, KS, V, true>(p, st) : launch_pair_fwd_v<T, KS, V, false>(p, st);
 }
 

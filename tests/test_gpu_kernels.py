@@ -763,7 +763,7 @@ def _pair_ref(ab, w1, b1, w2, b2):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,D", [(39, 32), (71, 96), (130, 384)])
+@pytest.mark.parametrize("N,D", [(39, 32), (71, 96), (130, 384), (70, 512), (33, 384)])
 def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
     B, classes = 2, [2, 3, 3, 3, 3]
     g = torch.Generator().manual_seed(N)
@@ -801,7 +801,7 @@ def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,D", [(39, 32), (71, 96), (130, 384)])
+@pytest.mark.parametrize("N,D", [(39, 32), (71, 96), (130, 384), (70, 512)])
 def test_pair_heads_fwd_classifier_dropout(ops, dtype, N, D):
     """Train mode: Dropout(p) between the two classifier layers (model/peneo_decoder.py:261) inside the fused kernel.  The mask
     is a pure function of (seed, document, pair, hidden column), restated on the host (tests/dropout_ref.py): logits must
