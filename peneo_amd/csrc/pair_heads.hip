@@ -23,7 +23,10 @@
 
 namespace peneo {
 
-constexpr int PH_WAVES = 8;
+#ifndef PH_WAVES_N
+#define PH_WAVES_N 8
+#endif
+constexpr int PH_WAVES = PH_WAVES_N;
 constexpr int PH_PAIRS = PH_WAVES * 32;   // pairs per workgroup (8 waves x 32)
 constexpr int NCP = 16;                   // padded class rows that are ever non-zero (<= 16)
 
@@ -221,7 +224,7 @@ __device__ __forceinline__ void pair_epilogue(const PairFwdParams& p, const f32x
 //   2: bias + SiLU + second layer of slab s-1 software-pipelined into the first-layer MFMA stream of slab s
 //   4: two independent first-layer accumulator chains (even / odd k-steps)
 template <typename T, int KS, int NSTAGE, int VARIANT, bool DROP>
-__global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? 2 : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
+__global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? (PH_WAVES > 8 ? 3 : 2) : 1) void pair_heads_fwd_kernel(PairFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool ASM_DMA = (VARIANT & 1) != 0, PIPE_EPI = (VARIANT & 2) != 0, DUAL = (VARIANT & 4) != 0;
   constexpr bool SGB = (VARIANT & 16) != 0;       // sched_group_barrier interleave: 1 MFMA : 1 ds_read : few VALU
@@ -764,6 +767,12 @@ __global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits
 // An accumulator is read by the VALU one whole slab (a barrier) after the chain that wrote it (two waves share the matrix pipe: the
 // wait states a compiler would insert assume an MFMA starts when it is issued).
 // ================================================================================================
+#ifdef PH_PROF
+__device__ unsigned long long* g_ph_prof;
+#endif
+#ifndef PH_HAND_LA
+#define PH_HAND_LA 3
+#endif
 typedef unsigned int ph_u32x4 __attribute__((ext_vector_type(4)));
 // ("+v": the destination counts as live before the read, so the register allocator cannot fold two of the rotating fragment sets
 // into one - a set is re-loaded only after the NEXT slot's MFMA has been issued behind the one that read it)
@@ -796,10 +805,14 @@ template <int KS, bool DROP>
 __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(PairFwdParams p) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NSTAGE = 3, NF = KS + 2;
+  constexpr int NF = KS + 2;
+  // four slab buffers where they fit (D = 384): the request for slab + 2 then goes out BEFORE the barrier (see `top`)
+  constexpr int NSTAGE = ((NF + PH_WAVES - 1) / PH_WAVES) * PH_WAVES * 1024 * 4 + 5 * 512 * 4 <= 160 * 1024 ? 4 : 3;
   constexpr int UPW = (NF + PH_WAVES - 1) / PH_WAVES;               // 1 KiB DMA pieces per wave per slab
   constexpr int SLAB_BYTES = UPW * PH_WAVES * 1024;                 // == packed slab stride
   static_assert(KS % 4 == 0 && KS >= 8 && UPW <= 12, "hand form: D = 128 .. 512 in steps of 64");
+  // fragment reads run LA slots ahead of their MFMA through LA + 1 rotating register sets (what the register budget allows)
+  constexpr int LA = KS <= 24 ? PH_HAND_LA : 3, NS = LA + 1;
   char* sW = smem;                                                   // [NSTAGE][SLAB_BYTES]
   float* sB1 = reinterpret_cast<float*>(smem + NSTAGE * SLAB_BYTES); // [nh * D]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   const uint32_t wdst = lds_addr(sW) + wave * (UPW * 1024);
   auto dma = [&](int slab_, int buf_) { lds_dma_units<0, UPW>(wsrc + (int64_t)slab_ * SLAB_BYTES, wdst + buf_ * SLAB_BYTES); };
   dma(0, 0);
-  if (nslab > 1) dma(1, 1);
+  dma(min(1, nslab - 1), 1);
 
   f32x16_t lg, z0, z1;
 #pragma unroll
@@ -870,9 +883,11 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   auto body = [&](auto m_c, auto e_c, int slab, f32x16_t& zw, const f32x16_t& zr) {
     constexpr bool DOM = decltype(m_c)::value, DOE = decltype(e_c)::value;
     const uint32_t wb = sW_l + (slab % NSTAGE) * SLAB_BYTES;
-    ph_u32x4 bv[4], fs[4];
+    ph_u32x4 bv[4], fs[NS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { bv[i] = ph_u32x4{0u, 0u, 0u, 0u}; fs[i] = bv[i]; }
+    for (int i = 0; i < 4; ++i) bv[i] = ph_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NS; ++i) fs[i] = ph_u32x4{0u, 0u, 0u, 0u};
     uint32_t st = 0u;
     float t[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t yp[8];
@@ -884,7 +899,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
       ph_dsr<0>(bv[0], ba); ph_dsr<32>(bv[1], ba); ph_dsr<64>(bv[2], ba); ph_dsr<96>(bv[3], ba);
       if constexpr (DROP) st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1));
     }
-    if constexpr (DOM) { ph_dsr<0>(fs[0], wb); ph_dsr<1024>(fs[1], wb); ph_dsr<2048>(fs[2], wb); }
+    if constexpr (DOM) ph_static_for<LA>([&](auto ic) { constexpr int I = decltype(ic)::value; ph_dsr<I * 1024>(fs[I], wb); });
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) :: "memory");
     // piece q of the epilogue: group g = q / 6 (accumulator registers 4g .. 4g+3), step q % 6
     auto piece = [&](auto qc) {
@@ -927,18 +942,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
     if constexpr (DOM) {
       ph_static_for<KS>([&](auto kc) {
         constexpr int K = decltype(kc)::value;
-        constexpr int younger = (KS - 1 - K) < 2 ? (KS - 1 - K) : 2;
-        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[K & 3]) : [n] "n"(younger) : "memory");
+        constexpr int younger = (KS - 1 - K) < LA - 1 ? (KS - 1 - K) : LA - 1;
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[K % NS]) : [n] "n"(younger) : "memory");
         // (the bias rows were requested in front of the fragments: they have landed with the first of these waits; the empty
         // statement keeps the compiler from using their registers any earlier)
         if constexpr (K == 0 && DOE) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
-        if constexpr (K == 0) ph_mma0(fs[0], xf[0].v, zw); else ph_mma(fs[K & 3], xf[K].v, zw);
-        if constexpr (K + 3 < KS) {
-          if constexpr (((K + 3) & 3) == 0) ph_dsr<(K + 3) * 1024>(fs[0], wb);
-          else if constexpr (((K + 3) & 3) == 1) ph_dsr<(K + 3) * 1024>(fs[1], wb);
-          else if constexpr (((K + 3) & 3) == 2) ph_dsr<(K + 3) * 1024>(fs[2], wb);
-          else ph_dsr<(K + 3) * 1024>(fs[3], wb);
-        }
+        if constexpr (K == 0) ph_mma0(fs[0], xf[0].v, zw); else ph_mma(fs[K % NS], xf[K].v, zw);
+        if constexpr (K + LA < KS) ph_dsr<(K + LA) * 1024>(fs[(K + LA) % NS], wb);
         if constexpr (DOE) {
           ph_static_for<(K + 1) * 24 / KS - K * 24 / KS>([&](auto ic) { piece(std::integral_constant<int, K * 24 / KS + decltype(ic)::value>{}); });
         }
@@ -955,12 +965,35 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
+#ifdef PH_PROF
+  // tools/ (a -DPH_PROF build): ticks in [0] the vm wait, [1] the barrier, [2] the DMA issue, [3] the slab bodies -> p.partials rows (debug only)
+  unsigned long long tp[4] = {0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+  auto mark = [&](int k) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tp[k] += t - tl; tl = t; };
+#else
+  auto mark = [](int) {};
+#endif
   auto top = [&](int slab) {
-    // slabs slab, slab + 1 are in flight (only `slab` itself at the very end): wait for the older one, meet, request slab + 2
-    if (slab + 1 < nslab) wait_vm<UPW>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (slab + 2 < nslab) dma(slab + 2, (slab + 2) % NSTAGE);
+    mark(3);
+    // slabs slab, slab + 1 are in flight.  All eight waves requesting slab + 2 at once behind the barrier held every one of them ~490
+    // ticks per slab (32 pieces x 16 cycles of the texture addresser, whose queue is short; spreading the pieces through the body
+    // only moved that time there).  With four buffers slab + 2 goes where slab - 2 was - which every wave has left before the
+    // PREVIOUS barrier - so a wave requests it while it waits for the others, and the last wave to arrive finds the queue empty.
+    // (The last two slabs request the last slab once more, into a free buffer: no branch, constant counts.)
+    if constexpr (NSTAGE == 4) {
+      dma(min(slab + 2, nslab - 1), (slab + 2) % NSTAGE);
+      mark(2);
+      wait_vm<2 * UPW>();                                   // slab has landed: at most slab + 1 and slab + 2 outstanding
+      mark(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (slab + 1 < nslab) wait_vm<UPW>(); else wait_vm<0>();
+      mark(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (slab + 2 < nslab) dma(slab + 2, (slab + 2) % NSTAGE);
+    }
+    mark(1);
   };
   top(0); body(yes{}, no{}, 0, z0, z1);
   int slab = 1;
@@ -976,13 +1009,20 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
     __builtin_amdgcn_s_barrier();
     body(no{}, yes{}, nslab, z1, z0);
   }
+  wait_vm<0>();                                             // (the last requests land in a buffer the epilogue's sums reuse)
+#ifdef PH_PROF
+  mark(3);
+  if (g_ph_prof && blockIdx.y == 0 && blockIdx.x < 256 && lane == 0)
+    for (int k = 0; k < 4; ++k) g_ph_prof[(blockIdx.x * PH_WAVES + wave) * 4 + k] = tp[k];
+#endif
   pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
 }
 
 template <int KS, bool DROP>
 static int launch_pair_fwd_hand(const PairFwdParams& p, hipStream_t st) {
   const size_t slab = (size_t)slab_stride_bytes(KS * 16, 2);
-  size_t sh = 3 * slab + (size_t)p.num_heads * p.D * sizeof(float);
+  const size_t nstage = 4 * slab + 5 * 512 * 4 <= 160 * 1024 ? 4 : 3;      // as in the kernel
+  size_t sh = nstage * slab + (size_t)p.num_heads * p.D * sizeof(float);
   if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_hand_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
     set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
@@ -1574,3 +1614,9 @@ extern "C" int peneo_spots_to_tags(const int32_t* spots_bijt, int n_spots, int B
   hipLaunchKernelGGL(spots_to_tags_kernel, dim3(blocks), dim3(256), 0, st, spots_bijt, n_spots, B, N, tags, status);
   return check_launch("peneo_spots_to_tags");
 }
+
+#ifdef PH_PROF
+extern "C" int peneo_pair_fwd_prof_buffer(unsigned long long* dev) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(peneo::g_ph_prof), &dev, sizeof(dev)) == hipSuccess ? 0 : -1;
+}
+#endif
