@@ -333,7 +333,9 @@ def main():
         l1 = PAIR_HEADS_GFLOP_PER_DOC - 2.0 * (args.seq_len - 1) * args.seq_len / 2 * (pcfg["backbone_config"]["hidden_size"] // 2) * 14 / 1e9
         pb_gflop = 2.0 * l1
         pb_achieved = pb_gflop * B / pb_ms if pb_ms > 0 else 0.0
-        fwd_roof = {"bound": "mfma", "kernel": f"pair_heads_fwd_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},{pcfg['backbone_config']['hidden_size'] // 32}>",
+        ks_f = pcfg['backbone_config']['hidden_size'] // 32      # D / 16; bf16 at 24 / 32: the hand-interleaved kernel (unless switched off)
+        hand = args.dtype == "bf16" and ks_f in (24, 32) and os.environ.get("PENEO_PAIR_FWD_HAND", "1") != "0"
+        fwd_roof = {"bound": "mfma", "kernel": f"pair_heads_fwd_hand_kernel<{ks_f}>" if hand else f"pair_heads_fwd_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},{ks_f}>",
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
