@@ -3,7 +3,7 @@
 
     python tools/timeline.py <..._kernel_trace.csv> [step_index_from_end=2 | +K = K-th train step from the start] [--list] [--gaps]
 
-Splits the trace into steps at every `pair_heads_fwd_kernel` launch of a train step (one per step), takes one steady-state
+Splits the trace into steps at every `pair_heads_fwd_kernel` / `pair_heads_fwd_hand_kernel` launch of a train step (one per step), takes one steady-state
 step and prints: wall span, union busy time, idle time, per-queue busy time, and per kernel name the total duration, the
 time during which it was the ONLY kernel running (exposed time) and the launch count.  `--list` dumps the step's launches
 in start order (offset, duration, queue, name) to follow the critical path by eye."""
@@ -27,7 +27,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "pair_heads_fwd_kernel" in r[3]]
+    marks = [i for i, r in enumerate(rows) if "pair_heads_fwd_kernel" in r[3] or "pair_heads_fwd_hand_kernel" in r[3]]
     # train steps are the pair_heads launches followed by a pair_dz kernel before the next mark
     train = []
     for a, b in zip(marks, marks[1:] + [len(rows)]):
