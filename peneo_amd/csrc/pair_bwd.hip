@@ -264,7 +264,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   const int t_swz = (r32 >> 2) & 3;
   // top of an iteration, both roles: everything this wave put in flight has completed (LDS-DMA pieces: vmcnt; tile /
   // column-sum stores that OTHER waves read: lgkmcnt), then the workgroup meets
-  unsigned long long t_wait = 0, t_vm = 0;
+  unsigned long long t_wait = 0, t_vm = 0, t_land = 0;
   auto top = [&]() {
     if (p.dbg) {
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
   auto report = [&]() {
     if (p.dbg && blockIdx.y == 0 && blockIdx.x < 256 && lane == 0) {
       unsigned long long* d = p.dbg + ((int64_t)blockIdx.x * PW_WAVES + wave) * 4;
-      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_vm; d[2] = t_wait; d[3] = 0;
+      d[0] = __builtin_amdgcn_s_memtime() - t_begin; d[1] = t_vm; d[2] = t_wait; d[3] = t_land;
     }
   };
 
@@ -420,7 +420,14 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         }
       };
       auto landed = [&](pb_u32x4 (&d_)[PB_MAXC]) {
+#ifdef PB_PROF
+        // d[3] of the debug buffer: ticks the producer spends in these waits (fragment reads of the next chunk + its own tile stores)
+        const unsigned long long tl0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]) :: "memory");
+#ifdef PB_PROF
+        if (p.dbg) { const unsigned long long tl1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_land += tl1 - tl0; }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       };
       auto chunk = [&](auto jc, pb_u32x4 (&cur)[PB_MAXC], pb_u32x4 (&nxt)[PB_MAXC]) {

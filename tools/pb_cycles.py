@@ -39,4 +39,4 @@ else:
     d = dbg.view(256, 8, 4).double().cpu()
     for name, sl in (("producers", slice(0, 4)), ("consumers", slice(4, 8))):
         t = d[:, sl]
-        print(f"{name}: loop {t[..., 0].mean():9.0f} ticks ({nslab + 2} iterations -> {t[..., 0].mean() / (nslab + 2):6.0f} / iteration)   s_waitcnt at top {t[..., 1].mean():9.0f} ({100 * t[..., 1].mean() / t[..., 0].mean():4.1f} %)   barrier wait {t[..., 2].mean():9.0f} ({100 * t[..., 2].mean() / t[..., 0].mean():4.1f} %)")
+        print(f"{name}: loop {t[..., 0].mean():9.0f} ticks ({nslab + 2} iterations -> {t[..., 0].mean() / (nslab + 2):6.0f} / iteration)   s_waitcnt at top {t[..., 1].mean():9.0f} ({100 * t[..., 1].mean() / t[..., 0].mean():4.1f} %)   barrier wait {t[..., 2].mean():9.0f} ({100 * t[..., 2].mean() / t[..., 0].mean():4.1f} %)   fragment-read waits (PB_PROF build) {t[..., 3].mean():9.0f} ({100 * t[..., 3].mean() / t[..., 0].mean():4.1f} %)")
