@@ -800,6 +800,43 @@ def test_pair_heads_fwd_and_loss(ops, dtype, N, D):
     assert rel_err(part2.sum(0)[:5], num) < 1e-5
 
 
+@pytest.mark.parametrize("N,D", [(511, 384), (301, 512)])
+def test_pair_heads_fwd_hand_kernel_is_repeatable_at_size(ops, N, D):
+    """The hand-interleaved forward kernel (bf16, D = 384 / 512) issues its MFMAs as inline-asm statements: the compiler knows neither
+    their latency nor that a partner wave shares the matrix pipe.  A hazard there shows up as launch-to-launch differences
+    (as the packed-fp32 one did): three launches of the train-mode call on the same inputs must agree bit for bit in the dlogits and
+    the loss partials, and the eval logits must agree with the fp32 torch computation."""
+    B, classes, dtype = 2, [2, 3, 3, 3, 3], torch.bfloat16
+    g = torch.Generator().manual_seed(N + D)
+    ab = torch.randn(B, N, 2 * D, generator=g).to(DEV).to(dtype)
+    P = N * (N + 1) // 2
+    w1 = [(torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV) for _ in classes]
+    w2 = [(torch.randn(c, D, generator=g) / math.sqrt(D)).to(DEV) for c in classes]
+    b1, b2 = (0.1 * torch.randn(len(classes) * D, generator=g)).to(DEV), torch.randn(14, generator=g).to(DEV)
+    wp = ops.pair_heads_pack(dtype, w1, w2)
+    tags = [torch.randint(0, c, (B, P), generator=g).to(DEV) for c in classes]
+    cw = [torch.tensor([1.0, 10.0, 10.0][:c], device=DEV) for c in classes]
+    ref = None
+    for _ in range(3):
+        _, partials, dlog = ops.pair_heads_fwd(ab, wp, b1, b2, classes, want_logits=False, tags=tags, class_weights=cw, want_dlogits=True,
+                                               drop_p=0.1, drop_seed=77)
+        torch.cuda.synchronize()
+        cur = [partials.clone()] + [d.clone() for d in dlog]
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(cur, ref))
+    logits, _, _ = ops.pair_heads_fwd(ab, wp, b1, b2, classes)
+    ii, jj = torch.triu_indices(N, N, device=DEV)
+    xq = F.silu(ab.float()[:, ii, :D] + ab.float()[:, jj, D:]).to(dtype).float()
+    off = 0
+    for h, c in enumerate(classes):
+        y = F.silu(F.linear(xq, w1[h].to(dtype).float(), b1[h * D:(h + 1) * D])).to(dtype).float()
+        want = F.linear(y, w2[h].to(dtype).float(), b2[off:off + c])
+        assert (logits[h] - want).abs().max() < 3e-2, h
+        off += c
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,D", [(39, 32), (71, 96), (130, 384), (70, 512)])
 def test_pair_heads_fwd_classifier_dropout(ops, dtype, N, D):
