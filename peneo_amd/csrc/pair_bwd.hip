@@ -419,12 +419,14 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
           if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], ((F0 + 2) & 1) ? za1 : za0);
         }
       };
-      auto landed = [&](pb_u32x4 (&d_)[PB_MAXC]) {
+      auto landed = [&](pb_u32x4 (&d_)[PB_MAXC], auto in_chunk) {
 #ifdef PB_PROF
         // d[3] of the debug buffer: ticks the producer spends in these waits (fragment reads of the next chunk + its own tile stores)
         const unsigned long long tl0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]) :: "memory");
+        // the next chunk's fragments have landed; the dz tile store this chunk just issued (younger, and the LDS completes a wave's
+        // operations in order) may still be in flight: waiting for it too cost the producers a store latency per chunk
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]) : [n] "n"((DOE && decltype(in_chunk)::value) ? 1 : 0) : "memory");
 #ifdef PB_PROF
         if (p.dbg) { const unsigned long long tl1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_land += tl1 - tl0; }
 #endif
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
           const int f = ((rowc >> 2) + half) & 3;
           *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
         }
-        if constexpr (J + 1 < 8) landed(nxt);
+        if constexpr (J + 1 < 8) landed(nxt, std::true_type{});
       };
       // the first chunk's fragments are in LDS since the barrier: their read latency runs under the LDS-DMA issue block,
       // the column-sum flush and the dlogits staging (`pre`)
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         const pb_u32x4 w2f = pb_u32x4{half ? 0u : cw2.x, half ? 0u : cw2.y, 0u, 0u};
         pb_mma(gA, w2f, dy);
       }
-      landed(fa);
+      landed(fa, std::false_type{});
       chunk(std::integral_constant<int, 0>{}, fa, fb);
       chunk(std::integral_constant<int, 1>{}, fb, fa);
       chunk(std::integral_constant<int, 2>{}, fa, fb);
