@@ -19,6 +19,7 @@
 // domain in fp32.  scores = scale * q.k + bias (reference: modeling_layoutlmv3.py:365-389).
 #include <cstdlib>
 #include "common.h"
+#include "attention.h"
 
 namespace peneo {
 
@@ -44,9 +45,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // single-pass backward (lane = key, registers = queries) loads its key's dword per 32-query block and takes register r's
 // bit with one v_bfe_i32 (0 / -1), used as an AND mask on P and on keep_scale.  1 / (1 - p) is applied once to the
 // accumulators (O, dV), not per element.
-__host__ __device__ __forceinline__ int attn_kslot(int key) {
-  return (key & ~31) | (((key >> 3) & 3) << 3) | ((key & 3) << 1) | ((key >> 2) & 1);
-}
+// (attn_kslot: attention.h)
 __device__ __forceinline__ bool attn_word_keep(const uint32_t* words_bh, int Tk, int q, int key) {
   return (words_bh[(int64_t)(q >> 5) * Tk + attn_kslot(key)] >> (q & 31)) & 1u;
 }
@@ -245,16 +244,6 @@ __device__ __forceinline__ void bias_read4(const char* tile, int row, int col, f
   }
 }
 
-struct AttnParams {
-  const void* q; const void* k; const void* v; int64_t ld;
-  const void* vt; const void* kt; const void* qt; const void* dot;  // [B, nh, DP, Tp] transposed copies
-  int B, nh, T, d, Tp; float scale;
-  const void* bias; int64_t bias_ld; const float* key_bias;       // bias [B, nh, T, bias_ld]; key_bias [B, Tp]
-  void* out; int64_t ld_out; float* lse;
-  float drop_p, keep_scale; const uint32_t* words; int nqb, Tk;   // dropout keep bits (peneo_attn_drop_words) or NULL
-  const void* d_out; void* dq; void* dk; void* dv; int64_t ld_d; float* g_bias; float* delta;
-  void* ds_out;   // single-pass backward only: bf16 dS^T [B, nh, T keys, Tp queries] of this layer (or NULL)
-};
 
 // 8 elements of row `row` starting at column c of a [rows, ld] matrix -> fragment (zero beyond rmax / cmax)
 template <typename T>
@@ -1319,6 +1308,18 @@ static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
       if (dq_acc && hipMemsetAsync(dq_acc, 0, sizeof(float) * R * cols, st) != hipSuccess) {
         set_error("peneo_attn_bwd: memset of the dQ accumulator failed");
         return PENEO_ERR_LAUNCH;
+      }
+      if constexpr (DP == 64) {
+        if (dq_from_ds && attn_bwd_pipe_supported(p)) {   // the pipelined form (attn_bwd_pipe.hip) + dQ from its dS^T slab
+          rc = launch_attn_bwd_pipe(p, st);
+          if (rc) return rc;
+          size_t sq = dqs_smem<DP>();
+          rc = set_smem(attn_dq_from_ds_kernel<DP>, sq);
+          if (rc) return rc;
+          dim3 qgrid((p.T + AQ - 1) / AQ, p.nh, p.B);
+          hipLaunchKernelGGL((attn_dq_from_ds_kernel<DP>), qgrid, dim3(256), sq, st, p);
+          return check_launch("peneo_attn_bwd(dq from dS)");
+        }
       }
       size_t sf = fused_smem<DP>();
       dim3 fgrid((p.T + FKEYS - 1) / FKEYS, p.nh, p.B);
