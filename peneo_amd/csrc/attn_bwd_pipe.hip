@@ -32,9 +32,15 @@ namespace {
 constexpr int TQ = 32;     // queries per tile
 constexpr int WK = 128;    // keys per workgroup (4 waves x 32)
 constexpr int O_Q = 0, O_DO = 4096, O_BIAS = 8192, O_LSE = 16384, O_DELTA = 16640, O_WORDS = 16896, BUF = 17408;
-constexpr int NBUF = 3;
 constexpr int STG_PITCH = 80, STG_WAVE = 32 * STG_PITCH;
-constexpr int LDS_BYTES = NBUF * BUF + 4 * STG_WAVE;
+// OCC = workgroups per CU.  2: ring of three buffers, S(t + 1) computed at the end of iteration t (202 registers).  3: ring of two,
+// S at the top of its own iteration, the softmax arithmetic and the dV / dK products in two halves of 16 queries (168 registers, 45 KB
+// of LDS): all 576 workgroups of 8 documents are resident at once (768 slots) instead of 512 + a second round of 64 that takes as
+// long as the first - a wave's 23 tiles are the unit of time
+constexpr int ring_of(int occ) { return occ >= 3 ? 2 : 3; }
+// (OCC 3 has no dS^T patch - the rows go out straight from registers - and keeps the K fragments in LDS: 16 KB, a hand-made spill,
+// every lane reads back its own 64 bytes; 50.8 KB per workgroup)
+constexpr int lds_bytes_of(int occ) { return ring_of(occ) * BUF + (occ >= 3 ? 4 * 4096 : 4 * STG_WAVE); }
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ float g_lse_pad = 1.0e30f;   // lse of query rows past T
@@ -67,9 +73,11 @@ __device__ __forceinline__ void dma4_v(const char* ptr_lane, uint32_t lds_unifor
 }
 __device__ __forceinline__ uint32_t and_u(float x, int m) { return __float_as_uint(x) & (uint32_t)m; }
 
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
+template <bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_pipe_kernel(AttnParams p) {
   typedef bf16_t T;
+  constexpr int NBUF = ring_of(OCC);
+  constexpr bool PF = NBUF == 3;       // S one tile ahead
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,6 +122,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
     asm volatile("" : "+v"(vf[ks].v.x), "+v"(vf[ks].v.y), "+v"(vf[ks].v.z), "+v"(vf[ks].v.w));
   }
 
+  // OCC 3: the K fragments live in LDS ([wave][k-step][lane] x 16 B, private to the lane that wrote them: no barrier)
+  char* kspill = smem + NBUF * BUF + wave * 4096 + lane * 16;
+  if constexpr (!PF) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<uint4*>(kspill + 1024 * ks) = kf[ks].v;
+  }
+
   // ---- DMA sources of this wave's pieces (lane constants; a tile adds a uniform base) ----
   const uint32_t lds0 = lds_addr(smem);
   const int qrow = 8 * wave + (lane >> 3);                               // Q / dO piece `wave`: rows 8 wave .. 8 wave + 7
@@ -146,12 +161,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
   };
 
   // ---- LDS read addresses (lane constants relative to a buffer) ----
-  int aS[4];
-  {
-    const int sg = qslot_swz(l31);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) aS[ks] = l31 * 128 + (((2 * ks + half) ^ sg) << 4);
-  }
+  // S / dP fragment of k-step ks: row l31, slot (2 ks + half) ^ swz = base ^ (ks << 5)
+  const int aS0 = l31 * 128 + ((half ^ qslot_swz(l31)) << 4);
   const int li = lane & 15, lj = (lane >> 4) & 1;
   int aT[2][2];                                      // transpose reads of the Q / dO tile: [d tile][rows +0 / +8]; + 2048 kk
 #pragma unroll
@@ -167,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
   char* stg = smem + NBUF * BUF + wave * STG_WAVE;
   char* stg_w = stg + l31 * STG_PITCH + 8 * half;                       // + 16 g
   const char* stg_r = stg + (lane >> 2) * STG_PITCH + (lane & 3) * 16;  // + 16 rows: STG_PITCH * 16
-  T* slab = reinterpret_cast<T*>(p.ds_out) + ((int64_t)bh * Tn + key0 + wave * 32) * (int64_t)Tp;
+  T* slab = reinterpret_cast<T*>(p.ds_out) + ((int64_t)bh * Tn + key0 + wave * 32) * (int64_t)Tp;   // uniform
+  const int slab_l = (lane >> 2) * Tp + (lane & 3) * 8;                                              // + 16 rows: 16 Tp
+  const int slab_k = l31 * Tp + 8 * half;                                                            // OCC 3: lane = key, 8 queries
 
   f32x16_t dk[2], dv[2], s;
 #pragma unroll
@@ -179,9 +192,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      Frag<T> a;
-      a.v = *reinterpret_cast<const uint4*>(buf + O_Q + aS[ks]);
-      mma_step(a, kf[ks], acc);
+      Frag<T> a, kb_;
+      a.v = *reinterpret_cast<const uint4*>(buf + O_Q + (aS0 ^ (ks << 5)));
+      if constexpr (PF) kb_ = kf[ks]; else kb_.v = *reinterpret_cast<const uint4*>(kspill + 1024 * ks);
+      mma_step(a, kb_, acc);
     }
     return acc;
   };
@@ -190,26 +204,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
     for (int i = 0; i < 2; ++i) {
       const int row = (lane >> 2) + 16 * i;
       const uint4 v = *reinterpret_cast<const uint4*>(stg_r + i * 16 * STG_PITCH);
-      if (key0 + wave * 32 + row < Tn) *reinterpret_cast<uint4*>(slab + (int64_t)row * Tp + tt * TQ + (lane & 3) * 8) = v;
+      if (key0 + wave * 32 + row < Tn) *reinterpret_cast<uint4*>(slab + tt * TQ + 16 * i * Tp + slab_l) = v;
     }
   };
 
   dma_tile(0, 0);
-  if (nt > 1) dma_tile(1, 1);
+  if (PF && nt > 1) dma_tile(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  s = s_tile(smem);
+  if constexpr (PF) s = s_tile(smem);
 
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     const int nxt = cur == NBUF - 1 ? 0 : cur + 1;
     if (t > 0) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile t + 1 has landed (and the stores of tile t - 2 are out)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next tile has landed (and the stores of tile t - 2 are out)
       __builtin_amdgcn_s_barrier();
     }
-    if (t + 2 < nt) dma_tile(t + 2, nxt == NBUF - 1 ? 0 : nxt + 1);
-    if (t > 0) flush(t - 1);
+    if constexpr (PF) { if (t + 2 < nt) dma_tile(t + 2, nxt == NBUF - 1 ? 0 : nxt + 1); }
+    else { if (t + 1 < nt) dma_tile(t + 1, nxt); }
+    if constexpr (PF) { if (t > 0) flush(t - 1); }
     const char* buf = smem + cur * BUF;
+    if constexpr (!PF) s = s_tile(buf);
 
     // dP[q, key] = dO . V^T
     f32x16_t dp;
@@ -218,45 +234,51 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       Frag<T> a;
-      a.v = *reinterpret_cast<const uint4*>(buf + O_DO + aS[ks]);
+      a.v = *reinterpret_cast<const uint4*>(buf + O_DO + (aS0 ^ (ks << 5)));
       mma_step(a, vf[ks], dp);
     }
-    // P = exp2((S scale + bias) log2e - lse); dS = P (dP keep / (1 - p) - delta); bf16 pairs in MFMA operand order
     uint32_t cw = 0u;
     if constexpr (DROP) cw = *reinterpret_cast<const uint32_t*>(buf + O_WORDS + aW) >> (4 * half);
-    uint32_t pp[8], dd[8];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 l4 = *reinterpret_cast<const float4*>(buf + O_LSE + 16 * half + 32 * g);
-      const float4 d4 = *reinterpret_cast<const float4*>(buf + O_DELTA + 16 * half + 32 * g);
-      const uint2 bu = tr64(buf + O_BIAS + aB + 2048 * g);
-      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-      const float bf[4] = {__uint_as_float(bu.x << 16), __uint_as_float(bu.x & 0xffff0000u), __uint_as_float(bu.y << 16),
-                           __uint_as_float(bu.y & 0xffff0000u)};
-      float pd[4], ds[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const float pv = __builtin_amdgcn_exp2f(fmaf(fmaf(s[r], p.scale, bf[e]), kLog2e, -lv[e]));   // (bit for bit the fused kernel's order)
-        if constexpr (DROP) {
-          const int m = __builtin_amdgcn_sbfe((int)cw, 8 * g + e, 1);   // 0 / -1: bit (8 g + e) = this lane's query of register r
-          pd[e] = __uint_as_float(and_u(pv, m));                        // (1 / (1 - p) goes onto dV once, at the end)
-          ds[e] = pv * fmaf(dp[r], __uint_as_float(and_u(keep_scale, m)), -dl[e]);
-        } else {
-          pd[e] = pv;
-          ds[e] = pv * (dp[r] - dl[e]);
-        }
-      }
-      pp[2 * g] = pack_bf16x2(pd[0], pd[1]); pp[2 * g + 1] = pack_bf16x2(pd[2], pd[3]);
-      dd[2 * g] = pack_bf16x2(ds[0], ds[1]); dd[2 * g + 1] = pack_bf16x2(ds[2], ds[3]);
-      *reinterpret_cast<uint2*>(stg_w + 16 * g) = make_uint2(dd[2 * g], dd[2 * g + 1]);
-    }
-    // dV^T[d, key] += dO^T[d, q] . P[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      // P = exp2((S scale + bias) log2e - lse); dS = P (dP keep / (1 - p) - delta); bf16 pairs in MFMA operand order
+      uint32_t pp[4], dd[4];
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = 2 * kk + gg;
+        const float4 l4 = *reinterpret_cast<const float4*>(buf + O_LSE + 16 * half + 32 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(buf + O_DELTA + 16 * half + 32 * g);
+        const uint2 bu = tr64(buf + O_BIAS + aB + 2048 * g);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float bf[4] = {__uint_as_float(bu.x << 16), __uint_as_float(bu.x & 0xffff0000u), __uint_as_float(bu.y << 16),
+                             __uint_as_float(bu.y & 0xffff0000u)};
+        float pd[4], ds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pv = __builtin_amdgcn_exp2f(fmaf(fmaf(s[r], p.scale, bf[e]), kLog2e, -lv[e]));   // (bit for bit the fused kernel's order)
+          if constexpr (DROP) {
+            const int m = __builtin_amdgcn_sbfe((int)cw, 8 * g + e, 1);   // 0 / -1: bit (8 g + e) = this lane's query of register r
+            pd[e] = __uint_as_float(and_u(pv, m));                        // (1 / (1 - p) goes onto dV once, at the end)
+            ds[e] = pv * fmaf(dp[r], __uint_as_float(and_u(keep_scale, m)), -dl[e]);
+          } else {
+            pd[e] = pv;
+            ds[e] = pv * (dp[r] - dl[e]);
+          }
+        }
+        pp[2 * gg] = pack_bf16x2(pd[0], pd[1]); pp[2 * gg + 1] = pack_bf16x2(pd[2], pd[3]);
+        dd[2 * gg] = pack_bf16x2(ds[0], ds[1]); dd[2 * gg + 1] = pack_bf16x2(ds[2], ds[3]);
+        if constexpr (PF) *reinterpret_cast<uint2*>(stg_w + 16 * g) = make_uint2(dd[2 * gg], dd[2 * gg + 1]);
+      }
+      if constexpr (!PF) {   // dS^T of these 16 queries: two groups and a v_permlane32_swap make 16 contiguous bytes per lane
+        const auto rx = __builtin_amdgcn_permlane32_swap(dd[0], dd[2], false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(dd[1], dd[3], false, false);
+        if (mykey < Tn) *reinterpret_cast<uint4*>(slab + t * TQ + 16 * kk + slab_k) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+      }
+      // dV^T[d, key] += dO^T[d, q] . P[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]   (these 16 queries)
       Frag<T> pf, dsf;
-      pf.v = make_uint4(pp[4 * kk], pp[4 * kk + 1], pp[4 * kk + 2], pp[4 * kk + 3]);
-      dsf.v = make_uint4(dd[4 * kk], dd[4 * kk + 1], dd[4 * kk + 2], dd[4 * kk + 3]);
+      pf.v = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+      dsf.v = make_uint4(dd[0], dd[1], dd[2], dd[3]);
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
         const Frag<T> dot = tr_frag(buf + O_DO + 2048 * kk + aT[t2][0], buf + O_DO + 2048 * kk + aT[t2][1]);
@@ -264,17 +286,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
         const Frag<T> qtf = tr_frag(buf + O_Q + 2048 * kk + aT[t2][0], buf + O_Q + 2048 * kk + aT[t2][1]);
         mma_step(qtf, dsf, dk[t2]);
       }
+      if constexpr (!PF) __builtin_amdgcn_sched_barrier(0);   // (register budget: the second half starts after the first has gone)
     }
-    if (t + 1 < nt) s = s_tile(smem + nxt * BUF);
+    if constexpr (PF) { if (t + 1 < nt) s = s_tile(smem + nxt * BUF); }
     cur = nxt;
   }
-  flush(nt - 1);
+  if constexpr (PF) flush(nt - 1);
   // the slab's columns between the last tile and Tp stay zero (its readers load whole 16-byte groups up to Tp)
   for (int c = nt * TQ; c < Tp; c += TQ) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = (lane >> 2) + 16 * i;
-      if (key0 + wave * 32 + row < Tn) *reinterpret_cast<uint4*>(slab + (int64_t)row * Tp + c + (lane & 3) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      if (key0 + wave * 32 + row < Tn) *reinterpret_cast<uint4*>(slab + c + 16 * i * Tp + slab_l) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
 
@@ -317,15 +340,19 @@ bool attn_bwd_pipe_supported(const AttnParams& p) {
 int launch_attn_bwd_pipe(const AttnParams& p, hipStream_t st) {
   const int nkb = (p.T + WK - 1) / WK;
   const dim3 grid((unsigned)((int64_t)nkb * p.nh * p.B));
-  auto go = [&](auto kern) -> int {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      set_error("peneo_attn_bwd: cannot raise dynamic LDS to %d bytes", LDS_BYTES);
+  auto go = [&](auto kern, int lds) -> int {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("peneo_attn_bwd: cannot raise dynamic LDS to %d bytes", lds);
       return PENEO_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     return check_launch("peneo_attn_bwd(pipe)");
   };
-  return p.drop_p > 0.f ? go(attn_bwd_pipe_kernel<true>) : go(attn_bwd_pipe_kernel<false>);
+  // three workgroups per CU when two per CU would need a second round (a grid that fits 512 slots runs the deeper ring)
+  static const int force = [] { const char* e = getenv("PENEO_ATTN_BWD_OCC"); return e ? atoi(e) : 0; }();
+  const bool three = force ? force >= 3 : grid.x > 512;
+  if (three) return p.drop_p > 0.f ? go(attn_bwd_pipe_kernel<true, 3>, lds_bytes_of(3)) : go(attn_bwd_pipe_kernel<false, 3>, lds_bytes_of(3));
+  return p.drop_p > 0.f ? go(attn_bwd_pipe_kernel<true, 2>, lds_bytes_of(2)) : go(attn_bwd_pipe_kernel<false, 2>, lds_bytes_of(2));
 }
 
 }  // namespace peneo

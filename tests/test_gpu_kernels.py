@@ -660,6 +660,38 @@ def test_attention_key_bias_only(ops, dtype):
     assert rel_err(dqkv, leaf.grad) < (3e-5 if dtype == torch.float32 else 4e-2)
 
 
+@pytest.mark.parametrize("B,nh,T,drop", [(1, 2, 709, 0.0), (2, 3, 709, 0.1), (2, 2, 200, 0.2), (1, 1, 64, 0.1), (2, 2, 33, 0.0),
+                                         (1, 16, 1221, 0.1), (1, 2, 129, 0.1), (33, 16, 64, 0.1)])
+def test_attention_bwd_pipelined_kernel_is_the_fused_kernel_bit_for_bit(ops, B, nh, T, drop):
+    """attn_bwd_pipe.hip (LDS-DMA ring, one barrier per 32-query tile; what a bias + dS^T-slab call at head dim 64 runs) against
+    attn_bwd_fused_kernel, which a call that also asks for the fp32 bias gradient still runs: same arithmetic in the same order, so
+    dq | dk | dv and the dS^T slab must be IDENTICAL (the fused kernel itself is held to fp32 autograd by test_attention_fwd_bwd).
+    Ragged tails in both directions (T = 709 / 1221 / 129 / 33), masked keys, the padding columns of the slab, and a grid of more
+    than 512 workgroups (33 x 16: the three-per-CU instantiation with the K fragments in LDS and no dS^T patch)."""
+    d, H = 64, nh * 64
+    g = torch.Generator().manual_seed(T + int(drop * 100))
+    qkv = torch.randn(B * T, 3 * H, generator=g).to(DEV).to(torch.bfloat16)
+    Tp = ops.attn_padded_len(T)
+    bias = torch.full((B, nh, T, Tp), -1.0e30, dtype=torch.bfloat16, device=DEV)
+    bias[..., :T] = (0.5 * torch.randn(B, nh, T, T, generator=g)).to(DEV).to(torch.bfloat16)
+    bias[0, :, :, T // 3: T // 2] = -1.0e30
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    out, lse = ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_seed=5)
+    d_out = torch.randn(B * T, H, generator=g).to(DEV).to(torch.bfloat16)
+    res = []
+    for fused in (True, False):
+        dqkv = torch.full_like(qkv, 3.0)
+        ds = torch.full((B, nh, T, Tp), 7.0, device=DEV, dtype=torch.bfloat16)
+        gb = torch.zeros(bias.shape, dtype=torch.float32, device=DEV) if fused else None
+        ops.attn_bwd(q, k, v, out, d_out, lse, B, nh, T, d, 0.125, bias, None, dqkv, gb, drop_p=drop, drop_seed=5, ds_out=ds)
+        res.append((dqkv, ds))
+    assert bool(torch.isfinite(res[1][0].float()).all())
+    assert torch.equal(res[0][0], res[1][0]), "dq | dk | dv"
+    assert torch.equal(res[0][1], res[1][1]), "dS^T slab"
+    if Tp > T:
+        assert float(res[1][1][..., T:].float().abs().max()) == 0.0
+
+
 def test_head_transpose(ops):
     B, nh, T, d = 2, 3, 70, 30
     x = torch.randn(B * T, nh * d + 6, device=DEV)
