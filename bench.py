@@ -127,13 +127,13 @@ def plan_launch(gpus: int, environ) -> tuple:
 def spawn_ranks(n: int, argv) -> int:
     """Start `n` fresh rank processes of this script under torch.distributed.run and relay their output and exit code.  The
     parent never touches the GPU (no HIP call, no torch.cuda.is_available()): the ranks are children, not re-execs."""
-    import socket
     import subprocess
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    import uuid
+    # the launcher picks AND HOLDS the rendezvous port itself (c10d store on 127.0.0.1:0): a port found by bind / close here could be
+    # taken by another process before the ranks connect (concurrent bench runs or tests on one box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", f"--rdzv-id=peneo-{uuid.uuid4().hex[:12]}", "--local-addr", "127.0.0.1",
+           os.path.abspath(__file__), *argv]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -339,6 +339,7 @@ def main():
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                     "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
+                    "traffic_source": "profiles/pmc_traffic.json (recorded rocprofv3 --pmc passes, not measured by this run)",
                     "avg_launch_ms": round(ph_ms, 4), "launches": len(ph)}
         if pb_ms > 0:
             ks = pcfg['backbone_config']['hidden_size'] // 32       # D / 16: 24 -> the wave-specialised kernel, 32 -> the one-wave kernel
@@ -346,6 +347,7 @@ def main():
                         "achieved": round(pb_achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(pb_achieved / PEAK_BF16_TFLOPS, 4),
                         "traffic": pmc_traffic_bytes("pair_bwd_fused_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
+                        "traffic_source": "profiles/pmc_traffic.json (recorded rocprofv3 --pmc passes, not measured by this run)",
                         "avg_launch_ms": round(pb_ms, 4), "launches": len(pb)}
         else:
             dom_roof = fwd_roof

@@ -403,8 +403,11 @@ int peneo_pair_dz_fused(int dtype, const void* ab_doc, int N, int D, int i0, int
  * args->dlogits[h] is the whole [B, P, classes[h]] map, args->scale the device vector of peneo_loss_finish.
  * Replaces, per document, peneo_pair_x_fwd + peneo_pair_dz_fused + the du GEMM (grad_src epilogue) + peneo_pair_x_bwd:
  * the autograd graph through model/peneo_decoder.py:149-177 and :231-292 except the first-layer weight gradient.
- * `w_packed`: peneo_pair_bwd_pack (per 32-unit slab the B-operand fragments of both products). */
-int peneo_pair_bwd_supported(int dtype, int D);
+ * `w_packed`: peneo_pair_bwd_pack (per 32-unit slab the B-operand fragments of both products).
+ * peneo_pair_bwd_supported: 1 when the fused launch exists for (dtype, D) AND its LDS image fits `num_heads` heads (the per-column
+ * table grows with the head count: D = 512 holds 5 heads, not 6); num_heads <= 0 asks about (dtype, D) only.  On 0 a caller runs
+ * the per-document chain (peneo_pair_x_fwd / peneo_pair_dz_fused / peneo_gemm / peneo_pair_x_bwd). */
+int peneo_pair_bwd_supported(int dtype, int D, int num_heads);
 int64_t peneo_pair_bwd_rows(int N);
 size_t peneo_pair_bwd_packed_bytes(int num_heads, int D);
 int peneo_pair_bwd_pack(const float* const* w1 /* host array of num_heads device pointers to [D, D] fp32 */, int num_heads, int D,
@@ -532,6 +535,12 @@ int peneo_spots_to_tags(const int32_t* spots_bijt, int n_spots, int B, int N, in
                         peneo_stream_t stream);
 int peneo_spots_compact(const float* logits, int64_t P, int C, int N, int32_t* spots_ijt, float* scores,
                         int32_t* count, int max_spots, peneo_stream_t stream);
+
+/* ---- diagnostics: NOT part of the thread-safety contract -------------------------------------------------------------
+ * Process-wide switch of the forward GEMM tile choice (gemm_big.hip): 0 = always the 128 x 128 kernel, 1 = the calibrated
+ * choice (default; also set by PENEO_GEMM_BIG), 256 / 384 / 128 = force one big-tile shape where its constraints hold.  A plain
+ * global: set it while no peneo_gemm call is in flight on any thread.  Used by the kernel tests and tools/ only. */
+void peneo_gemm_set_big_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -157,14 +157,19 @@ __device__ __forceinline__ bool dropout_keep_b(uint32_t base, uint32_t lo, uint3
 // of the forward kernel holds (accumulator rows 8g + 4 half + e of its pair).  Each (document, pair, slab, half) owns a
 // chain of 16 fields: a two-round 24-bit-multiply mixer (full-rate v_mul_u32_u24, as the attention mask) of the counter
 // seeds it, then one v_mad_u32_u24 per field:
-//     st_0 = mix24(((p * nslab + slab) * 2 + h) ^ key(seed, b));  st_{i+1} = (st_i[23:0] * 0xC2B2AF + 0x9E3779) mod 2^32
+//     st_0 = mix24((((p * nslab + slab) * 2 + h) ^ key(seed, b)) * 0x9E3779B1);  st_{i+1} = (st_i[23:0] * 0xC2B2AF + 0x9E3779) mod 2^32
 //     keep(unit 8 (i >> 2) + 4 h + (i & 3)) = (st_{i+1} >> 16) >= p_drop * 2^16
 // i.e. 1.5 integer operations per element instead of a hash each (the mask generation was 27 % of the forward kernel).
 // Backward kernels regenerate the same bits.  tools/check_dropout_hash.py: keep rate, neighbour / slab / pair correlations
 // and count statistics at the noise floor.
 __device__ __forceinline__ uint32_t pair_drop_key(uint32_t seed, int b) { return mix32(seed ^ ((uint32_t)(b + 1) * 0x9e3779b9u)); }
 __device__ __forceinline__ uint32_t pair_drop_seed(uint32_t key, uint32_t counter /* (p * nslab + slab) * 2 + half */) {
-  uint32_t x = counter ^ key;
+  // One full 32-bit multiply in front of the 24-bit mixer (round 5): the v_mul_u32_u24 rounds read 24 bits, so without it bits 24..31
+  // of the counter entered only through the x >> 16 fold and counters c and c ^ 0x01000100 seeded the SAME chain - a structural
+  // duplicate at a fixed far offset for every chain once the counter passes 2^24 (config 4: N = 1023, 80 slabs -> 83.8 M chains).
+  // An odd multiplier is a bijection on 32 bits and carries every counter bit into the bits the mixer reads; collisions above
+  // 2^24 chains are now the birthday kind (tools/check_dropout_hash.py counts both).  One quarter-rate instruction per 16 elements.
+  uint32_t x = (counter ^ key) * 0x9E3779B1u;
   x ^= x >> 16; x = __umul24(x, 0x9E3779u); x ^= x >> 13; x = __umul24(x, 0x85EBCBu); x ^= x >> 16;
   return x;
 }

@@ -1237,14 +1237,27 @@ static int launch_pair_bwd_1w(const PairBwdParams& p, hipStream_t st) {
 }  // namespace peneo
 using namespace peneo;
 
+#ifdef PB_PROF
 static unsigned long long* g_pb_dbg = nullptr;
-/* tools/ only (not in the header): device buffer [256 blocks][8 waves][4] that receives per-wave cycle counts of the
- * wave-specialised kernel: loop cycles, cycles in s_waitcnt at the top of the iterations, cycles in the barrier */
+/* instrumented builds only (tools/prof_build.sh pairbwd; not part of the product library or its header): device buffer
+ * [256 blocks][8 waves][4] that receives per-wave cycle counts of the wave-specialised kernel */
 extern "C" void peneo_pair_bwd_debug_buffer(unsigned long long* dev) { g_pb_dbg = dev; }
+#else
+static unsigned long long* const g_pb_dbg = nullptr;
+#endif
 
-extern "C" int peneo_pair_bwd_supported(int dtype, int D) {
+// LDS of a launch (the formulas of launch_pair_bwd_one / launch_pair_bwd_ws): the weight ring, 12 bytes per hidden column, the rest
+static size_t pair_bwd_lds_bytes(int D, int num_heads) {
+  const size_t ks = (size_t)D / 16, ncol = (size_t)num_heads * D;
+  if (ks == 32) return 3 * ks * 1024 + ncol * 12 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)4 * 32 * 80;
+  return 4 * ks * 1024 + ncol * 12 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048 + (size_t)2 * 4 * 32 * 32 * 2;
+}
+extern "C" int peneo_pair_bwd_supported(int dtype, int D, int num_heads) {
   const int ks = D / 16;
-  return dtype == PENEO_BF16 && D % 32 == 0 && (ks == 2 || ks == 4 || ks == 8 || ks == 24 || ks == 32);
+  if (!(dtype == PENEO_BF16 && D % 32 == 0 && (ks == 2 || ks == 4 || ks == 8 || ks == 24 || ks == 32))) return 0;
+  if (num_heads > PENEO_MAX_HEADS) return 0;
+  // the per-column table grows with the head count: D = 512 fits 5 heads (161 792 B) but not 6; a caller that gets 0 runs the chunked path
+  return num_heads <= 0 || pair_bwd_lds_bytes(D, num_heads) <= (size_t)160 * 1024;
 }
 
 extern "C" int64_t peneo_pair_bwd_rows(int N) { return N > 0 ? (int64_t)pb_num_tiles(N) * PB_ROWS : 0; }
@@ -1267,7 +1280,9 @@ extern "C" size_t peneo_pair_bwd_partial_bytes(int B, int N, int D) {
 extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int D, const void* w_packed, const float* b1,
                                     const peneo_pair_dz_args* args, void* dz, void* x, float* d_ab, float* workspace,
                                     float* partials, peneo_stream_t stream) {
-  PENEO_REQUIRE(peneo_pair_bwd_supported(dtype, D), "peneo_pair_bwd_fused: bf16 and D/16 in {2, 4, 8, 24, 32} only (got D=%d)", D);
+  PENEO_REQUIRE(peneo_pair_bwd_supported(dtype, D, 0), "peneo_pair_bwd_fused: bf16 and D/16 in {2, 4, 8, 24, 32} only (got D=%d)", D);
+  PENEO_REQUIRE(args && peneo_pair_bwd_supported(dtype, D, args->num_heads),
+                "peneo_pair_bwd_fused: %d heads at D=%d need more than 160 KiB of LDS (ask peneo_pair_bwd_supported first)", args ? args->num_heads : 0, D);
   PENEO_REQUIRE(ab && w_packed && b1 && args && dz && x && d_ab && workspace && partials && B > 0 && N > 0, "peneo_pair_bwd_fused: bad arguments");
   PENEO_REQUIRE(args->num_heads > 0 && args->num_heads <= PENEO_MAX_HEADS && args->D == D && args->scale, "peneo_pair_bwd_fused: bad head description");
   PENEO_REQUIRE(args->num_heads * D >= 64, "peneo_pair_bwd_fused: needs at least two 32-unit slabs of hidden units");

@@ -37,19 +37,26 @@ int gemm(int ak, int bk, int M, int N, int K, const void* A, int64_t lda, const 
                     split > 1 ? ws.n : 0, st);
 }
 
-// two reusable events per device for the main -> side hand-offs of a backward (a wait captures the record that precedes it,
-// so re-recording an event for the next layer does not disturb waits already enqueued)
+// two reusable events per (host thread, device) for the main -> side hand-offs of a backward (a wait captures the record that
+// precedes it, so re-recording an event for the next layer does not disturb waits already enqueued).  Per THREAD: two host threads
+// running backwards on one device with different stream pairs must not interleave record / wait on one event (round-4 review); a
+// thread's events are destroyed when it exits.
 struct DevEvents { hipEvent_t e[2]; bool ok; };
+struct ThreadEvents {
+  DevEvents tab[64] = {};
+  ~ThreadEvents() {
+    for (DevEvents& d : tab)
+      if (d.ok) { (void)hipEventDestroy(d.e[0]); (void)hipEventDestroy(d.e[1]); }
+  }
+};
 DevEvents* events_of_current_device() {
-  static std::mutex mu;
-  static DevEvents tab[64] = {};
+  static thread_local ThreadEvents mine;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  DevEvents& d = tab[dev];
+  DevEvents& d = mine.tab[dev];
   if (!d.ok) {
-    for (int i = 0; i < 2; ++i)
-      if (hipEventCreateWithFlags(&d.e[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&d.e[0], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&d.e[1], hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(d.e[0]); return nullptr; }
     d.ok = true;
   }
   return &d;

@@ -142,7 +142,7 @@ SIGNATURES = {
     "peneo_pair_loss_partials": (_i64, [_i, _i]),
     "peneo_loss_finish": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "peneo_weighted_ce": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),
-    "peneo_pair_bwd_supported": (_i, [_i, _i]),
+    "peneo_pair_bwd_supported": (_i, [_i, _i, _i]),
     "peneo_pair_bwd_rows": (_i64, [_i]),
     "peneo_pair_bwd_packed_bytes": (_sz, [_i, _i]),
     "peneo_pair_bwd_pack": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -162,6 +162,7 @@ SIGNATURES = {
     "peneo_encoder_layer_bwd": (_i, [_vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "peneo_gemm_set_big_mode": (None, [_i]),    # diagnostics block of the header: process-wide, not thread-safe
 }
 
 _lib: Optional[C.CDLL] = None

@@ -218,9 +218,14 @@ JOINS_BEFORE_READ = "_peneo_joins_before_read"
 
 
 def mark_late(params) -> None:
-    import weakref
     for p in params:
-        _LATE[id(p)] = weakref.ref(p)
+        key = id(p)
+        # the weak reference's callback drops the entry when the parameter dies (the table does not grow across model rebuilds);
+        # it only deletes an entry that still is this reference: the id may have been re-registered by a new parameter meanwhile
+        def _drop(ref, key=key):
+            if _LATE.get(key) is ref:
+                del _LATE[key]
+        _LATE[key] = weakref.ref(p, _drop)
 
 
 def is_late(p) -> bool:

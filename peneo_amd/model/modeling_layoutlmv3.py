@@ -360,7 +360,8 @@ def _stage_forward(ctx, model, st, idx, x, params):
     R, dev = B * T, x.device
     if not x.is_contiguous():
         x = x.contiguous()
-    bufs = _LayerBuffers(R, H, I, B * nh * T, any(ctx.needs_input_grad), dev)
+    # (needs_input_grad reflects requires_grad under torch.no_grad() too: an eval forward must not allocate / store zi)
+    bufs = _LayerBuffers(R, H, I, B * nh * T, st.grad_mode and any(ctx.needs_input_grad), dev)
     L, keep = _describe_layer(model, st, idx, params, x, bufs)
     out = torch.empty((R, H), dtype=st.dtype, device=dev)
     wsb = _layer_ws_bytes(R, H, I, 0)
@@ -484,7 +485,7 @@ class _LayerStage(torch.autograd.Function):
         h1 = ops.gemm(att, Wo, bias=bo, residual=x, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 2))
         a, m1, r1 = ops.layernorm_fwd(h1, g1, b1, cfg.layer_norm_eps)
         # the GELU pre-activation is only needed by the backward: inference (no input needs a gradient) skips its 35 MB store
-        zi = torch.empty((B * T, cfg.intermediate_size), dtype=dt, device=x.device) if any(ctx.needs_input_grad) else None
+        zi = torch.empty((B * T, cfg.intermediate_size), dtype=dt, device=x.device) if (st.grad_mode and any(ctx.needs_input_grad)) else None
         inter = ops.gemm(a, Wi, bias=bi, act=ACT_GELU, preact=zi)
         h2 = ops.gemm(inter, Wo2, bias=bo2, residual=a, drop_p=seeds.p_hidden, drop_seed=seeds.seed(site + 3))
         out, m2, r2 = ops.layernorm_fwd(h2, g2, b2, cfg.layer_norm_eps)

@@ -288,7 +288,7 @@ class _DecoderStage(torch.autograd.Function):
         P = N * (N + 1) // 2
         w2d = [w.detach().contiguous() for w in w2s]
         drop_p, drop_seed = sv["k12_drop"]
-        use_fused_bwd = dec.fused_bwd and ops.pair_bwd_supported(dt, D)
+        use_fused_bwd = dec.fused_bwd and ops.pair_bwd_supported(dt, D, nh)   # (LDS: the head count enters, D = 512 holds 5 heads)
         # rows the dz producers spread their partial sums over: 256 for the fused kernels / the GEMM epilogue, the full
         # 1024 for the stand-alone peneo_pair_dz (the chunked path with the classifier dropout active)
         dz_ws = ops.pair_dz_workspace(nh, D, dev, slots=256 if (use_fused_bwd or drop_p == 0.0) else None)

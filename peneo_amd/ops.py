@@ -699,8 +699,9 @@ def pair_dz_fused(ab_doc: torch.Tensor, i0: int, i1: int, wp: torch.Tensor, b1: 
               "peneo_pair_dz_fused")
 
 
-def pair_bwd_supported(dtype: torch.dtype, D: int) -> bool:
-    return dtype == torch.bfloat16 and bool(lib().peneo_pair_bwd_supported(BF16, D))
+def pair_bwd_supported(dtype: torch.dtype, D: int, num_heads: int = 0) -> bool:
+    """The fused pair-space backward exists for (dtype, D) and its LDS image fits `num_heads` heads (0: do not ask)."""
+    return dtype == torch.bfloat16 and bool(lib().peneo_pair_bwd_supported(BF16, D, num_heads))
 
 
 def pair_bwd_rows(N: int) -> int:

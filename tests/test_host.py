@@ -43,6 +43,21 @@ def test_struct_layouts_match_the_header_sizes():
     assert ctypes.sizeof(hip.PairDzArgs) == 8 + 4 * 8 + 8 * 8 * 2 + 8 + 16 + 8
 
 
+def test_fused_pair_backward_query_knows_the_lds_limit():
+    """peneo_pair_bwd_supported(dtype, D, num_heads) is a host-side question (no GPU call): the fused launch's LDS image grows with
+    the head count, so D = 512 holds the reference's 5 heads but not 6 (the caller then runs the per-document chain instead of
+    getting PENEO_ERR_INVALID from peneo_pair_bwd_fused), D = 384 holds 5 of the 8 heads PENEO_MAX_HEADS allows."""
+    from peneo_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    f = lib.peneo_pair_bwd_supported
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int] * 3
+    BF16, F32 = hip.BF16, hip.F32
+    assert f(BF16, 512, 0) == 1 and f(BF16, 512, 5) == 1 and f(BF16, 512, 6) == 0
+    assert f(BF16, 384, 5) == 1 and f(BF16, 384, 8) == 0 and f(BF16, 384, 9) == 0
+    assert f(BF16, 128, 8) == 1 and f(BF16, 64, 8) == 1
+    assert f(F32, 384, 5) == 0 and f(BF16, 400, 5) == 0
+
+
 def test_no_cpu_fallback():
     from peneo_amd import ops
     from peneo_amd.hip import PeneoHipError

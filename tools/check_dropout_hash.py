@@ -17,8 +17,11 @@ def mix32(x):
     return x
 
 
-def mix24(x):
+def mix24(x, premul=True):
+    """pair_drop_seed's mixer; premul=False is the round-3/4 form without the full 32-bit multiply in front."""
     x = x.astype(np.uint64)
+    if premul:
+        x = (x * u(0x9E3779B1)) & M
     x ^= x >> u(16); x = ((x & u(0xFFFFFF)) * u(0x9E3779)) & M
     x ^= x >> u(13); x = ((x & u(0xFFFFFF)) * u(0x85EBCB)) & M
     x ^= x >> u(16)
@@ -76,6 +79,30 @@ def k12(p=0.1, P=3000, nslab=60, seed=12345):
           f"{keep.sum(0).std():.2f} ({np.sqrt(P * p * (1 - p)):.2f})")
 
 
+def k12_far_duplicates(n=83_800_000, seed=12345, chunk=1 << 22):
+    """Chains (counters 0 .. n - 1: config 4 has N = 1023, P = 523 776 pairs x 80 slabs x 2 halves = 83.8 M) that start from the
+    SAME 32-bit state as another chain, i.e. carry the same 16-element mask.  A random map of n counters into 2^32 states leaves
+    about n^2 / 2^33 colliding pairs (birthday level: 8.2e5 at n = 83.8 M, i.e. 1.9 % of the chains); the round-3/4 seed paired
+    every counter above 2^24 with the one at c ^ 0x01000100 (~80 % of the chains)."""
+    key = int(mix32(np.array([(seed ^ 0x9E3779B9) & 0xFFFFFFFF], dtype=np.uint64))[0])
+    for premul in (False, True):
+        st = np.empty(n, dtype=np.uint32)
+        for a in range(0, n, chunk):
+            c = np.arange(a, min(n, a + chunk), dtype=np.uint64)
+            st[a:a + len(c)] = mix24(c ^ u(key), premul).astype(np.uint32)
+        partner = np.arange(n, dtype=np.int64) ^ 0x01000100
+        ok = partner < n
+        structural = int((st[ok] == st[partner[ok]]).sum())
+        st.sort()
+        dup = int((st[1:] == st[:-1]).sum())
+        print(f"K12 seeds, {n / 1e6:.1f} M chains, {'with' if premul else 'without'} the 32-bit pre-multiply: chains whose partner at "
+              f"c ^ 0x01000100 has the same state: {structural} ({structural / n:.1%}); equal neighbours after sorting: {dup} "
+              f"(birthday expectation {n * n / 2 ** 33:.3g})")
+
+
 if __name__ == "__main__":
+    import sys
     main()
     k12()
+    if "--far" in sys.argv:
+        k12_far_duplicates()
