@@ -155,9 +155,15 @@ def main():
     ap.add_argument("--vocab", type=int, default=0, help="250002 = the XLM-R-vocabulary backbones (side measurement: word-table "
                     "gather / scatter kernels against the HBM roofline)")
     ap.add_argument("--no-ragged", action="store_true", help="skip the ragged side line")
+    ap.add_argument("--trained-agree-lr", type=float, default=5e-5, help="backbone learning rate of that training (decoder: x 30)")
+    ap.add_argument("--trained-agree-steps", type=int, default=-1,
+                    help="optimizer steps on one batch before the indices_agree_trained side metric (0: skip; default: 4000 = ~75 s, "
+                         "or 0 with --no-cpu-baseline, i.e. in the quick runs of tools/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-forward", action="store_true", help="time eval forward only (reported as a side metric)")
     args = ap.parse_args()
+    if args.trained_agree_steps < 0:
+        args.trained_agree_steps = 0 if args.no_cpu_baseline else 4000
 
     plan = plan_launch(args.gpus, os.environ)
     if plan[0] == "fail":
@@ -322,6 +328,66 @@ def main():
     torch.cuda.synchronize()
     opt_ms = (time.perf_counter() - t2) * 1e3 / 3
 
+    # side metric: `indices_agree` above is taken on random-init weights, where every logit sits in a near-tie
+    # band.  What the reference decodes in practice (model/peneo_decoder.py:98-114) are separated logits: train this model on ONE
+    # synthetic batch with the fused AdamW (reference groups: decoder lr x 30) until the positive spots separate, then count the
+    # pair-tag indices the bf16 path decides differently from the fp32 path of the same trained weights, and compare the decoded
+    # spot lists (get_spots_from_shaking_tag) of the two precisions.  Outside the timed region; not part of `value`.
+    indices_agree_trained = None
+    if world == 1 and args.trained_agree_steps > 0 and args.backbone == "layoutlmv3":
+        from peneo_amd.model.peneo_decoder import HandshakingTaggingScheme
+        model.train()
+        tb = batches[0]
+        for g_ in opt.param_groups:      # (the groups were built at 5e-5 / 1.5e-3 for the timing above)
+            g_["lr"] = g_["lr"] * (args.trained_agree_lr / 5e-5)
+        for it in range(args.trained_agree_steps):
+            for p_ in model.parameters():
+                p_.grad = None
+            out_t = net(**tb)
+            out_t["loss"].backward()
+            opt.step()
+        loss_tr = float(out_t["loss"].detach())
+        model.eval()
+        Nn = tb["input_ids"].shape[1] - 1
+        with torch.no_grad():
+            o16 = model(**tb)
+            model.set_compute_dtype(torch.float32)
+            o32 = model(**tb)
+            model.set_compute_dtype(dtype)
+            flips = total = pos32 = pos_flips = 0
+            edges = (2e-3, 1e-2, 5e-2, 2e-1)
+            above = [0] * len(edges)
+            n_spots, spots_differ, max_flip_margin, max_dlogit = 0, 0, 0.0, 0.0
+            for k in o32:
+                if not k.endswith("_shaking_outputs"):
+                    continue
+                a16, a32 = o16[k].argmax(-1), o32[k].argmax(-1)
+                diff = a16 != a32
+                top2 = o32[k].float().topk(2, dim=-1).values
+                margin = top2[..., 0] - top2[..., 1]
+                flips += int(diff.sum()); total += diff.numel()
+                for i_, e_ in enumerate(edges):
+                    above[i_] += int((diff & (margin > e_)).sum())
+                if int(diff.sum()):
+                    max_flip_margin = max(max_flip_margin, float(margin[diff].max()))
+                max_dlogit = max(max_dlogit, float((o16[k].float() - o32[k].float()).abs().max()))
+                pos = a32 != 0
+                pos32 += int(pos.sum()); pos_flips += int((diff & (pos | (a16 != 0))).sum())
+                for b_ in range(B):       # decoded (i, j, tag) lists, the reference's definition of "indices"
+                    s16 = HandshakingTaggingScheme.get_spots_from_shaking_tag(o16[k][b_], seq_len=Nn)
+                    s32 = HandshakingTaggingScheme.get_spots_from_shaking_tag(o32[k][b_], seq_len=Nn)
+                    n_spots += len(s32)
+                    spots_differ += len(set(tuple(x[:3]) for x in s16) ^ set(tuple(x[:3]) for x in s32))
+            indices_agree_trained = {"train_steps": args.trained_agree_steps, "lr": args.trained_agree_lr, "loss_after": round(loss_tr, 6),
+                                     "bf16_vs_fp32_flips": flips, "of": total, "flip_rate": round(flips / max(1, total), 9),
+                                     "flips_with_fp32_margin_above": {str(e_): n_ for e_, n_ in zip(edges, above)},
+                                     "largest_fp32_margin_of_a_flip": round(max_flip_margin, 5),
+                                     "max_abs_logit_difference_bf16_vs_fp32": round(max_dlogit, 5),
+                                     "fp32_positive_tags": pos32, "flips_touching_a_positive": pos_flips,
+                                     "decoded_spots_fp32": n_spots, "decoded_spots_differing": spots_differ}
+            del o16, o32
+        model.train()
+
     if rank == 0:
         docs = world * B * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
@@ -378,6 +444,7 @@ def main():
                              "tflops_algorithmic": round(FWD_GFLOP_PER_DOC * B / fwd_ms, 1),
                              "frac_of_mfma_peak": round(FWD_GFLOP_PER_DOC * B / fwd_ms / PEAK_BF16_TFLOPS, 4)},
             "indices_agree": indices_agree,
+            "indices_agree_trained": indices_agree_trained,
             "ragged": ragged,
             "embed_bwd": ({"avg_launch_ms": round(sum(eb) / len(eb), 4), "launches": len(eb), "vocab": vocab,
                            # algorithmic bytes: every token reads its d_x row (H * 2 B) and adds H fp32 values into 6 tables

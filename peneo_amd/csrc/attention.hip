@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void attn_drop_words_kernel(uint32_t* words, i
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     uint32_t st = mix32(seed ^ ((uint32_t)i * 0x9e3779b9u) ^ ((uint32_t)(i >> 32) * 0x85ebca6bu));
     uint32_t w = 0;
+    const uint32_t inc = pair_drop_inc_of(st);   // (bits 24..31 of the seed word select the chain's increment: 2^32 distinct words' chains)
 #pragma unroll
     for (int bit = 0; bit < 32; ++bit) {
-      st = pair_drop_step(st);
+      st = pair_drop_step(st, inc);
       w |= ((st >> 16) >= thr16 ? 1u : 0u) << bit;
     }
     words[i] = w;

@@ -157,23 +157,33 @@ __device__ __forceinline__ bool dropout_keep_b(uint32_t base, uint32_t lo, uint3
 // of the forward kernel holds (accumulator rows 8g + 4 half + e of its pair).  Each (document, pair, slab, half) owns a
 // chain of 16 fields: a two-round 24-bit-multiply mixer (full-rate v_mul_u32_u24, as the attention mask) of the counter
 // seeds it, then one v_mad_u32_u24 per field:
-//     st_0 = mix24((((p * nslab + slab) * 2 + h) ^ key(seed, b)) * 0x9E3779B1);  st_{i+1} = (st_i[23:0] * 0xC2B2AF + 0x9E3779) mod 2^32
+//     w = premix(((p * nslab + slab) * 2 + h) ^ key(seed, b));  st_0 = mix24(w);  st_{i+1} = (st_i[23:0] * 0xC2B2AF + inc(w[31:24])) mod 2^32
 //     keep(unit 8 (i >> 2) + 4 h + (i & 3)) = (st_{i+1} >> 16) >= p_drop * 2^16
 // i.e. 1.5 integer operations per element instead of a hash each (the mask generation was 27 % of the forward kernel).
 // Backward kernels regenerate the same bits.  tools/check_dropout_hash.py: keep rate, neighbour / slab / pair correlations
 // and count statistics at the noise floor.
 __device__ __forceinline__ uint32_t pair_drop_key(uint32_t seed, int b) { return mix32(seed ^ ((uint32_t)(b + 1) * 0x9e3779b9u)); }
-__device__ __forceinline__ uint32_t pair_drop_seed(uint32_t key, uint32_t counter /* (p * nslab + slab) * 2 + half */) {
-  // One full 32-bit multiply in front of the 24-bit mixer (round 5): the v_mul_u32_u24 rounds read 24 bits, so without it bits 24..31
-  // of the counter entered only through the x >> 16 fold and counters c and c ^ 0x01000100 seeded the SAME chain - a structural
-  // duplicate at a fixed far offset for every chain once the counter passes 2^24 (config 4: N = 1023, 80 slabs -> 83.8 M chains).
-  // An odd multiplier is a bijection on 32 bits and carries every counter bit into the bits the mixer reads; collisions above
-  // 2^24 chains are now the birthday kind (tools/check_dropout_hash.py counts both).  One quarter-rate instruction per 16 elements.
+// One full 32-bit multiply in front of the 24-bit mixer (round 5): the v_mul_u32_u24 rounds read 24 bits, so without it bits 24..31
+// of the counter entered only through the x >> 16 fold and counters c and c ^ 0x01000100 seeded the SAME chain - a structural
+// duplicate at a fixed far offset for every chain once the counter passes 2^24 (config 4: N = 1023, 80 slabs -> 83.8 M chains).
+// An odd multiplier is a bijection on 32 bits and carries every counter bit into the bits the mixer reads.
+__device__ __forceinline__ uint32_t pair_drop_premix(uint32_t key, uint32_t counter /* (p * nslab + slab) * 2 + half */) {
   uint32_t x = (counter ^ key) * 0x9E3779B1u;
-  x ^= x >> 16; x = __umul24(x, 0x9E3779u); x ^= x >> 13; x = __umul24(x, 0x85EBCBu); x ^= x >> 16;
+  return x ^ (x >> 16);
+}
+__device__ __forceinline__ uint32_t pair_drop_seed(uint32_t key, uint32_t counter) {
+  uint32_t x = pair_drop_premix(key, counter);
+  x = __umul24(x, 0x9E3779u); x ^= x >> 13; x = __umul24(x, 0x85EBCBu); x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ uint32_t pair_drop_step(uint32_t st) { return __umul24(st, 0xC2B2AFu) + 0x9E3779u; }
+// A chain is an LCG on the low 24 bits of its state, so the mixer above (which reads 24 bits of the premixed word) can start at most
+// 2^24 different chains.  Round 5: the chain's INCREMENT comes from the 8 premixed bits the mixer does NOT read (odd: bit 0 of
+// 0x9E3779 is kept), so the 2^32 premixed words give 2^32 different chains and duplicates among config 4's 83.8 M chains are at the
+// birthday level (tools/check_dropout_hash.py --far).  The v_mad_u32_u24 of a field takes the increment from a register instead of a
+// constant: same instruction count.  (The attention keep words take the increment from bits 24..31 of their mix32 seed word.)
+__device__ __forceinline__ uint32_t pair_drop_inc_of(uint32_t word) { return 0x9E3779u ^ ((word >> 24) << 8); }
+__device__ __forceinline__ uint32_t pair_drop_inc(uint32_t key, uint32_t counter) { return pair_drop_inc_of(pair_drop_premix(key, counter)); }
+__device__ __forceinline__ uint32_t pair_drop_step(uint32_t st, uint32_t inc) { return __umul24(st, 0xC2B2AFu) + inc; }
 __device__ __forceinline__ uint32_t pair_drop_thr16_dev(float p) { return p > 0.f ? (uint32_t)(p * 65536.f + 0.5f) : 0u; }
 // threshold and the matching scale: p is realised as thr16 / 2^16 (0.1 -> 6554 / 65536) and the kept values are scaled by
 // 2^16 / (2^16 - thr16), so the mask is unbiased for the probability it really uses
@@ -181,21 +191,23 @@ inline uint32_t pair_drop_thr16_host(float p) { return p > 0.f ? (uint32_t)(p * 
 inline float pair_drop_scale_host(float p) { const uint32_t t = pair_drop_thr16_host(p); return t ? 65536.f / (65536.f - (float)t) : 1.f; }
 // Kernels whose lane owns ONE hidden unit (chain position i) and walks many pairs jump to that position: the 24-bit state
 // after i steps is affine in the seed, st_i[23:0] = (A^i st_0 + C_i) mod 2^24, so an element costs the seed + two multiply-adds.
-struct PairDropJump { uint32_t a, c; };
+struct PairDropJump { uint32_t a, s; };   // st_i = a st_0 + inc s   (mod 2^24):  a = A^i,  s = 1 + A + ... + A^(i-1)
 __device__ __forceinline__ PairDropJump pair_drop_jump(int i /* chain position 0..15 */) {
-  uint32_t a = 1u, c = 0u;
-  for (int k = 0; k < i; ++k) { a = (a * 0xC2B2AFu) & 0xFFFFFFu; c = (c * 0xC2B2AFu + 0x9E3779u) & 0xFFFFFFu; }
-  return PairDropJump{a, c};
+  uint32_t a = 1u, sm = 0u;
+  for (int k = 0; k < i; ++k) { sm = (sm * 0xC2B2AFu + 1u) & 0xFFFFFFu; a = (a * 0xC2B2AFu) & 0xFFFFFFu; }
+  return PairDropJump{a, sm};
 }
-__device__ __forceinline__ bool pair_drop_keep_at(uint32_t seedword, PairDropJump j, uint32_t thr16) {
-  const uint32_t si = __umul24(seedword, j.a) + j.c;            // low 24 bits = state after i steps
-  return (pair_drop_step(si) >> 16) >= thr16;
+__device__ __forceinline__ bool pair_drop_keep_at(uint32_t seedword, uint32_t inc, PairDropJump j, uint32_t thr16) {
+  const uint32_t si = __umul24(seedword, j.a) + __umul24(inc, j.s);   // low 24 bits = state after i steps
+  return (pair_drop_step(si, inc) >> 16) >= thr16;
 }
 // one element (the chunked / fp32 kernels, where speed does not matter): n = column in [0, nslab * 32)
 __device__ __forceinline__ bool pair_drop_keep(uint32_t key, int64_t pair, int n, int nslab, uint32_t thr16) {
   const int slab = n >> 5, w = n & 31, half = (w >> 2) & 1, i = 4 * (w >> 3) + (w & 3);
-  uint32_t st = pair_drop_seed(key, (uint32_t)((pair * nslab + slab) * 2 + half));
-  for (int k = 0; k <= i; ++k) st = pair_drop_step(st);
+  const uint32_t cnt = (uint32_t)((pair * nslab + slab) * 2 + half);
+  uint32_t st = pair_drop_seed(key, cnt);
+  const uint32_t inc = pair_drop_inc(key, cnt);
+  for (int k = 0; k <= i; ++k) st = pair_drop_step(st, inc);
   return (st >> 16) >= thr16;
 }
 

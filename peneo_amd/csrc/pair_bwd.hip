@@ -554,9 +554,10 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         if (s + 1 < nslab) {
           _Float16* mrow = sMask + ((((s + 1) & 1) * 4 + grp) * 32 * 2 + mhp) * 16 + mreg;
           uint32_t st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(s + 1));
+          const uint32_t inc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(s + 1));
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            st = pair_drop_step(st);
+            st = pair_drop_step(st, inc);
             const int unit = 8 * (i >> 2) + 4 * half + (i & 3);
             mrow[unit * 32] = (st >> 16) >= p.drop_thr16 ? (_Float16)0.f : (_Float16)(-30000.f);
           }
@@ -943,6 +944,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
       const uint32_t ndst = __builtin_amdgcn_readfirstlane(ring + nslot * HALF_BYTES + wave * 1024);
       const uint32_t mwa = lds_addr(sMask) + grp * (32 * MROW) + half * (4 * MROW) + mhp * 32 + mreg * 2;
       uint32_t mst = DROP ? pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)s) : 0u;
+      const uint32_t minc = DROP ? pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)s) : 0u;
       const uint32_t thr32 = p.drop_thr16 << 16;
       // A wave has ONE MFMA in flight: the next one holds the wave until the matrix pipe is free, and only what stands
       // BETWEEN two MFMAs issues in the first one's shadow.  So: wait, MFMA, [next reads + a weight piece], MFMA, [mask steps].
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(PB_WAVES * 64, 1) void pair_bwd_one_kernel(PairBwdP
         if constexpr (DROP) {
           pb_static_for<pb_mask_steps(NZ, J + 1) - pb_mask_steps(NZ, J)>([&](auto ic) {
             constexpr int I = pb_mask_steps(NZ, J) + decltype(ic)::value;
-            mst = pair_drop_step(mst);
+            mst = pair_drop_step(mst, minc);
             const uint32_t v = mst >= thr32 ? 0u : 0xF753u;   // field = bits 16.. of the state; f16 0 / -30000
             pb_dsw16<(8 * (I >> 2) + (I & 3)) * MROW>(mwa, v);
           });

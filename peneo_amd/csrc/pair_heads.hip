@@ -357,9 +357,10 @@ __global__ __launch_bounds__(PH_WAVES * 64, sizeof(T) == 2 ? (PH_WAVES > 8 ? 3 :
       // K12 dropout (peneo_decoder.py:261): this lane's 16 hidden units of the slab (rows 8g + 4 half + e, y[4g + e]) are the
       // 16 fields of ONE chain (common.h); the 1 / (1 - p) factor is applied to the logits
       uint32_t st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)bias_slab);
+      const uint32_t inc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)bias_slab);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        st = pair_drop_step(st);
+        st = pair_drop_step(st, inc);
         y[i] = (st >> 16) >= p.drop_thr16 ? y[i] : 0.f;
       }
     }
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
     for (int i = 0; i < 4; ++i) bv[i] = ph_u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < NS; ++i) fs[i] = ph_u32x4{0u, 0u, 0u, 0u};
-    uint32_t st = 0u;
+    uint32_t st = 0u, sinc = 0u;
     float t[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t yp[8];
 #pragma unroll
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
       // accumulator registers 4g .. 4g+3 = hidden rows 8g + 4 half + 0..3 of the slab: one 16-byte bias read per group
       const uint32_t ba = sB1_l + (uint32_t)(slab - 1) * 128;
       ph_dsr<0>(bv[0], ba); ph_dsr<32>(bv[1], ba); ph_dsr<64>(bv[2], ba); ph_dsr<96>(bv[3], ba);
-      if constexpr (DROP) st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1));
+      if constexpr (DROP) { st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); sinc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); }
     }
     if constexpr (DOM) ph_static_for<LA>([&](auto ic) { constexpr int I = decltype(ic)::value; ph_dsr<I * 1024>(fs[I], wb); });
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) :: "memory");
@@ -923,14 +924,14 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         if constexpr (DROP) {
           // K12 dropout: the lane's 16 hidden units of the slab are the 16 fields of ONE chain, in register order
 #pragma unroll
-          for (int e = 0; e < 3; ++e) { st = pair_drop_step(st); t[e] = st >= thr32 ? t[e] : 0.f; }
+          for (int e = 0; e < 3; ++e) { st = pair_drop_step(st, sinc); t[e] = st >= thr32 ? t[e] : 0.f; }
         }
       } else {
-        if constexpr (DROP) { st = pair_drop_step(st); t[3] = st >= thr32 ? t[3] : 0.f; }
+        if constexpr (DROP) { st = pair_drop_step(st, sinc); t[3] = st >= thr32 ? t[3] : 0.f; }
         yp[2 * G] = pack_bf16x2(t[0], t[1]); yp[2 * G + 1] = pack_bf16x2(t[2], t[3]);
       }
       // anchor: the piece stays between the MFMAs it was written between
-      asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(st));
+      asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(st), "+v"(sinc));
       if constexpr (S == 5) asm volatile("" : "+v"(yp[2 * G]), "+v"(yp[2 * G + 1]));
       // groups 0, 1 done: y rows 0..15 of the slab are complete -> the first second-layer MFMA
       if constexpr (Q == 11) ph_mma_late(w2a, ph_u32x4{yp[0], yp[1], yp[2], yp[3]}, lg);
@@ -1296,8 +1297,9 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_dz_fused_kernel(DzFused
             // batch kernel peneo_pair_bwd_fused does not cover: D = 512)
             // the forward's classifier dropout: this lane's unit sits at a fixed chain position, its pairs vary
             const uint32_t cnt0 = (uint32_t)(((p.a.drop_pair0 + lp0 + row0) * nslab + es) * 2) + drop_half;
-            const f2 kk = f2{pair_drop_keep_at(pair_drop_seed(drop_key, cnt0), drop_jump, drop_thr) ? drop_scale : 0.f,
-                             pair_drop_keep_at(pair_drop_seed(drop_key, cnt0 + 2u * (uint32_t)nslab), drop_jump, drop_thr) ? drop_scale : 0.f};
+            const uint32_t cnt1 = cnt0 + 2u * (uint32_t)nslab;
+            const f2 kk = f2{pair_drop_keep_at(pair_drop_seed(drop_key, cnt0), pair_drop_inc(drop_key, cnt0), drop_jump, drop_thr) ? drop_scale : 0.f,
+                             pair_drop_keep_at(pair_drop_seed(drop_key, cnt1), pair_drop_inc(drop_key, cnt1), drop_jump, drop_thr) ? drop_scale : 0.f};
             dz = dz * kk;
             const f2 ym = y * kk;
             s0 = __builtin_elementwise_fma(g0, ym, s0); s1 = __builtin_elementwise_fma(g1, ym, s1); s2 = __builtin_elementwise_fma(g2, ym, s2);

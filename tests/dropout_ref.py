@@ -38,12 +38,14 @@ def k12_keep(seed: int, b: int, p0: int, p1: int, ncol: int, p: float) -> torch.
     sl = np.arange(nslab, dtype=np.uint64)[None, :, None]
     hh = np.arange(2, dtype=np.uint64)[None, None, :]
     x = ((((pp * _u(nslab) + sl) * _u(2) + hh)) & _M) ^ key
-    x = (x * _u(0x9E3779B1)) & _M     # full 32-bit multiply in front of the 24-bit rounds (common.h: pair_drop_seed)
-    x ^= x >> _u(16); x = _mul24(x, 0x9E3779); x ^= x >> _u(13); x = _mul24(x, 0x85EBCB); x ^= x >> _u(16)
+    x = (x * _u(0x9E3779B1)) & _M     # full 32-bit multiply in front of the 24-bit rounds (common.h: pair_drop_premix)
+    x ^= x >> _u(16)
+    inc = _u(0x9E3779) ^ ((x >> _u(24)) << _u(8))     # the chain's increment: the 8 premixed bits the 24-bit mixer does not read
+    x = _mul24(x, 0x9E3779); x ^= x >> _u(13); x = _mul24(x, 0x85EBCB); x ^= x >> _u(16)
     out = np.zeros((p1 - p0, nslab, 32), dtype=bool)
     st = x
     for i in range(16):
-        st = (_mul24(st, 0xC2B2AF) + _u(0x9E3779)) & _M
+        st = (_mul24(st, 0xC2B2AF) + inc) & _M
         g, e = i >> 2, i & 3
         for h in range(2):
             out[:, :, 8 * g + 4 * h + e] = (st[:, :, h] >> _u(16)) >= thr

@@ -8,7 +8,8 @@ from peneo_amd import ops
 dt = torch.bfloat16
 bad = 0
 for (B, nh, T, d, drop) in [(1, 2, 709, 64, 0.0), (2, 3, 709, 64, 0.1), (2, 2, 200, 64, 0.2), (1, 1, 64, 64, 0.1), (2, 2, 33, 64, 0.0),
-                            (1, 16, 1221, 64, 0.1), (3, 2, 128, 64, 0.1), (1, 2, 129, 64, 0.1)]:
+                            (1, 16, 1221, 64, 0.1), (3, 2, 128, 64, 0.1), (1, 2, 129, 64, 0.1), (20, 16, 140, 64, 0.1), (20, 10, 300, 64, 0.0),
+                            (8, 12, 709, 64, 0.1)]:
     g = torch.Generator().manual_seed(T + int(drop * 100))
     H = nh * d
     qkv = torch.randn(B * T, 3 * H, generator=g).to("cuda").to(dt)
