@@ -30,26 +30,16 @@ namespace peneo {
 namespace {
 
 constexpr int TQ = 32;     // queries per tile
-// a workgroup = NW waves x 32 keys (NW = 4 or 5).  A tile's buffer: Q [32][128 B], dO [32][128 B], bias of the first 128 keys
-// [32][256 B], (NW = 5) bias of keys 128..159 [32][64 B], lse [64], delta [64], keep words [NW * 32]
-constexpr int O_Q = 0, O_DO = 4096, O_BIAS = 8192;
-constexpr int o_bx(int nw) { return 16384; }
-constexpr int o_lse(int nw) { return 16384 + (nw > 4 ? 2048 : 0); }
-constexpr int o_delta(int nw) { return o_lse(nw) + 256; }
-constexpr int o_words(int nw) { return o_delta(nw) + 256; }
-constexpr int buf_bytes(int nw) { return o_words(nw) + (nw > 4 ? 768 : 512); }
+constexpr int WK = 128;    // keys per workgroup (4 waves x 32)
+// a tile's buffer: Q [32][128 B], dO [32][128 B], bias [32 q][128 keys] (256-byte rows), lse [64], delta [64], keep words [128]
+constexpr int O_Q = 0, O_DO = 4096, O_BIAS = 8192, O_LSE = 16384, O_DELTA = 16640, O_WORDS = 16896, BUF = 17408;
 constexpr int STG_PITCH = 80, STG_WAVE = 32 * STG_PITCH;
-// OCC = workgroups per CU.  2: ring of three buffers, S(t + 1) computed at the end of iteration t (202 registers).  3: ring of two,
-// S at the top of its own iteration, the softmax arithmetic and the dV / dK products in two halves of 16 queries (168 registers, 45 KB
-// of LDS): all 576 workgroups of 8 documents are resident at once (768 slots) instead of 512 + a second round of 64 that takes as
-// long as the first - a wave's 23 tiles are the unit of time
-// NW = 5 (160 keys per workgroup, OCC 3 form only): T = 709 is 5 x 160 -> 480 workgroups for 8 documents x 12 heads, which fit the 512
-// slots of two per CU in ONE round with at most two workgroups' DMA streams per CU (the kernel is bound by the rate at which a CU
-// turns global lines into LDS lines: 576 workgroups of 128 keys put three on a quarter of the CUs, and those set the time)
-constexpr int ring_of(int occ) { return occ >= 3 ? 2 : 3; }
-// (OCC 3 has no dS^T patch - the rows go out straight from registers - and keeps the K fragments in LDS: 16 KB, a hand-made spill,
-// every lane reads back its own 64 bytes; 50.8 KB per workgroup)
-constexpr int lds_bytes_of(int occ, int nw) { return ring_of(occ) * buf_bytes(nw) + (occ >= 3 ? nw * 4096 : nw * STG_WAVE); }
+// Two workgroups per CU (205 registers, 62 KB of LDS).  Measured and removed in round 5 (profiles/r05_attention_bwd.txt): a 168-register
+// form at three per CU (ring of two, K fragments parked in LDS, dS^T rows straight from registers: all 576 workgroups of 8 documents
+// resident at once) and a 160-key form of five waves (480 workgroups, one round at two per CU) - 76 / 86 us against 76 alone and no
+// better in the step: the launch is bound by the CU's global -> LDS fill and by instruction issue, not by workgroups per CU.
+constexpr int NBUF = 3;
+constexpr int LDS_BYTES = NBUF * BUF + 4 * STG_WAVE;
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ float g_lse_pad = 1.0e30f;   // lse of query rows past T
@@ -82,14 +72,9 @@ __device__ __forceinline__ void dma4_v(const char* ptr_lane, uint32_t lds_unifor
 }
 __device__ __forceinline__ uint32_t and_u(float x, int m) { return __float_as_uint(x) & (uint32_t)m; }
 
-template <bool DROP, int OCC, int NW>
-__global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams p) {
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
   typedef bf16_t T;
-  constexpr int NBUF = ring_of(OCC);
-  constexpr bool PF = NBUF == 3;       // S one tile ahead
-  constexpr int WK = 32 * NW, BUF = buf_bytes(NW);
-  constexpr int O_BX = o_bx(NW), O_LSE = o_lse(NW), O_DELTA = o_delta(NW), O_WORDS = o_words(NW);
-  static_assert(NW == 4 || (NW == 5 && !PF), "five waves: the three-per-SIMD form only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,50 +119,54 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
     asm volatile("" : "+v"(vf[ks].v.x), "+v"(vf[ks].v.y), "+v"(vf[ks].v.z), "+v"(vf[ks].v.w));
   }
 
-  // OCC 3: the K fragments live in LDS ([wave][k-step][lane] x 16 B, private to the lane that wrote them: no barrier)
-  char* kspill = smem + NBUF * BUF + wave * 4096 + lane * 16;
   const bool wave_on = key0 + wave * 32 < Tn;      // a wave whose 32 keys all lie past T only serves the DMA stream and the barriers
-  if constexpr (!PF) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<uint4*>(kspill + 1024 * ks) = kf[ks].v;
-  }
 
   // ---- DMA sources of this wave's pieces (lane constants; a tile adds a uniform base) ----
-  //   waves 0..3: Q piece w, dO piece w (rows 8 w .. 8 w + 7), bias pieces 2 w, 2 w + 1 (four rows each) + one small piece
-  //   (lse | delta | keep words 0..63 | 64..127);  wave 4 (NW = 5): the two pieces of the extra bias columns + keep words 128..159
+  //   wave w: Q piece w, dO piece w (rows 8 w .. 8 w + 7), bias pieces 2 w, 2 w + 1 (four rows each) + one small piece
+  //   (lse | delta | keep words 0..63 | 64..127)
   const uint32_t lds0 = lds_addr(smem);
-  const int qrow = 8 * wave + (lane >> 3);
-  const uint32_t qcol = (uint32_t)(((lane & 7) ^ qslot_swz(qrow)) << 4);
-  const int brow0 = 8 * wave + (lane >> 4);
-  const int bcl = (int)p.bias_ld * 2 - 16;                               // (a key block may pass the padded row end: clamp)
-  const uint32_t bcol0 = (uint32_t)min(key0 * 2 + (((lane & 15) ^ ((brow0 & 3) << 2)) << 4), bcl);
-  const uint32_t bcol1 = (uint32_t)min(key0 * 2 + (((lane & 15) ^ (((brow0 + 4) & 3) << 2)) << 4), bcl);
-  const uint32_t xcol = (uint32_t)min((key0 + 128) * 2 + ((lane & 3) << 4), bcl);   // extra bias: rows of 64 B, no swizzle needed
   const uint32_t ldq2 = (uint32_t)(p.ld * 2), ldo2 = (uint32_t)(p.ld_out * 2), ldb2 = (uint32_t)(p.bias_ld * 2);
-  auto dma_tile = [&](int t, int buf) {
-    const int q0 = t * TQ, lim = Tn - 1 - q0;
+  // lane offsets of the four 1 KiB pieces (rows clamped to `lim`: only the last tile has rows past T, and recomputes them)
+  auto piece_offsets = [&](int lim, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+    const int bcl = (int)p.bias_ld * 2 - 16;                             // (a key block may pass the padded row end: clamp)
+    const int qrow = 8 * wave + (lane >> 3);
+    const uint32_t qcol = (uint32_t)(((lane & 7) ^ qslot_swz(qrow)) << 4);
+    const int brow0 = 8 * wave + (lane >> 4);
+    o0 = (uint32_t)min(qrow, lim) * ldq2 + qcol;
+    o1 = (uint32_t)min(qrow, lim) * ldo2 + qcol;
+    o2 = (uint32_t)min(brow0, lim) * ldb2 + (uint32_t)min(key0 * 2 + (((lane & 15) ^ ((brow0 & 3) << 2)) << 4), bcl);
+    o3 = (uint32_t)min(brow0 + 4, lim) * ldb2 + (uint32_t)min(key0 * 2 + (((lane & 15) ^ (((brow0 + 4) & 3) << 2)) << 4), bcl);
+  };
+  uint32_t po0, po1, po2, po3;
+  piece_offsets(TQ - 1, po0, po1, po2, po3);
+  // tiles are requested strictly in order: the uniform source pointers of the NEXT tile to request run along (scalar adds)
+  const char* nq = reinterpret_cast<const char*>(Q);
+  const char* ndo = reinterpret_cast<const char*>(dO);
+  const char* nb = reinterpret_cast<const char*>(bias);
+  const char* ndl = reinterpret_cast<const char*>(delta);
+  const char* nw = DROP ? reinterpret_cast<const char*>(p.words + (int64_t)bh * p.nqb * (int64_t)p.Tk + key0) : nullptr;
+  const float* nl = lse;
+  int nq0 = 0;                                                            // first query of that tile
+  auto dma_tile = [&](auto buf_c) {
+    const int buf = buf_c;                              // an integral_constant (static ring position) or a plain int
+    const int lim = Tn - 1 - nq0;
     const uint32_t dst = lds0 + buf * BUF;
-    const char* bt = reinterpret_cast<const char*>(bias + (int64_t)q0 * p.bias_ld);
-    const char* wrow = DROP ? reinterpret_cast<const char*>(p.words + ((int64_t)bh * p.nqb + t) * (int64_t)p.Tk + key0) : nullptr;
-    const int wlim = p.Tk - 1 - key0;                                     // (the last 160-key block passes the row of keep words)
-    if (NW == 4 || wave < 4) {
-      lds_dma_1k_s<0>((uint32_t)min(qrow, lim) * ldq2 + qcol, reinterpret_cast<const char*>(Q + (int64_t)q0 * p.ld), dst + O_Q + wave * 1024);
-      lds_dma_1k_s<0>((uint32_t)min(qrow, lim) * ldo2 + qcol, reinterpret_cast<const char*>(dO + (int64_t)q0 * p.ld_out), dst + O_DO + wave * 1024);
-      lds_dma_1k_s<0>((uint32_t)min(brow0, lim) * ldb2 + bcol0, bt, dst + O_BIAS + wave * 2048);
-      lds_dma_1k_s<0>((uint32_t)min(brow0 + 4, lim) * ldb2 + bcol1, bt, dst + O_BIAS + wave * 2048 + 1024);
-      if (wave == 0) {
-        const char* src = (q0 + lane < Tn) ? reinterpret_cast<const char*>(lse + q0 + lane) : reinterpret_cast<const char*>(&g_lse_pad);
-        dma4_v(src, dst + O_LSE);
-      } else if (wave == 1) {
-        dma4_s((uint32_t)min(lane, lim) * 4u, reinterpret_cast<const char*>(delta + q0), dst + O_DELTA);
-      } else if (DROP) {
-        dma4_s((uint32_t)min((wave - 2) * 64 + lane, wlim) * 4u, wrow, dst + O_WORDS + (wave - 2) * 256);
-      }
-    } else {
-      lds_dma_1k_s<0>((uint32_t)min(lane >> 2, lim) * ldb2 + xcol, bt, dst + O_BX);
-      lds_dma_1k_s<0>((uint32_t)min(16 + (lane >> 2), lim) * ldb2 + xcol, bt, dst + O_BX + 1024);
-      if (DROP) dma4_s((uint32_t)min(128 + lane, wlim) * 4u, wrow, dst + O_WORDS + 512);
+    uint32_t o0 = po0, o1 = po1, o2 = po2, o3 = po3;
+    if (lim < TQ - 1) piece_offsets(lim, o0, o1, o2, o3);               // the last tile (uniform branch)
+    lds_dma_1k_s<0>(o0, nq, dst + O_Q + wave * 1024);
+    lds_dma_1k_s<0>(o1, ndo, dst + O_DO + wave * 1024);
+    lds_dma_1k_s<0>(o2, nb, dst + O_BIAS + wave * 2048);
+    lds_dma_1k_s<0>(o3, nb, dst + O_BIAS + wave * 2048 + 1024);
+    if (wave == 0) {
+      const char* src = (nq0 + lane < Tn) ? reinterpret_cast<const char*>(nl + lane) : reinterpret_cast<const char*>(&g_lse_pad);
+      dma4_v(src, dst + O_LSE);
+    } else if (wave == 1) {
+      dma4_s((uint32_t)min(lane, lim) * 4u, ndl, dst + O_DELTA);
+    } else if (DROP) {
+      dma4_s((uint32_t)((wave - 2) * 64 + lane) * 4u, nw, dst + O_WORDS + (wave - 2) * 256);
     }
+    nq += (int64_t)TQ * ldq2; ndo += (int64_t)TQ * ldo2; nb += (int64_t)TQ * ldb2; ndl += TQ * 4; nl += TQ; nq0 += TQ;
+    if (DROP) nw += (int64_t)p.Tk * 4;
   };
 
   // ---- LDS read addresses (lane constants relative to a buffer) ----
@@ -193,18 +182,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
       const int slot = 4 * t2 + 2 * lj + ((li & 3) >> 1);
       aT[t2][w8] = row * 128 + ((slot ^ qslot_swz(row)) << 4) + ((li & 1) << 3);
     }
-  // bias of this lane's key, four queries per transpose read: the [32][256 B] image (waves 0..3) or the [32][64 B] one (wave 4)
-  const int aB = (NW == 4 || wave < 4)
-      ? O_BIAS + (4 * half + (li >> 2)) * 256 + (((4 * wave + 2 * lj + ((li & 3) >> 1)) ^ ((li >> 2) << 2)) << 4) + ((li & 1) << 3)
-      : O_BX + (4 * half + (li >> 2)) * 64 + 32 * lj + 8 * (li & 3);
-  const int aBg = (NW == 4 || wave < 4) ? 2048 : 512;                   // eight query rows further
+  const int aB = O_BIAS + (4 * half + (li >> 2)) * 256 + (((4 * wave + 2 * lj + ((li & 3) >> 1)) ^ ((li >> 2) << 2)) << 4) + ((li & 1) << 3);
   const int aW = attn_kslot(keyl) * 4;
   char* stg = smem + NBUF * BUF + wave * STG_WAVE;
   char* stg_w = stg + l31 * STG_PITCH + 8 * half;                       // + 16 g
   const char* stg_r = stg + (lane >> 2) * STG_PITCH + (lane & 3) * 16;  // + 16 rows: STG_PITCH * 16
   T* slab = reinterpret_cast<T*>(p.ds_out) + ((int64_t)bh * Tn + key0 + wave * 32) * (int64_t)Tp;   // uniform
   const int slab_l = (lane >> 2) * Tp + (lane & 3) * 8;                                              // + 16 rows: 16 Tp
-  const int slab_k = l31 * Tp + 8 * half;                                                            // OCC 3: lane = key, 8 queries
 
   f32x16_t dk[2], dv[2], s;
 #pragma unroll
@@ -216,10 +200,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      Frag<T> a, kb_;
+      Frag<T> a;
       a.v = *reinterpret_cast<const uint4*>(buf + O_Q + (aS0 ^ (ks << 5)));
-      if constexpr (PF) kb_ = kf[ks]; else kb_.v = *reinterpret_cast<const uint4*>(kspill + 1024 * ks);
-      mma_step(a, kb_, acc);
+      mma_step(a, kf[ks], acc);
     }
     return acc;
   };
@@ -232,25 +215,27 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
     }
   };
 
-  dma_tile(0, 0);
-  if (PF && nt > 1) dma_tile(1, 1);
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  dma_tile(I0{});
+  if (nt > 1) dma_tile(I1{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if constexpr (PF) s = s_tile(smem);
+  s = s_tile(smem);
 
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int nxt = cur == NBUF - 1 ? 0 : cur + 1;
+  // one tile; the ring position is a compile-time constant (the loop below is unrolled over the ring), so every LDS address of
+  // the body is a lane constant plus an immediate
+  auto tile = [&](auto cur_c, int t) {
+    const int cur = cur_c, nxt = cur + 1 == NBUF ? 0 : cur + 1, nn = nxt + 1 == NBUF ? 0 : nxt + 1;
     if (t > 0) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next tile has landed (and the stores of tile t - 2 are out)
       __builtin_amdgcn_s_barrier();
     }
-    if constexpr (PF) { if (t + 2 < nt) dma_tile(t + 2, nxt == NBUF - 1 ? 0 : nxt + 1); }
-    else { if (t + 1 < nt) dma_tile(t + 1, nxt); }
-    if constexpr (PF) { if (t > 0) flush(t - 1); }
+    if (t + 2 < nt) dma_tile(nn);
+    if (t > 0) flush(t - 1);
     const char* buf = smem + cur * BUF;
-    if (!wave_on) { cur = nxt; continue; }            // (wave-uniform; the barrier and this wave's DMA pieces are above)
-    if constexpr (!PF) s = s_tile(buf);
+    if (!wave_on) return;                              // (wave-uniform; the barrier and this wave's DMA pieces are above)
 
     // dP[q, key] = dO . V^T
     f32x16_t dp;
@@ -273,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
         const int g = 2 * kk + gg;
         const float4 l4 = *reinterpret_cast<const float4*>(buf + O_LSE + 16 * half + 32 * g);
         const float4 d4 = *reinterpret_cast<const float4*>(buf + O_DELTA + 16 * half + 32 * g);
-        const uint2 bu = tr64(buf + aB + aBg * g);
+        const uint2 bu = tr64(buf + aB + 2048 * g);
         const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
         const float bf[4] = {__uint_as_float(bu.x << 16), __uint_as_float(bu.x & 0xffff0000u), __uint_as_float(bu.y << 16),
                              __uint_as_float(bu.y & 0xffff0000u)};
@@ -293,12 +278,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
         }
         pp[2 * gg] = pack_bf16x2(pd[0], pd[1]); pp[2 * gg + 1] = pack_bf16x2(pd[2], pd[3]);
         dd[2 * gg] = pack_bf16x2(ds[0], ds[1]); dd[2 * gg + 1] = pack_bf16x2(ds[2], ds[3]);
-        if constexpr (PF) *reinterpret_cast<uint2*>(stg_w + 16 * g) = make_uint2(dd[2 * gg], dd[2 * gg + 1]);
-      }
-      if constexpr (!PF) {   // dS^T of these 16 queries: two groups and a v_permlane32_swap make 16 contiguous bytes per lane
-        const auto rx = __builtin_amdgcn_permlane32_swap(dd[0], dd[2], false, false);
-        const auto ry = __builtin_amdgcn_permlane32_swap(dd[1], dd[3], false, false);
-        if (mykey < Tn) *reinterpret_cast<uint4*>(slab + t * TQ + 16 * kk + slab_k) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        *reinterpret_cast<uint2*>(stg_w + 16 * g) = make_uint2(dd[2 * gg], dd[2 * gg + 1]);
       }
       // dV^T[d, key] += dO^T[d, q] . P[q, key] ;  dK^T[d, key] += Q^T[d, q] . dS[q, key]   (these 16 queries)
       Frag<T> pf, dsf;
@@ -311,12 +291,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_pipe_kernel(AttnParams 
         const Frag<T> qtf = tr_frag(buf + O_Q + 2048 * kk + aT[t2][0], buf + O_Q + 2048 * kk + aT[t2][1]);
         mma_step(qtf, dsf, dk[t2]);
       }
-      if constexpr (!PF) __builtin_amdgcn_sched_barrier(0);   // (register budget: the second half starts after the first has gone)
     }
-    if constexpr (PF) { if (t + 1 < nt) s = s_tile(smem + nxt * BUF); }
-    cur = nxt;
+    if (t + 1 < nt) s = s_tile(smem + nxt * BUF);
+  };
+  {                            // the ring position is static: three copies of the body
+    int t = 0;
+    for (; t + 3 <= nt; t += 3) { tile(I0{}, t); tile(I1{}, t + 1); tile(I2{}, t + 2); }
+    if (t < nt) tile(I0{}, t);
+    if (t + 1 < nt) tile(I1{}, t + 1);
   }
-  if constexpr (PF) flush(nt - 1);
+  flush(nt - 1);
   // the slab's columns between the last tile and Tp stay zero (its readers load whole 16-byte groups up to Tp)
   for (int c = nt * TQ; c < Tp; c += TQ) {
 #pragma unroll
@@ -363,27 +347,16 @@ bool attn_bwd_pipe_supported(const AttnParams& p) {
 }
 
 int launch_attn_bwd_pipe(const AttnParams& p, hipStream_t st) {
-  auto go = [&](auto kern, int nw, int lds) -> int {
-    const int nkb = (p.T + 32 * nw - 1) / (32 * nw);
-    const dim3 grid((unsigned)((int64_t)nkb * p.nh * p.B));
+  const dim3 grid((unsigned)((int64_t)((p.T + WK - 1) / WK) * p.nh * p.B));
+  auto go = [&](auto kern, int lds) -> int {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       set_error("peneo_attn_bwd: cannot raise dynamic LDS to %d bytes", lds);
       return PENEO_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     return check_launch("peneo_attn_bwd(pipe)");
   };
-  // Which form: a grid of 128-key workgroups that fits the 512 slots of two per CU runs the deeper ring (OCC 2); otherwise 160-key
-  // workgroups if THEY fit 512 (T = 709, 8 documents x 12 heads: 480 instead of 576), else 128 keys at three per CU.
-  // PENEO_ATTN_BWD_FORM = 24 / 34 / 35 forces (OCC, waves) for A/B runs and tests.
-  static const int force = [] { const char* e = getenv("PENEO_ATTN_BWD_FORM"); return e ? atoi(e) : 0; }();
-  const int64_t bh = (int64_t)p.nh * p.B;
-  const int64_t g4 = (int64_t)((p.T + 127) / 128) * bh, g5 = (int64_t)((p.T + 159) / 160) * bh;
-  const int form = force ? force : (g4 <= 512 ? 24 : (g5 <= 512 ? 35 : 34));
-  const bool drop = p.drop_p > 0.f;
-  if (form == 35) return drop ? go(attn_bwd_pipe_kernel<true, 3, 5>, 5, lds_bytes_of(3, 5)) : go(attn_bwd_pipe_kernel<false, 3, 5>, 5, lds_bytes_of(3, 5));
-  if (form == 34) return drop ? go(attn_bwd_pipe_kernel<true, 3, 4>, 4, lds_bytes_of(3, 4)) : go(attn_bwd_pipe_kernel<false, 3, 4>, 4, lds_bytes_of(3, 4));
-  return drop ? go(attn_bwd_pipe_kernel<true, 2, 4>, 4, lds_bytes_of(2, 4)) : go(attn_bwd_pipe_kernel<false, 2, 4>, 4, lds_bytes_of(2, 4));
+  return p.drop_p > 0.f ? go(attn_bwd_pipe_kernel<true>, LDS_BYTES) : go(attn_bwd_pipe_kernel<false>, LDS_BYTES);
 }
 
 }  // namespace peneo

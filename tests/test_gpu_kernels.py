@@ -667,11 +667,9 @@ def test_attention_bwd_pipelined_kernel_is_the_fused_kernel_bit_for_bit(ops, B, 
     """attn_bwd_pipe.hip (LDS-DMA ring, one barrier per 32-query tile; what a bias + dS^T-slab call at head dim 64 runs) against
     attn_bwd_fused_kernel, which a call that also asks for the fp32 bias gradient still runs: same arithmetic in the same order, so
     dq | dk | dv and the dS^T slab must be IDENTICAL (the fused kernel itself is held to fp32 autograd by test_attention_fwd_bwd).
-    Ragged tails in both directions (T = 709 / 1221 / 129 / 33), masked keys, the padding columns of the slab, and the three forms the
-    launcher picks by grid size: up to 512 workgroups of 128 keys -> the three-buffer ring at two per CU; (33 x 16 heads, T = 64)
-    more than 512 either way -> 128 keys at three per CU (K fragments in LDS, no dS^T patch); (20 x 16 at T = 140, 20 x 10 at
-    T = 300, and the benchmark's 8 x 12 at T = 709) -> 160-key workgroups of five waves, whose fifth wave reads its own bias
-    sub-tile and, at T = 709, lies wholly past the padded row (keys 768..799: clamped sources, idle wave)."""
+    Ragged tails in both directions (T = 709 / 1221 / 129 / 33 / 140 / 300), masked keys, key blocks whose last waves lie wholly past
+    T (idle waves that only serve the DMA stream), the padding columns of the slab, grids below and above the 512 resident slots
+    (33 x 16 heads; the benchmark's 8 x 12 at T = 709: 576 workgroups)."""
     d, H = 64, nh * 64
     g = torch.Generator().manual_seed(T + int(drop * 100))
     qkv = torch.randn(B * T, 3 * H, generator=g).to(DEV).to(torch.bfloat16)
