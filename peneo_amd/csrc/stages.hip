@@ -9,6 +9,7 @@
 //
 // Reference: the layer is LayoutLMv3Layer.forward (modeling_layoutlmv3.py:482-529: self-attention :335-404, RobertaSelfOutput,
 // RobertaIntermediate, RobertaOutput) and its autograd.
+#include <cstdlib>
 #include <mutex>
 #include "common.h"
 
@@ -159,12 +160,20 @@ extern "C" int peneo_encoder_layer_bwd(const peneo_encoder_layer* L, const peneo
     if (hipEventRecord(ev->e[0], main) != hipSuccess || hipStreamWaitEvent(side, ev->e[0], 0) != hipSuccess) return check_launch("peneo_encoder_layer_bwd (event)");
   }
   ep = {};
+  // Round 5: with a side stream the four weight gradients of the layer are ONE grouped launch behind the attention backward
+  // (peneo_gemm_group: 432 tiles with the full K = rows, no split-k partials, no reduce launches; 97 us alone against 160 + 40 for
+  // the four GEMMs and their reductions) - measured 0.15-0.2 ms per step ahead of the per-GEMM launches, which started three of
+  // them beside the attention backward (3 of 3 interleaved pairs, profiles/r05_ab_runs.txt; round 2 had measured the grouped
+  // launch 0.3 ms BEHIND: the attention kernels it ran beside were latency-bound then and are bound by memory and issue now).
+  // Serial mode (no side stream: profiling) and PENEO_WGRAD_GROUP=0 keep the per-GEMM launches.
+  static const bool group_on = [] { const char* e = getenv("PENEO_WGRAD_GROUP"); return !e || atoi(e) != 0; }();
+  const bool grouped = group_on && side != main;
   STAGE_TRY(peneo_colsum(PENEO_BF16, d_dense2, H, R, H, G->dbo2, 1, side));
-  STAGE_TRY(gemm(0, 0, H, I, R, d_dense2, H, L->inter, I, G->dwo2, I, PENEO_F32, ep, wsd, side));
+  if (!grouped) STAGE_TRY(gemm(0, 0, H, I, R, d_dense2, H, L->inter, I, G->dwo2, I, PENEO_F32, ep, wsd, side));
   STAGE_TRY(peneo_colsum(PENEO_BF16, G->d_zi, I, R, I, G->dbi, 1, side));
-  STAGE_TRY(gemm(0, 0, I, H, R, G->d_zi, I, L->a, H, G->dwi, H, PENEO_F32, ep, wsd, side));
+  if (!grouped) STAGE_TRY(gemm(0, 0, I, H, R, G->d_zi, I, L->a, H, G->dwi, H, PENEO_F32, ep, wsd, side));
   STAGE_TRY(peneo_colsum(PENEO_BF16, d_dense1, H, R, H, G->dbo, 1, side));
-  STAGE_TRY(gemm(0, 0, H, H, R, d_dense1, H, L->att, H, G->dwo, H, PENEO_F32, ep, wsd, side));
+  if (!grouped) STAGE_TRY(gemm(0, 0, H, H, R, d_dense1, H, L->att, H, G->dwo, H, PENEO_F32, ep, wsd, side));
   // attention backward (single pass: dS^T slab of this layer, dQ from the slab)
   const char* qkv = reinterpret_cast<const char*>(L->qkv);
   char* dqkv = reinterpret_cast<char*>(G->dqkv);
@@ -175,7 +184,16 @@ extern "C" int peneo_encoder_layer_bwd(const peneo_encoder_layer* L, const peneo
     if (hipEventRecord(ev->e[1], main) != hipSuccess || hipStreamWaitEvent(side, ev->e[1], 0) != hipSuccess) return check_launch("peneo_encoder_layer_bwd (event)");
   }
   STAGE_TRY(peneo_colsum(PENEO_BF16, G->dqkv, 3 * H, R, 3 * H, G->dbqkv, 1, side));
-  STAGE_TRY(gemm(0, 0, 3 * H, H, R, G->dqkv, 3 * H, L->x, H, G->dwqkv, H, PENEO_F32, ep, wsd, side));
+  if (!grouped) {
+    STAGE_TRY(gemm(0, 0, 3 * H, H, R, G->dqkv, 3 * H, L->x, H, G->dwqkv, H, PENEO_F32, ep, wsd, side));
+  } else {
+    peneo_gemm_problem pr[4] = {};
+    pr[0] = {3 * H, H, R, G->dqkv, 3 * H, L->x, H, G->dwqkv, H, 0, nullptr};
+    pr[1] = {I, H, R, G->d_zi, I, L->a, H, G->dwi, H, 0, nullptr};
+    pr[2] = {H, I, R, d_dense2, H, L->inter, I, G->dwo2, I, 0, nullptr};
+    pr[3] = {H, H, R, d_dense1, H, L->att, H, G->dwo, H, 0, nullptr};
+    STAGE_TRY(peneo_gemm_group(PENEO_BF16, 0, 0, PENEO_F32, pr, 4, side));
+  }
   // d_x = dqkv Wqkv + d_h1
   ep = {};
   ep.residual = G->d_h1; ep.ld_res = H;
