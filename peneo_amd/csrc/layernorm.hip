@@ -395,7 +395,7 @@ static void launch_ln_bwd32(hipStream_t st, const void* dy, LnMap dym, const voi
                             const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                             int64_t rows, float drop_p, uint32_t seed, void* dx2, float drop2_p, uint32_t seed2,
                             float* partial = nullptr, int64_t partial_rows = 0, float* dcol = nullptr) {
-  constexpr int64_t cap = 256;   // fewer same-address atomics on dgamma / dbeta (measured 64..1024)
+  constexpr int64_t cap = 256;   // fewer same-address atomics on dgamma / dbeta (measured 64..1024 alone; 128..1024 in the step, round 5: +-0.1 ms)
   int64_t blocks = (rows + 7) / 8;
   if (partial) blocks = partial_rows;          // one partial row per block: the caller sized the buffer (ln_partial_rows)
   else if (blocks > cap) blocks = cap;
