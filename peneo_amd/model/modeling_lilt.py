@@ -297,24 +297,23 @@ def _post_attn_bwd2(wc, idx, dt, seeds, site_t, site_l, d_out, d_lout, sv_t, sv_
         d_dense1, d_ldense1 = d_h1, d_lh1
     d_att, d_latt = ops.gemm_group([(d_dense1, Wo, None), (d_ldense1, lWo, None)], b_kmajor=False)
 
+    # Round 5: only the bias column sums start here.  The six weight gradients of this half leave as operand pairs: the caller
+    # runs them behind the attention backward, together with the two QKV weight gradients, as TWO grouped launches (four text,
+    # four layout; each tile with its full K) instead of four split-k launches + reductions and two groups - the schedule that
+    # measured best for the LayoutLMv3 layer (csrc/stages.hip), and 7 launches per layer less for a step that is close to host-bound
     def side_work():
         ops.colsum(d_dense2, out=dbo2, accumulate=True)
-        dwo2 = wgrad(d_dense2, inter)
         ops.colsum(d_zi, out=dbi, accumulate=True)
-        dwi = wgrad(d_zi, a)
         ops.colsum(d_dense1, out=dbo, accumulate=True)
-        dwo = wgrad(d_dense1, att)
         ops.colsum(d_ldense2, out=ldbo2, accumulate=True)
         ops.colsum(d_lzi, out=ldbi, accumulate=True)
         ops.colsum(d_ldense1, out=ldbo, accumulate=True)
-        ldwo2, ldwi, ldwo = ops.gemm_group([(d_ldense2, linter, None), (d_lzi, la, None), (d_ldense1, latt, None)], a_kmajor=False,
-                                           b_kmajor=False, out_dtype=torch.float32)
-        return dwo2, dwi, dwo, ldwo2, ldwi, ldwo
-    dwo2, dwi, dwo, ldwo2, ldwi, ldwo = on_side(side_work, (d_dense2, inter, d_zi, a, d_dense1, att, d_ldense2, linter, d_lzi, la,
-                                                            d_ldense1, latt))
-    gt = (dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2)
-    gl = (ldwo, ldbo, ldg1, ldb1, ldwi, ldbi, ldwo2, ldbo2, ldg2, ldb2)
-    return d_att, d_h1, gt, d_latt, d_lh1, gl
+    on_side(side_work, (d_dense2, d_zi, d_dense1, d_ldense2, d_lzi, d_ldense1))
+    wg_t = [(d_zi, a), (d_dense2, inter), (d_dense1, att)]                 # -> dwi, dwo2, dwo
+    wg_l = [(d_lzi, la), (d_ldense2, linter), (d_ldense1, latt)]          # -> ldwi, ldwo2, ldwo
+    gt = (None, dbo, dg1, db1, None, dbi, None, dbo2, dg2, db2)
+    gl = (None, ldbo, ldg1, ldb1, None, ldbi, None, ldbo2, ldg2, ldb2)
+    return d_att, d_h1, gt, d_latt, d_lh1, gl, wg_t, wg_l
 
 
 class _LiltLayerStage(torch.autograd.Function):
@@ -395,8 +394,9 @@ class _LiltLayerStage(torch.autograd.Function):
                 side.wait_event(ev)
                 return fn()
 
+        wg_t = wg_l = None
         if ctx.grouped:
-            d_att, d_x_res, gt, d_latt, d_l_res, gl = _post_attn_bwd2(wc, idx, dt, seeds, site + 2, site + 6, d_xo, d_lo, sv_t, sv_l, tp, lp, on_side)
+            d_att, d_x_res, gt, d_latt, d_l_res, gl, wg_t, wg_l = _post_attn_bwd2(wc, idx, dt, seeds, site + 2, site + 6, d_xo, d_lo, sv_t, sv_l, tp, lp, on_side)
         else:
             d_att, d_x_res, gt = _post_attn_bwd(wc, f"L{idx}.t", dt, seeds, site + 2, d_xo, sv_t, tp, on_side)
             d_latt, d_l_res, gl = _post_attn_bwd(wc, f"L{idx}.l", dt, seeds, site + 6, d_lo, sv_l, lp, on_side)
@@ -413,8 +413,21 @@ class _LiltLayerStage(torch.autograd.Function):
         Wqkv = wc.cat_rows(f"L{idx}.qkv", [wq, wk, wv], dt)
         Wlqkv = wc.cat_rows(f"L{idx}.lqkv", [lwq, lwk, lwv], dt)
         wg = lambda dy, xin: ops.gemm(dy, xin, a_kmajor=False, b_kmajor=False, out_dtype=torch.float32)
-        dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)),
-                                               (dqkv, dlqkv, x, l))
+        if ctx.grouped:
+            def all_wgrads():
+                gt_ = ops.gemm_group([(dqkv, x, None)] + [(dy, xin, None) for dy, xin in wg_t], a_kmajor=False, b_kmajor=False,
+                                     out_dtype=torch.float32)
+                gl_ = ops.gemm_group([(dlqkv, l, None)] + [(dy, xin, None) for dy, xin in wg_l], a_kmajor=False, b_kmajor=False,
+                                     out_dtype=torch.float32)
+                return ops.colsum(dqkv), ops.colsum(dlqkv), gt_, gl_
+            dbqkv, dblqkv, gt_, gl_ = on_side(all_wgrads, (dqkv, dlqkv, x, l) + tuple(t for pr in wg_t + wg_l for t in pr))
+            dwqkv, dwi_, dwo2_, dwo_ = gt_
+            dwlqkv, ldwi_, ldwo2_, ldwo_ = gl_
+            gt = (dwo_,) + gt[1:4] + (dwi_,) + gt[5:6] + (dwo2_,) + gt[7:]
+            gl = (ldwo_,) + gl[1:4] + (ldwi_,) + gl[5:6] + (ldwo2_,) + gl[7:]
+        else:
+            dbqkv, dblqkv, dwqkv, dwlqkv = on_side(lambda: (ops.colsum(dqkv), ops.colsum(dlqkv), wg(dqkv, x), wg(dlqkv, l)),
+                                                   (dqkv, dlqkv, x, l))
         if ctx.grouped:
             d_x, d_l = ops.gemm_group([(dqkv, Wqkv, None, dict(residual=d_x_res)), (dlqkv, Wlqkv, None, dict(residual=d_l_res))], b_kmajor=False)
         else:

@@ -387,6 +387,9 @@ def test_train_mode_masks_are_the_same_function_in_both_precisions(name):
     attention backward) and the bf16 path (fused kernels) of ONE model see the same masks when the seed counters are
     reset -- losses and gradients must then agree to bf16 accuracy, and differ clearly from the eval-mode ones."""
     from peneo_amd.model.engine import DropoutSeeds
+    # (the seed base is torch.initial_seed(), random per process: with an unlucky one the train-mode loss of these tiny fixtures
+    # lands within 1e-3 of the eval loss and the "dropout really was on" check below fails - about one run in twelve before this line)
+    torch.manual_seed(20251003)
     fx = load_golden(name)
     b = to_cuda(fx["batch"])
     m = build_model(fx["config"], fx["state_dict"]).train()
