@@ -336,6 +336,7 @@ def test_bf16_path_matches_fp32_path_at_the_benchmark_size_with_dropout_on():
     parameter gradient must agree to bf16 accuracy, and the loss must differ from the eval-mode one (dropout really on)."""
     from seeded import layoutlmv3_config, peneo_config, seeded_fill_
     from peneo_amd.data import synthetic_rfund_batch
+    torch.manual_seed(20251003)      # (the dropout seed base is torch.initial_seed(): fixed, so that the run is the same every time)
     pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
     m = build_model(pcfg)
     seeded_fill_(m.state_dict(), 11)
