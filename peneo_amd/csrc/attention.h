@@ -25,5 +25,8 @@ __host__ __device__ __forceinline__ int attn_kslot(int key) {
 // attn_bwd_pipe_supported says whether a call qualifies; the launch writes dK, dV and the dS^T slab (dQ comes from the slab).
 bool attn_bwd_pipe_supported(const AttnParams& p);
 int launch_attn_bwd_pipe(const AttnParams& p, hipStream_t st);
+// attn_fwd_pipe.hip: the pipelined forward (bf16, head dim 64, bias tensor, V row-major), bit-identical to attn_fwd_kernel
+bool attn_fwd_pipe_supported(const AttnParams& p);
+int launch_attn_fwd_pipe(const AttnParams& p, hipStream_t st);
 
 }  // namespace peneo

@@ -1251,6 +1251,9 @@ static int set_smem(KernelT kern, size_t bytes) {
 template <typename T, int DP, bool DROP>
 static int launch_fwd_d(const AttnParams& p, hipStream_t st) {
   dim3 grid((p.T + AQ - 1) / AQ, p.nh, p.B);
+  if constexpr (sizeof(T) == 2 && DP == 64) {
+    if (attn_fwd_pipe_supported(p)) return launch_attn_fwd_pipe(p, st);   // attn_fwd_pipe.hip (round 5)
+  }
   if constexpr (sizeof(T) == 2) {
     if (p.vt == nullptr) {   // V given row-major: transpose reads
       if constexpr (DP <= 64) {

@@ -661,6 +661,31 @@ def test_attention_key_bias_only(ops, dtype):
 
 
 @pytest.mark.parametrize("B,nh,T,drop", [(1, 2, 709, 0.0), (2, 3, 709, 0.1), (2, 2, 200, 0.2), (1, 1, 64, 0.1), (2, 2, 33, 0.0),
+                                         (1, 16, 1221, 0.1), (1, 2, 129, 0.1), (33, 16, 64, 0.1), (8, 12, 709, 0.1)])
+def test_attention_fwd_pipelined_kernel_is_the_staged_kernel_bit_for_bit(ops, B, nh, T, drop):
+    """attn_fwd_pipe.hip (LDS-DMA ring, one barrier per 32-key tile; what a bf16 call with a bias tensor at head dim 64 runs) against
+    attn_fwd_kernel, which the same call still runs when it hands over a transposed copy of V: the same online softmax over 32-key
+    blocks in the same order, so the output and lse must be IDENTICAL (attn_fwd_kernel itself is held to fp32 autograd by
+    test_attention_fwd_bwd, and so is the new kernel through that test's (1, 2, 709, 64) case).  Ragged tails, masked keys,
+    dropout words, grids below and above the resident slots."""
+    d, H = 64, nh * 64
+    g = torch.Generator().manual_seed(T + int(drop * 100) + 1)
+    qkv = torch.randn(B * T, 3 * H, generator=g).to(DEV).to(torch.bfloat16)
+    Tp = ops.attn_padded_len(T)
+    bias = torch.full((B, nh, T, Tp), -1.0e30, dtype=torch.bfloat16, device=DEV)
+    bias[..., :T] = (0.5 * torch.randn(B, nh, T, T, generator=g)).to(DEV).to(torch.bfloat16)
+    bias[0, :, :, T // 3: T // 2] = -1.0e30
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    w = ops.attn_drop_words(B, nh, T, drop, 5)[0] if drop > 0 else None
+    out_new, lse_new = ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_words=w)
+    out_old, lse_old = ops.attn_fwd(q, k, v, B, nh, T, d, 0.125, bias, None, drop_p=drop, drop_words=w,
+                                    vt=ops.head_transpose(v, B, nh, T, d))
+    assert bool(torch.isfinite(out_new.float()).all())
+    assert torch.equal(out_new, out_old), "attention output"
+    assert torch.equal(lse_new, lse_old), "lse"
+
+
+@pytest.mark.parametrize("B,nh,T,drop", [(1, 2, 709, 0.0), (2, 3, 709, 0.1), (2, 2, 200, 0.2), (1, 1, 64, 0.1), (2, 2, 33, 0.0),
                                          (1, 16, 1221, 0.1), (1, 2, 129, 0.1), (33, 16, 64, 0.1), (20, 16, 140, 0.1),
                                          (20, 10, 300, 0.0), (8, 12, 709, 0.1)])
 def test_attention_bwd_pipelined_kernel_is_the_fused_kernel_bit_for_bit(ops, B, nh, T, drop):
