@@ -22,7 +22,8 @@ __host__ __device__ __forceinline__ int attn_kslot(int key) {
 }
 
 // attn_bwd_pipe.hip: the pipelined single-pass backward (bf16, head dim 64, bias tensor, dS^T slab requested).
-// attn_bwd_pipe_supported says whether a call qualifies; the launch writes dK, dV and the dS^T slab (dQ comes from the slab).
+// attn_bwd_pipe_supported says whether a call qualifies; the launch writes dK, dV and the dS^T slab, then dQ from the slab
+// (returns 0; or 1 when the caller still has to launch attn_dq_from_ds_kernel: PENEO_ATTN_DQ_PIPE=0).
 bool attn_bwd_pipe_supported(const AttnParams& p);
 int launch_attn_bwd_pipe(const AttnParams& p, hipStream_t st);
 // attn_fwd_pipe.hip: the pipelined forward (bf16, head dim 64, bias tensor, V row-major), bit-identical to attn_fwd_kernel

@@ -1316,7 +1316,7 @@ static int launch_bwd_d(const AttnParams& p, float* dq_acc, hipStream_t st) {
       if constexpr (DP == 64) {
         if (dq_from_ds && attn_bwd_pipe_supported(p)) {   // the pipelined form (attn_bwd_pipe.hip) + dQ from its dS^T slab
           rc = launch_attn_bwd_pipe(p, st);
-          if (rc) return rc;
+          if (rc <= 0) return rc;      // 0: dK, dV, the slab AND dQ are launched
           size_t sq = dqs_smem<DP>();
           rc = set_smem(attn_dq_from_ds_kernel<DP>, sq);
           if (rc) return rc;

@@ -335,6 +335,123 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pipe_kernel(AttnParams p) {
   }
 }
 
+
+// ================================================================================================
+// dQ[q, :] = scale * sum_key dS[q, key] K[key, :] from this layer's dS^T slab (key-major [B, nh, T, Tp]), pipelined like the kernel
+// above (replaces attn_dq_from_ds_kernel of attention.hip for head dim 64; same sums in the same order: bit-identical).
+// Workgroup = 128 queries (lane = query: dQ^T[d, q] = K^T[d, key] . dS^T[key, q], so a lane ends up with 4 consecutive d of its row
+// per register group and the rows leave by v_permlane32_swap pairs), streaming 32-key tiles: the slab block [32 keys][128 q]
+// (256-byte rows, source slots permuted by (row & 3) << 2) and the K rows [32][128 B] (slot ^ bitrev3(row >> 1)) arrive by LDS-DMA
+// into a ring of three; both operands are read with the hardware transpose read.  K rows past T come from a zero line (the slab rows
+// read beside them are clamped to T - 1: finite x 0).
+// ================================================================================================
+constexpr int DQ_O_S = 0, DQ_O_K = 8192, DQ_BUF = 12288;
+__device__ uint4 g_zero_line[8];    // 128 zero bytes (device globals are zero-initialised)
+
+__global__ __launch_bounds__(256, 2) void attn_dq_pipe_kernel(AttnParams p) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Tn = p.T, Tp = p.Tp;
+  const int nqb = (Tn + 127) / 128;
+  int u;
+  {
+    const int nwg = gridDim.x, L = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, x = L & 7, i = L >> 3;
+    u = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i;
+  }
+  const int qb = u % nqb, bh = u / nqb, h = bh % p.nh, b = bh / p.nh;
+  const int q0 = qb * 128, myq = q0 + wave * 32 + l31;
+  const T* DS = reinterpret_cast<const T*>(p.ds_out) + (int64_t)bh * Tn * (int64_t)Tp;
+  const T* K = reinterpret_cast<const T*>(p.k) + (int64_t)b * Tn * p.ld + h * 64;
+  const int nt = (Tn + 31) / 32;
+  const uint32_t lds0 = lds_addr(smem);
+  const uint32_t lds2 = (uint32_t)(Tp * 2), ldk2 = (uint32_t)(p.ld * 2);
+  // DMA: wave w sends slab pieces 2 w, 2 w + 1 (four key rows each) and K piece w (eight key rows)
+  const int srow0 = 8 * wave + (lane >> 4), krow = 8 * wave + (lane >> 3);
+  const int scl = Tp * 2 - 16;                                   // (a query block may pass the padded row end: clamp; those rows are not stored)
+  const uint32_t sc0 = (uint32_t)min(q0 * 2 + (((lane & 15) ^ ((srow0 & 3) << 2)) << 4), scl);
+  const uint32_t sc1 = (uint32_t)min(q0 * 2 + (((lane & 15) ^ (((srow0 + 4) & 3) << 2)) << 4), scl);
+  const uint32_t kcol = (uint32_t)(((lane & 7) ^ qslot_swz(krow)) << 4);
+  const char* ns = reinterpret_cast<const char*>(DS);
+  const char* nk = reinterpret_cast<const char*>(K);
+  int nk0 = 0;
+  auto dma_tile = [&](auto buf_c) {
+    const int buf = buf_c;
+    const uint32_t dst = lds0 + buf * DQ_BUF;
+    const int lim = Tn - 1 - nk0;
+    lds_dma_1k_s<0>((uint32_t)min(srow0, lim) * lds2 + sc0, ns, dst + DQ_O_S + wave * 2048);
+    lds_dma_1k_s<0>((uint32_t)min(srow0 + 4, lim) * lds2 + sc1, ns, dst + DQ_O_S + wave * 2048 + 1024);
+    if (lim >= 31) {
+      lds_dma_1k_s<0>((uint32_t)krow * ldk2 + kcol, nk, dst + DQ_O_K + wave * 1024);
+    } else {                                                      // the last tile: K rows past T read the zero line
+      const char* src = krow <= lim ? nk + (uint32_t)krow * ldk2 + kcol : reinterpret_cast<const char*>(g_zero_line) + (lane & 7) * 16;
+      lds_dma_1k<0>(src, dst + DQ_O_K + wave * 1024);
+    }
+    ns += (int64_t)32 * lds2; nk += (int64_t)32 * ldk2; nk0 += 32;
+  };
+  // transpose-read addresses: [4 key rows][16 columns] blocks; keys 16 kk + 8 half + {0..3} and + 4
+  const int li = lane & 15, lj = (lane >> 4) & 1;
+  int aA[2], aK[2][2];
+#pragma unroll
+  for (int w4 = 0; w4 < 2; ++w4) {
+    const int row = 8 * half + 4 * w4 + (li >> 2);
+    aA[w4] = DQ_O_S + row * 256 + (((4 * wave + 2 * lj + ((li & 3) >> 1)) ^ ((row & 3) << 2)) << 4) + ((li & 1) << 3);
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+      aK[t2][w4] = DQ_O_K + row * 128 + (((4 * t2 + 2 * lj + ((li & 3) >> 1)) ^ qslot_swz(row)) << 4) + ((li & 1) << 3);
+  }
+  f32x16_t acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  dma_tile(I0{});
+  if (nt > 1) dma_tile(I1{});
+  auto tile = [&](auto cur_c, int t) {
+    const int cur = cur_c, nxt = cur + 1 == 3 ? 0 : cur + 1, nn = nxt + 1 == 3 ? 0 : nxt + 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) dma_tile(nn);
+    const char* buf = smem + cur * DQ_BUF;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint2 b0 = tr64(buf + aA[0] + 4096 * kk), b1 = tr64(buf + aA[1] + 4096 * kk);
+      Frag<T> bf;                                                 // dS^T[key, q]: this lane's query, keys 16 kk + 8 half + 0..7
+      bf.v = make_uint4(b0.x, b0.y, b1.x, b1.y);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const uint2 a0 = tr64(buf + aK[t2][0] + 2048 * kk), a1 = tr64(buf + aK[t2][1] + 2048 * kk);
+        Frag<T> af;                                               // K^T[d, key]
+        af.v = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        mma_step(af, bf, acc[t2]);
+      }
+    }
+  };
+  {
+    int t = 0;
+    for (; t + 3 <= nt; t += 3) { tile(I0{}, t); tile(I1{}, t + 1); tile(I2{}, t + 2); }
+    if (t < nt) tile(I0{}, t);
+    if (t + 1 < nt) tile(I1{}, t + 1);
+  }
+  if (myq < Tn) {
+    T* dst = reinterpret_cast<T*>(p.dq) + ((int64_t)b * Tn + myq) * p.ld_d + h * 64;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x16_t& a = acc[t2];
+        uint32_t ax = pack_bf16x2(a[8 * m + 0] * p.scale, a[8 * m + 1] * p.scale), ay = pack_bf16x2(a[8 * m + 2] * p.scale, a[8 * m + 3] * p.scale);
+        uint32_t bx = pack_bf16x2(a[8 * m + 4] * p.scale, a[8 * m + 5] * p.scale), by = pack_bf16x2(a[8 * m + 6] * p.scale, a[8 * m + 7] * p.scale);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        *reinterpret_cast<uint4*>(dst + 32 * t2 + 16 * m + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+      }
+  }
+}
+
 }  // namespace
 
 bool attn_bwd_pipe_supported(const AttnParams& p) {
@@ -356,7 +473,14 @@ int launch_attn_bwd_pipe(const AttnParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     return check_launch("peneo_attn_bwd(pipe)");
   };
-  return p.drop_p > 0.f ? go(attn_bwd_pipe_kernel<true>, LDS_BYTES) : go(attn_bwd_pipe_kernel<false>, LDS_BYTES);
+  int rc = p.drop_p > 0.f ? go(attn_bwd_pipe_kernel<true>, LDS_BYTES) : go(attn_bwd_pipe_kernel<false>, LDS_BYTES);
+  if (rc) return rc;
+  // dQ from the slab just written
+  static const bool dq_pipe = [] { const char* e = getenv("PENEO_ATTN_DQ_PIPE"); return !e || atoi(e) != 0; }();
+  if (!dq_pipe || ((reinterpret_cast<uintptr_t>(p.dq) & 15) != 0)) return 1;   // 1: the caller launches attn_dq_from_ds_kernel
+  const dim3 qgrid((unsigned)((int64_t)((p.T + 127) / 128) * p.nh * p.B));
+  hipLaunchKernelGGL(attn_dq_pipe_kernel, qgrid, dim3(256), 3 * DQ_BUF, st, p);
+  return check_launch("peneo_attn_bwd(dq pipe)");
 }
 
 }  // namespace peneo
