@@ -340,9 +340,14 @@ def main():
         # fewer steps; the gradient path is the one the parity tests use)
         model.eval()
         tb = batches[0]
-        for g_ in opt.param_groups:      # (the groups were built at 5e-5 / 1.5e-3 for the timing above)
-            g_["lr"] = g_["lr"] * (args.trained_agree_lr / 5e-5)
-        for it in range(args.trained_agree_steps):
+        base_lrs = [g_["lr"] * (args.trained_agree_lr / 5e-5) for g_ in opt.param_groups]   # (built at 5e-5 / 1.5e-3 for the timing above)
+        nst = args.trained_agree_steps
+        for it in range(nst):
+            # the reference recipe's schedule shape (README.md:218-241: warm-up, then linear decay): without the decay the last
+            # steps still move the decision boundary of a few positives and the count below depends on where the run happens to stop
+            f_ = min(1.0, (it + 1) / max(1, nst // 20)) * max(0.0, 1.0 - it / nst)
+            for g_, lr0 in zip(opt.param_groups, base_lrs):
+                g_["lr"] = lr0 * f_
             for p_ in model.parameters():
                 p_.grad = None
             out_t = net(**tb)
