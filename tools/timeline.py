@@ -13,7 +13,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    name = name.replace("void ", "").replace("peneo::", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("peneo::", "")
     cut = name.find("(")
     return (name if cut < 0 else name[:cut])[:70]
 
