@@ -373,7 +373,6 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       __builtin_amdgcn_wave_barrier();
     };
     const f2 nl2e = f2{-1.4426950408889634f, -1.4426950408889634f};
-    const bool odd = (lane & 1) != 0;
 
     // one producer iteration: Z(s+1) accumulates into zw (fragments hand-issued one chunk ahead, two register sets, each
     // re-loaded only BEHIND the following chunk's MFMAs); E(s) reads zr (written during the previous iteration)
@@ -381,27 +380,40 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
       constexpr bool DOZ = decltype(z_c)::value, DOE = decltype(e_c)::value;
       const uint32_t zs = ring + ((s + 1) & 3) * HALF_BYTES + half * 512;
       const uint32_t za0 = zs + ((r32 ^ (4 * half)) << 4), za1 = zs + ((r32 ^ (4 * half + 8)) << 4);   // even / odd fragments
-      char* myT = sT + ((s & 1) * 4 + grp) * 2048;
       pb_u32x4 fa[PB_MAXC], fb[PB_MAXC];
+      // (defined without an instruction: the "+v" ties in `landed` want a value, any value, in the sets a short chunk leaves unused)
 #pragma unroll
-      for (int i = 0; i < PB_MAXC; ++i) { fa[i] = pb_u32x4{0u, 0u, 0u, 0u}; fb[i] = fa[i]; }
+      for (int i = 0; i < PB_MAXC; ++i) { asm volatile("" : "=v"(fa[i])); asm volatile("" : "=v"(fb[i])); }
       if constexpr (DOZ) {
+        // The accumulator of Z(s+1) starts at b1 + m instead of 0: the first-layer bias of the lane's hidden unit and, with the K12
+        // dropout, the element's f16 addend (0 = keep, -30000 = drop; written by the consumer waves one iteration ago) - the 16
+        // moves that zeroed it become 16 v_fma_mix_f32 and the E phase needs neither the bias add nor the mask.  Adding -30000 to
+        // the pre-activation zeroes y = z sigmoid(z) AND SiLU'(z) (so dz).
+        const float nb1 = sB1[(s + 1) * 32 + r32];
+        if constexpr (DROP) {
+          const pb_u32x4* mp = reinterpret_cast<const pb_u32x4*>(sMask + (((((s + 1) & 1) * 4 + grp) * 32 + r32) * 2 + half) * 16);
+          const pb_u32x4 mk0 = mp[0], mk1 = mp[1];
+          const uint32_t mw[8] = {mk0.x, mk0.y, mk0.z, mk0.w, mk1.x, mk1.y, mk1.z, mk1.w};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zw[r] = 0.f;
-        asm volatile("" : "+v"(zw));   // opaque zero: a literal 0 as srcC lets the compiler overlap the chain's destination with its B operand
+          for (int i = 0; i < 8; ++i) {     // registers 2i, 2i + 1 = halves (lo, hi) of dword i of the 16 addends
+            float lo, hi;
+            asm volatile("v_fma_mix_f32 %0, %2, 1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+                         "v_fma_mix_f32 %1, %2, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                         : "=&v"(lo), "=&v"(hi) : "v"(mw[i]), "v"(nb1));
+            zw[2 * i] = lo; zw[2 * i + 1] = hi;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zw[r] = nb1;
+        }
+        asm volatile("" : "+v"(zw));   // opaque: a srcC the compiler can see through lets it overlap the chain's destination with its B operand
       }
       uint2 cw2 = make_uint2(0u, 0u);
-      float cb1 = 0.f;
-      if constexpr (DOE) { cw2 = sW2p[s * 32 + r32]; cb1 = sB1[s * 32 + r32]; }
-      // K12 dropout: 16 f16 addends (0 / -30000) for this lane's (unit, half) = its 16 accumulator registers, written by the
-      // consumer waves one iteration ago.  Adding -30000 to the pre-activation zeroes y = z sigmoid(z) AND SiLU'(z) (so dz):
-      // one v_fma_mix_f32 per element masks both
-      pb_u32x4 mk0 = pb_u32x4{0u, 0u, 0u, 0u}, mk1 = mk0;
-      if constexpr (DOE && DROP) {
-        const pb_u32x4* mp = reinterpret_cast<const pb_u32x4*>(sMask + ((((s & 1) * 4 + grp) * 32 + r32) * 2 + half) * 16);
-        mk0 = mp[0]; mk1 = mp[1];
-      }
-      const f2 b1 = f2{cb1, cb1};
+      if constexpr (DOE) cw2 = sW2p[s * 32 + r32];
+      // dz tile of this slab: element (pair row R, unit r32) is one bf16 at byte 2 r32 of the row, its 16-byte slot XORed with
+      // (R >> 2) & 3 = (rowc >> 2) + half; rowc >> 2 is even for the rows of registers 0-7 / 16-.. and takes two values mod 4
+      const uint32_t tbase = lds_addr(sT) + ((s & 1) * 4 + grp) * 2048 + half * 256 + ((2 * r32) & 15);
+      const uint32_t tA = tbase + ((((r32 >> 3) ^ half)) << 4), tB = tbase + ((((r32 >> 3) ^ half ^ 2)) << 4);
       // dy[pair, hid] = sum_c g[pair, c] W2[c, hid] on the matrix cores: B operand = this lane's column of W2 (k = class:
       // lanes 0-31 hold (w0, w1, w2, 0 ...), lanes 32-63 the zero half), same accumulator layout as z
       f32x16_t dy;
@@ -424,9 +436,9 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         // d[3] of the debug buffer: ticks the producer spends in these waits (fragment reads of the next chunk + its own tile stores)
         const unsigned long long tl0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
 #endif
-        // the next chunk's fragments have landed; the dz tile store this chunk just issued (younger, and the LDS completes a wave's
-        // operations in order) may still be in flight: waiting for it too cost the producers a store latency per chunk
-        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]) : [n] "n"((DOE && decltype(in_chunk)::value) ? 1 : 0) : "memory");
+        // the next chunk's fragments have landed; the two dz tile stores this chunk just issued (younger, and the LDS completes a wave's
+        // operations in order) may still be in flight: waiting for them too cost the producers a store latency per chunk
+        asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(d_[0]), "+v"(d_[1]), "+v"(d_[2]) : [n] "n"((DOE && decltype(in_chunk)::value) ? 2 : 0) : "memory");
 #ifdef PB_PROF
         if (p.dbg) { const unsigned long long tl1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_land += tl1 - tl0; }
 #endif
@@ -443,16 +455,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         if constexpr (J + 1 < 8) issue(std::integral_constant<int, J + 1>{}, nxt);
         if constexpr (DOE) {
           constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
-          const int row0 = rowc + 4 * half;
-          f2 zz = f2{zr[r0], zr[r0 + 1]} + b1;
-          if constexpr (DROP) {
-            // registers r0, r0 + 1 = halves (lo, hi) of dword r0 / 2 of the 16 f16 addends
-            const uint32_t mw = (J < 4) ? (J == 0 ? mk0.x : J == 1 ? mk0.y : J == 2 ? mk0.z : mk0.w)
-                                        : (J == 4 ? mk1.x : J == 5 ? mk1.y : J == 6 ? mk1.z : mk1.w);
-            asm volatile("v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-                         "v_fma_mix_f32 %1, %2, 1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                         : "+v"(zz.x), "+v"(zz.y) : "v"(mw));
-          }
+          const f2 zz = f2{zr[r0], zr[r0 + 1]};       // bias and dropout addend are in the accumulator since its first MFMA
           const f2 t = zz * nl2e;
           const f2 den = f2{__builtin_amdgcn_exp2f(t.x) + 1.f, __builtin_amdgcn_exp2f(t.y) + 1.f};
           const f2 sg = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
@@ -460,14 +463,12 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
           // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
           const f2 dzv = f2{dy[r0], dy[r0 + 1]} * fma2(f2{-y.x, -y.y}, sg, sg + y);
           yv[r0] = y.x; yv[r0 + 1] = y.y;
-          sbx += dzv.x; sby += dzv.y;
-          const float give = odd ? dzv.x : dzv.y;
-          const float got = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));
-          const uint32_t packed = odd ? pack_bf16x2(got, dzv.y) : pack_bf16x2(dzv.x, got);
-          const int trow = row0 + (lane & 1);
-          const int boff = (r32 & ~1) * 2;
-          const int f = ((rowc >> 2) + half) & 3;
-          *reinterpret_cast<uint32_t*>(myT + trow * 64 + ((((boff >> 4) ^ f) << 4) | (boff & 15))) = packed;
+          if constexpr (J == 0) { sbx = dzv.x; sby = dzv.y; } else { sbx += dzv.x; sby += dzv.y; }
+          // rows rowc, rowc + 1 (+ 4 half) of the lane's unit: one conversion, two 16-bit stores (the halves of one register); the
+          // form with one 32-bit store per lane pair cost four more VALU instructions per two elements (exchange + selects)
+          const uint32_t packed = pack_bf16x2(dzv.x, dzv.y);
+          asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3"
+                       :: "v"(((rowc >> 2) & 2) ? tB : tA), "v"(packed), "n"(rowc * 64), "n"(rowc * 64 + 64) : "memory");
         }
         if constexpr (J + 1 < 8) landed(nxt, std::true_type{});
       };
@@ -541,28 +542,30 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
 #pragma unroll
       for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
     T* dz_row = p.dz + row * ncol + 8 * half;
-    __syncthreads();                                          // matches the producers' barrier
     const uint32_t drop_key = DROP ? pair_drop_key(p.drop_seed, b) : 0u;
     const uint32_t drop_base = (uint32_t)(mypair * nslab * 2) + (uint32_t)half;
     // this lane's pair as the producers see it: accumulator register r of the lanes of half hp, R = (r & 3) + 8 (r >> 2) + 4 hp
     const int mreg = (r32 & 3) + 4 * (r32 >> 3), mhp = (r32 >> 2) & 1;
+    // addends of slab q for the producers' Z(q) (the accumulator's start value): lane = (pair r32 of the group, half) walks the
+    // forward's chain of 16 fields = units 8g + 4 half + e and stores one f16 per unit at [unit][half of the pair's register][register]
+    auto masks_of = [&](int q) {
+      _Float16* mrow = sMask + (((q & 1) * 4 + grp) * 32 * 2 + mhp) * 16 + mreg;
+      uint32_t st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)q);
+      const uint32_t inc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)q);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        st = pair_drop_step(st, inc);
+        const int unit = 8 * (i >> 2) + 4 * half + (i & 3);
+        mrow[unit * 32] = (st >> 16) >= p.drop_thr16 ? (_Float16)0.f : (_Float16)(-30000.f);
+      }
+    };
+    if constexpr (DROP) masks_of(0);                          // Z(0) runs in iteration -1
+    __syncthreads();                                          // matches the producers' barrier
     for (int s = -1; s <= nslab; ++s) {
       top();
-      if constexpr (DROP) {
-        // addends of slab s + 1 for the producers' E(s + 1): lane = (pair r32 of the group, half) walks the forward's chain of
-        // 16 fields = units 8g + 4 half + e and stores one f16 per unit at [unit][half of the pair's register][register]
-        if (s + 1 < nslab) {
-          _Float16* mrow = sMask + ((((s + 1) & 1) * 4 + grp) * 32 * 2 + mhp) * 16 + mreg;
-          uint32_t st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(s + 1));
-          const uint32_t inc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(s + 1));
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            st = pair_drop_step(st, inc);
-            const int unit = 8 * (i >> 2) + 4 * half + (i & 3);
-            mrow[unit * 32] = (st >> 16) >= p.drop_thr16 ? (_Float16)0.f : (_Float16)(-30000.f);
-          }
-        }
-      }
+      // Z(s + 2) starts at the top of iteration s + 1: its addends are written during iteration s into the buffer Z(s) read its
+      // start values from at the top of iteration s - 1
+      if constexpr (DROP) { if (s + 2 < nslab) masks_of(s + 2); }
       if (s < 1) dma_iter(s);
       if (s >= 1) {
         const int u = s - 1;

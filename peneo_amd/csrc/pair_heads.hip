@@ -884,31 +884,34 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   auto body = [&](auto m_c, auto e_c, int slab, f32x16_t& zw, const f32x16_t& zr) {
     constexpr bool DOM = decltype(m_c)::value, DOE = decltype(e_c)::value;
     const uint32_t wb = sW_l + (slab % NSTAGE) * SLAB_BYTES;
+    // (registers the "+v" ties below want a value in are DEFINED by an empty statement, not by an instruction: the zero moves this
+    // replaces were 26 VALU slots per slab)
     ph_u32x4 bv[4], fs[NS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = ph_u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(bv[i]));
 #pragma unroll
-    for (int i = 0; i < NS; ++i) fs[i] = ph_u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < NS; ++i) asm volatile("" : "=v"(fs[i]));
     uint32_t st = 0u, sinc = 0u;
-    float t[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
+    float t[4], u[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { asm volatile("" : "=v"(t[e])); asm volatile("" : "=v"(u[e])); }
     uint32_t yp[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) yp[i] = 0u;
-    if constexpr (DOE) {
-      // accumulator registers 4g .. 4g+3 = hidden rows 8g + 4 half + 0..3 of the slab: one 16-byte bias read per group
-      const uint32_t ba = sB1_l + (uint32_t)(slab - 1) * 128;
+    for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(yp[i]));
+    if constexpr (DOE && DROP) { st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); sinc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); }
+    if constexpr (DOM) {
+      // The chain's accumulator STARTS at the first-layer bias: registers 4g .. 4g+3 = hidden rows 8g + 4 half + 0..3 of the slab, one
+      // 16-byte read per group straight into the accumulator's registers - the epilogue needs no bias add (16 VALU slots per slab)
+      const uint32_t ba = sB1_l + (uint32_t)slab * 128;
       ph_dsr<0>(bv[0], ba); ph_dsr<32>(bv[1], ba); ph_dsr<64>(bv[2], ba); ph_dsr<96>(bv[3], ba);
-      if constexpr (DROP) { st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); sinc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); }
+      ph_static_for<LA>([&](auto ic) { constexpr int I = decltype(ic)::value; ph_dsr<I * 1024>(fs[I], wb); });
     }
-    if constexpr (DOM) ph_static_for<LA>([&](auto ic) { constexpr int I = decltype(ic)::value; ph_dsr<I * 1024>(fs[I], wb); });
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) :: "memory");
     // piece q of the epilogue: group g = q / 6 (accumulator registers 4g .. 4g+3), step q % 6
     auto piece = [&](auto qc) {
       constexpr int Q = decltype(qc)::value, G = Q / 6, S = Q % 6;
       if constexpr (S == 0) {
-        const float bb[4] = {__uint_as_float(bv[G].x), __uint_as_float(bv[G].y), __uint_as_float(bv[G].z), __uint_as_float(bv[G].w)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { t[e] = zr[4 * G + e] + bb[e]; u[e] = t[e] * -1.4426950408889634f; }
+        for (int e = 0; e < 4; ++e) { t[e] = zr[4 * G + e]; u[e] = t[e] * -1.4426950408889634f; }
       } else if constexpr (S == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = __builtin_amdgcn_exp2f(u[e]);
@@ -947,8 +950,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fs[K % NS]) : [n] "n"(younger) : "memory");
         // (the bias rows were requested in front of the fragments: they have landed with the first of these waits; the empty
         // statement keeps the compiler from using their registers any earlier)
-        if constexpr (K == 0 && DOE) asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
-        if constexpr (K == 0) ph_mma0(fs[0], xf[0].v, zw); else ph_mma(fs[K % NS], xf[K].v, zw);
+        if constexpr (K == 0) {
+          asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+          zw = __builtin_bit_cast(f32x16_t, __builtin_shufflevector(__builtin_shufflevector(bv[0], bv[1], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                     __builtin_shufflevector(bv[2], bv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+        }
+        ph_mma(fs[K % NS], xf[K].v, zw);
         if constexpr (K + LA < KS) ph_dsr<(K + LA) * 1024>(fs[(K + LA) % NS], wb);
         if constexpr (DOE) {
           ph_static_for<(K + 1) * 24 / KS - K * 24 / KS>([&](auto ic) { piece(std::integral_constant<int, K * 24 / KS + decltype(ic)::value>{}); });
@@ -956,7 +964,8 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         __builtin_amdgcn_sched_barrier(0);
       });
       // this slab's second-layer fragments, for its epilogue one iteration later
-      ph_u32x4 na = ph_u32x4{0u, 0u, 0u, 0u}, nb = na;
+      ph_u32x4 na, nb;
+      asm volatile("" : "=v"(na)); asm volatile("" : "=v"(nb));
       ph_dsr<KS * 1024>(na, wb); ph_dsr<(KS + 1) * 1024>(nb, wb);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(na), "+v"(nb) :: "memory");
       w2a = na; w2b = nb;
