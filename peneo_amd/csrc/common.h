@@ -38,6 +38,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
+// fp32 -> f16 pair, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -258,6 +264,25 @@ template <> __device__ __forceinline__ Frag<float> pack_frag8<float>(const float
 // accumulator element r of lane l of a 32x32 tile sits at (row, col):
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }
+
+// ---------------------------------------------------------------- block walk of the pair triangle (pair_bwd.hip; the saving forward)
+// One block = 8 rows i x 16 columns j of the triangle = 128 pairs = four groups of 32 (group g: rows 2g, 2g + 1); blocks on the
+// diagonal / the last row of blocks carry pairs outside the triangle (i > j, or beyond N).
+constexpr int PB_TI = 8, PB_TJ = 16;
+constexpr int PB_ROWS = PB_TI * PB_TJ;
+__host__ __device__ inline int pb_row_tiles(int N) { return (N + PB_TI - 1) / PB_TI; }
+__host__ __device__ inline int pb_col_tiles(int N) { return (N + PB_TJ - 1) / PB_TJ; }
+// blocks of row-tile ti: tj = first(ti) .. pb_col_tiles - 1, first(ti) = 8 ti / 16
+__host__ __device__ inline int pb_tiles_before(int ti, int N) {
+  const int m = ti >> 1;
+  return ti * pb_col_tiles(N) - (m * (m - 1) + ((ti & 1) ? m : 0));
+}
+__host__ __device__ inline int pb_num_tiles(int N) { return pb_tiles_before(pb_row_tiles(N), N); }
+// Saved activations of the classifier heads (peneo_pair_heads_fwd_save -> peneo_pair_bwd_saved): per document, block, 32-unit slab
+// of the nh * D hidden units and group one 2 KiB record = the pre-activations z = W1 x + b1 of 32 pairs x 32 units as f16, a dropped
+// unit's as -30000 (the K12 dropout; SiLU and SiLU' of that are 0).  Record = [2 halves of 16 units][32 pairs][16 units]: 32-byte
+// rows in the group's pair order, the rows of the second half stored at pair ^ 4 (bank spread of the backward's transposing reads)
+constexpr int PB_REC_BYTES = 2048;
 
 // ---------------------------------------------------------------- LDS-DMA (global -> LDS without VGPRs)
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {

@@ -31,18 +31,8 @@
 namespace peneo {
 
 constexpr int PB_WAVES = 4;
-constexpr int PB_TI = 8, PB_TJ = 16;               // rows i / columns j of the pair triangle per workgroup
-constexpr int PB_ROWS = PB_TI * PB_TJ;              // 128 pairs per workgroup, 32 per wave
 constexpr int PB_SLOTS = 256;                       // rows of the dW2 / db1 workspace the atomics are spread over
-
-__host__ __device__ inline int pb_row_tiles(int N) { return (N + PB_TI - 1) / PB_TI; }
-__host__ __device__ inline int pb_col_tiles(int N) { return (N + PB_TJ - 1) / PB_TJ; }
-// blocks of row-tile ti: tj = first(ti) .. pb_col_tiles - 1, first(ti) = 8 ti / 16
-__host__ __device__ inline int pb_tiles_before(int ti, int N) {
-  const int m = ti >> 1;
-  return ti * pb_col_tiles(N) - (m * (m - 1) + ((ti & 1) ? m : 0));
-}
-__host__ __device__ inline int pb_num_tiles(int N) { return pb_tiles_before(pb_row_tiles(N), N); }
+// (PB_TI / PB_TJ / PB_ROWS and the block walk pb_*: common.h - the forward that saves activations walks the same blocks)
 
 struct PackBwdSrc { const float* w1[PENEO_MAX_HEADS]; int num_heads; int D; };
 
@@ -75,6 +65,7 @@ struct PairBwdParams {
   const void* wp; const float* b1;
   peneo_pair_dz_args a;          // dlogits[h]: [B, P, classes[h]] of the whole batch
   bf16_t* dz; bf16_t* x;         // [B][ntiles * 128][nh*D] / [.. ][D]
+  const char* act;               // saved-activation form: the forward's records (common.h: PB_REC_BYTES), else NULL
   float* part_a; float* part_b;  // per-block partial sums [B][ntiles][8][D] / [B][ntiles][16][D] fp32
   float* ws;                     // [PB_SLOTS][4 * nh*D]
   int ntiles;
@@ -103,7 +94,7 @@ constexpr int PB_MAXC = 3;   // fragments per chunk (KS = 24)
 #define PB_DBG 0      // tools/ab_pb_dbg.sh: 65536 = packed-fp32 dz arithmetic in the wave-specialised kernel (reproduces the corruption)
 #endif
 #ifndef PB_ABLATE
-#define PB_ABLATE 0   // timing experiments (tools/): 1 no dz stores, 2 no du MFMAs, 4 no z MFMAs, 8 no epilogue, 16 no du-half DMA, 32 no DMA (ws kernel)
+#define PB_ABLATE 0   // timing experiments (tools/): 1 no dz stores, 2 no du MFMAs, 4 no z MFMAs, 8 no epilogue, 16 no du-half DMA, 32 no DMA, 64 no z fragment reads, 128 no mask generation (ws kernel)
 #endif
 
 // d_ab[b, i, :D] = sum over the blocks of row-tile i / 8 of part_a ; d_ab[b, j, D:] = sum over the blocks of column-tile j / 16 of part_b
@@ -425,7 +416,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         constexpr int J = decltype(jc)::value;
         constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
         static_assert(C <= PB_MAXC, "chunk too large");
-        if constexpr (DOZ) {
+        if constexpr (DOZ && !(PB_ABLATE & 64)) {
           if constexpr (C > 0) pb_dsr<(F0 + 0) * 1024>(d_[0], ((F0 + 0) & 1) ? za1 : za0);
           if constexpr (C > 1) pb_dsr<(F0 + 1) * 1024>(d_[1], ((F0 + 1) & 1) ? za1 : za0);
           if constexpr (C > 2) pb_dsr<(F0 + 2) * 1024>(d_[2], ((F0 + 2) & 1) ? za1 : za0);
@@ -559,13 +550,13 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_ws_kernel(PairBwdPa
         mrow[unit * 32] = (st >> 16) >= p.drop_thr16 ? (_Float16)0.f : (_Float16)(-30000.f);
       }
     };
-    if constexpr (DROP) masks_of(0);                          // Z(0) runs in iteration -1
+    if constexpr (DROP && !(PB_ABLATE & 128)) masks_of(0);    // Z(0) runs in iteration -1
     __syncthreads();                                          // matches the producers' barrier
     for (int s = -1; s <= nslab; ++s) {
       top();
       // Z(s + 2) starts at the top of iteration s + 1: its addends are written during iteration s into the buffer Z(s) read its
       // start values from at the top of iteration s - 1
-      if constexpr (DROP) { if (s + 2 < nslab) masks_of(s + 2); }
+      if constexpr (DROP && !(PB_ABLATE & 128)) { if (s + 2 < nslab) masks_of(s + 2); }
       if (s < 1) dma_iter(s);
       if (s >= 1) {
         const int u = s - 1;
@@ -692,6 +683,14 @@ template <int OFF> __device__ __forceinline__ void pb_trd(pb_u32x2& d, uint32_t 
 template <int OFF> __device__ __forceinline__ void pb_dsw16(uint32_t a, uint32_t v) {
   asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
 }
+// ("+v": the destination counts as live before the read, so the register allocator cannot fold two rotating sets into one)
+template <int OFF> __device__ __forceinline__ void pb_trd_tied(pb_u32x2& d, uint32_t a) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "+v"(d) : "v"(a), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void pb_lgkm(pb_u32x2& a, pb_u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void pb_lgkm4(pb_u32x4& a, pb_u32x4& b, pb_u32x2& c, pb_u32x2& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
 constexpr int pb_uoff(int f) { return (f >> 1) * 2048 + (f & 1) * 256; }
 constexpr int pb_mask_steps(int nz, int j) { return j * 16 / nz; }   // mask steps done before chunk j of nz
 // registers an inline-asm read fills are pinned behind the wait that covers it
@@ -714,6 +713,309 @@ __device__ __forceinline__ void pb_dma_piece(uint32_t voff_lane, const char* bas
 }
 __device__ __forceinline__ void pb_mma_acc(const pb_u32x4& a, const pb_u32x4& b, f32x16_t& acc) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// ================================================================================================
+// Saved-activation form (bf16, D = 384; peneo_pair_bwd_saved).  The forward (pair_heads_fwd_hand_kernel<.., SAVE>) walked the pairs
+// in THESE blocks and left, per group and 32-unit slab, the pre-activations z (f16, a dropped unit's as -30000) as a [32 pairs][32 units]
+// tile, and x = SiLU(a_i + b_j) in block-row order.  What is left of the kernel above:
+//   producers (waves 0-3, group g):  dy = g W2 (one MFMA), y and SiLU'(z) from the saved z (the E phase of the kernel above, z read as
+//       the f16 half it was saved as), dz = dy SiLU'(z), the dz tile for the consumers, the db1 sums, dW2 sums = g^T y (two MFMAs) -
+//       no first-layer product (24 of the 51 MFMAs per slab and their 24 KiB of fragment reads), no dropout chain, no x
+//   consumers (waves 4-7):           du += dz W1 (24 MFMAs per slab), dz rows to memory, the column-sum flush, at the end d_a / d_b
+// A group's record (2 KiB) arrives by LDS-DMA three slabs ahead through a ring of four; the producer reads its accumulator-layout
+// values with ds_read_b64_tr_b16 (16 lanes x 4 consecutive units of one pair row in, 4 consecutive pairs of one unit out: lane & 31 =
+// unit, registers = pairs, the layout dy has).  The weight ring holds three slabs (only the consumers read it).
+// vm counter: the producers only ever have record pieces in flight (2 per slab: all loads, in order -> vmcnt(4) = "slab s has
+// landed"); the consumers have weight pieces (6 per wave and slab), the dz row stores and the flush atomics: loads and writes may
+// retire out of order with each other, so the count that proves "the 6 pieces of slab s-1 are in" is 6.
+// ================================================================================================
+template <int KS, bool DROP>
+__global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdParams p) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF_BYTES = KS * 1024;
+  constexpr int NDT = KS / 2;
+  constexpr int PPC = KS / 4;                                // weight pieces per consumer wave and slab
+  static_assert(KS % 4 == 0, "weight pieces are dealt to four consumer waves");
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, r32 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave < 4;
+  const int grp = wave & 3;
+  const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
+  char* sA = smem;                                                          // [3][HALF_BYTES] weight ring: slab s in slot s % 3
+  char* sR = smem + 3 * HALF_BYTES;                                         // [4][4 groups][PB_REC_BYTES] record ring: slab s in slot s & 3
+  uint2* sW2p = reinterpret_cast<uint2*>(sR + 4 * 4 * PB_REC_BYTES);        // [ncol]: the column's W2 rows as bf16 (w0, w1 | w2, 0)
+  float4* sG = reinterpret_cast<float4*>(sW2p + ncol);                      // [4][32]
+  float4* sPart = sG + 4 * 32;                                              // [2][4][32]
+  char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
+
+  int ti = 0;
+  {
+    const int nti = pb_row_tiles(N);
+    while (ti + 1 < nti && pb_tiles_before(ti + 1, N) <= (int)blockIdx.x) ++ti;
+  }
+  const int tj = (ti >> 1) + ((int)blockIdx.x - pb_tiles_before(ti, N));
+  const int b = blockIdx.y;
+  const int i0 = ti * PB_TI + 2 * grp, j0 = tj * PB_TJ;
+  const int pi = i0 + (r32 >> 4), pj = j0 + (r32 & 15);
+  const bool pair_ok = pi < N && pj < N && pi <= pj;
+  const int ci = min(pi, N - 1), cj = min(pj, N - 1);
+  const int64_t mypair = pair_row_start(ci, N) + (cj - ci);
+  const int64_t rows_per_doc = (int64_t)p.ntiles * PB_ROWS;
+  const int64_t row = (int64_t)b * rows_per_doc + (int64_t)blockIdx.x * PB_ROWS + grp * 32 + r32;
+  const int nslab = ncol / 32, spb = D / 32;
+  const T* abd = p.ab + (int64_t)b * N * 2 * D;
+
+  for (int n = tid; n < ncol; n += PW_WAVES * 64) {
+    const int h = n / D, k = n - h * D, Cn = p.a.classes[h];
+    const float ds = DROP ? p.drop_scale : 1.f;     // dy = g W2 / (1 - p): the scale of the kept units rides on the W2 rows
+    sW2p[n] = make_uint2(pack_bf16x2(ds * p.a.w2[h][k], Cn > 1 ? ds * p.a.w2[h][(int64_t)D + k] : 0.f),
+                         pack_bf16x2(Cn > 2 ? ds * p.a.w2[h][(int64_t)2 * D + k] : 0.f, 0.f));
+  }
+  const uint32_t ring = lds_addr(sA), recs = lds_addr(sR);
+  auto top = [&](auto n_c) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(decltype(n_c)::value) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (producer) {
+    // ---------------------------------------------------------------- producer: dz, db1 / dW2 sums
+    // scale_h * dlogits_h of the lane's pair for every head, read once (lanes 0-31; zero for pairs outside the triangle)
+    float gl[PENEO_MAX_HEADS][3];
+#pragma unroll
+    for (int h = 0; h < PENEO_MAX_HEADS; ++h) {
+      gl[h][0] = 0.f; gl[h][1] = 0.f; gl[h][2] = 0.f;
+      if (h < nh && lane < 32 && pair_ok) {
+        const int Cn = p.a.classes[h];
+        const float sc = p.a.scale[h];
+        const float* dl = p.a.dlogits[h] + ((int64_t)b * p.P + mypair) * Cn;
+        gl[h][0] = dl[0] * sc;
+        if (Cn > 1) gl[h][1] = dl[1] * sc;
+        if (Cn > 2) gl[h][2] = dl[2] * sc;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // from here on this wave's vm counter only sees its record pieces
+    // record of slab s: 2 pieces of 1 KiB into slot s & 3
+    const char* rsrc = p.act + ((((int64_t)b * p.ntiles + blockIdx.x) * nslab * 4 + grp) * PB_REC_BYTES) + lane * 16;
+    auto request = [&](int s) {
+      const char* src = rsrc + (int64_t)min(s, nslab - 1) * (4 * PB_REC_BYTES);     // (past the end: the last slab again, into a free slot)
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(recs + ((s & 3) * 4 + grp) * PB_REC_BYTES);
+      lds_dma_1k<0>(src, dst); lds_dma_1k<1024>(src, dst);
+    };
+    request(0); request(1); request(2);
+    // MFMA operands of the current head (see the kernel above): gA = A operand of dy, gT0 / gT1 = A operands of the dW2 sums
+    pb_u32x4 gA = pb_u32x4{0u, 0u, 0u, 0u}, gT0 = gA, gT1 = gA;
+    auto stage_g = [&](int h) {
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+      for (int k = 0; k < PENEO_MAX_HEADS; ++k) { gx = (k == h) ? gl[k][0] : gx; gy = (k == h) ? gl[k][1] : gy; gz = (k == h) ? gl[k][2] : gz; }
+      gA = pb_u32x4{pack_bf16x2(gx, gy), pack_bf16x2(gz, 0.f), 0u, 0u};         // lanes >= 32 (k = 8..15) and bad pairs: zeros
+      float* gt = reinterpret_cast<float*>(sG + grp * 32);                        // [3][32] floats: g_c of pair
+      if (lane < 32) { gt[lane] = gx; gt[32 + lane] = gy; gt[64 + lane] = gz; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int c = r32;                                                          // class row of this lane in gT
+      float v[16];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e4 = 0; e4 < 2; ++e4) {
+          const float4 q = c < 3 ? *reinterpret_cast<const float4*>(gt + c * 32 + 16 * kk + 8 * e4 + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[8 * kk + 4 * e4 + 0] = q.x; v[8 * kk + 4 * e4 + 1] = q.y; v[8 * kk + 4 * e4 + 2] = q.z; v[8 * kk + 4 * e4 + 3] = q.w;
+        }
+      gT0 = pb_u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      gT1 = pb_u32x4{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // transposing reads of a record (two 1 KiB halves hg of 16 units, 32-byte rows, the second half's rows at pair ^ 4: common.h): the
+    // 16-lane group (hg = (lane >> 4) & 1, half) supplies, for quad qd, rows 8 qd + 4 half + r (r = (lane & 15) >> 2), units 16 hg + 4 c ..
+    // + 3 (c = lane & 3) and receives pairs 8 qd + 4 half + 0..3 of unit 16 hg + (lane & 15) = lane & 31
+    const uint32_t tr_l = (uint32_t)(((lane >> 4) & 1) * 1024 + ((4 * (half ^ ((lane >> 4) & 1)) + ((lane & 15) >> 2)) * 32) + (lane & 3) * 8);
+    const uint32_t tbase = lds_addr(sT) + grp * 2048 + half * 256 + ((2 * r32) & 15);
+    const uint32_t tA0 = tbase + ((((r32 >> 3) ^ half)) << 4), tB0 = tbase + ((((r32 >> 3) ^ half ^ 2)) << 4);
+    const float nl2e = -1.4426950408889634f;
+    __syncthreads();                                          // sW2p visible (matches the consumers' barrier)
+    for (int s = 0; s < nslab; ++s) {
+      top(std::integral_constant<int, 4>{});                  // record s has landed (records s + 1, s + 2 may be on their way)
+      request(s + 3);                                         // slot (s + 3) & 3: last read by E(s - 1)
+      if (s % spb == 0) stage_g(s / spb);
+      const uint2 cw2 = sW2p[s * 32 + r32];
+      const uint32_t ra = recs + ((s & 3) * 4 + grp) * PB_REC_BYTES + tr_l;
+      pb_u32x2 zv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(zv[i]));
+      pb_trd<0>(zv[0], ra); pb_trd<256>(zv[1], ra); pb_trd<512>(zv[2], ra); pb_trd<768>(zv[3], ra);
+      f32x16_t dy, acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dy[r] = 0.f; acc[r] = 0.f; }
+      {
+        const pb_u32x4 w2f = pb_u32x4{half ? 0u : cw2.x, half ? 0u : cw2.y, 0u, 0u};
+        pb_mma(gA, w2f, dy);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zv[0]), "+v"(zv[1]), "+v"(zv[2]), "+v"(zv[3]) :: "memory");
+      const uint32_t tsel[2] = {tA0 + (s & 1) * (4 * 2048), tB0 + (s & 1) * (4 * 2048)};
+      float sbx = 0.f, sby = 0.f;
+      float yv[16];
+      pb_static_for<8>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int r0 = 2 * J, rowc = (r0 & 3) + 8 * (r0 >> 2);
+        const uint32_t zw2 = (J & 1) ? zv[J >> 1].y : zv[J >> 1].x;  // registers r0, r0 + 1 = halves (lo, hi) of dword J of the 16 saved values
+        // (plain C++, compiled to v_fma_mix_f32: the compiler then also places the wait states between the dy MFMA and its first reader -
+        // an inline-asm reader gets none and read zeros for rows 0, 1)
+        const f16x2_t zh = __builtin_bit_cast(f16x2_t, zw2);
+        const float t0 = __builtin_fmaf((float)zh[0], nl2e, 0.f), t1 = __builtin_fmaf((float)zh[1], nl2e, 0.f);
+        const float sg0 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(t0) + 1.f), sg1 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(t1) + 1.f);
+        const float y0 = __builtin_fmaf((float)zh[0], sg0, 0.f), y1 = __builtin_fmaf((float)zh[1], sg1, 0.f);
+        // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
+        const float d0 = dy[r0] * fmaf(-y0, sg0, sg0 + y0), d1 = dy[r0 + 1] * fmaf(-y1, sg1, sg1 + y1);
+        yv[r0] = y0; yv[r0 + 1] = y1;
+        if constexpr (J == 0) { sbx = d0; sby = d1; } else { sbx += d0; sby += d1; }
+        const uint32_t packed = pack_bf16x2(d0, d1);
+        const uint32_t taddr = tsel[((rowc >> 2) & 2) ? 1 : 0];      // (a plain use: asm operands alone do not capture in a generic lambda)
+        asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3"
+                     :: "v"(taddr), "v"(packed), "n"(rowc * 64), "n"(rowc * 64 + 64) : "memory");
+      });
+      // dW2 sums out[c, unit] = sum_pair g[pair, c] y[pair, unit]: y as the B operand straight from its accumulator-layout registers
+      const pb_u32x4 yb0 = pb_u32x4{pack_bf16x2(yv[0], yv[1]), pack_bf16x2(yv[2], yv[3]), pack_bf16x2(yv[4], yv[5]), pack_bf16x2(yv[6], yv[7])};
+      const pb_u32x4 yb1 = pb_u32x4{pack_bf16x2(yv[8], yv[9]), pack_bf16x2(yv[10], yv[11]), pack_bf16x2(yv[12], yv[13]), pack_bf16x2(yv[14], yv[15])};
+      pb_mma(gT0, yb0, acc);
+      pb_mma(gT1, yb1, acc);
+      float sbt = sbx + sby;
+      sbt += __shfl_xor(sbt, 32);
+      const float ys = DROP ? p.drop_scale : 1.f;     // dW2 = sum g (y m) / (1 - p)
+      if (lane < 32) sPart[(s & 1) * (4 * 32) + grp * 32 + lane] = make_float4(acc[0] * ys, acc[1] * ys, acc[2] * ys, sbt);
+    }
+    top(std::integral_constant<int, 0>{});                    // iteration nslab: the consumers' U(nslab - 1); every piece of this wave has landed
+    __syncthreads();     // the consumers' reduction buffer (the rings) is free
+    __syncthreads();     // ... and filled
+  } else {
+    // ---------------------------------------------------------------- consumer: du, d_a / d_b
+    f32x16_t du[NDT];
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) du[t][r] = 0.f;
+    T* dz_row = p.dz + row * ncol + 8 * half;
+    const char* wbase = reinterpret_cast<const char*>(p.wp) + lane * 16;
+    // slab's pieces (the z-fragment image of the packed weights, third part) -> ring slot; wave w carries pieces w - 4, w, w + 4, ...
+    auto wrequest = [&](int slab, int slot) {
+      const char* src = wbase + (int64_t)min(slab, nslab - 1) * (3 * HALF_BYTES) + 2 * HALF_BYTES;
+#pragma unroll
+      for (int k = 0; k < PPC; ++k) {
+        const int q = (wave - 4) + k * 4;
+        lds_dma_1k<0>(src + q * 1024, __builtin_amdgcn_readfirstlane(ring + slot * HALF_BYTES + q * 1024));
+      }
+    };
+    wrequest(0, 0);
+    wrequest(1, 1);
+    float* wslot = p.ws + (int64_t)(blockIdx.x % PB_SLOTS) * 4 * ncol;
+    const int t_swz = (r32 >> 2) & 3;
+    __syncthreads();                                          // matches the producers' barrier
+    int slot = 0;                                             // s % 3
+    for (int s = 0; s <= nslab; ++s) {
+      // the 6 pieces of slab s - 1 are in: of this wave's operations only its newest 6 may be outstanding (header)
+      if (s < nslab) top(std::integral_constant<int, 6>{}); else top(std::integral_constant<int, 0>{});
+      if (s >= 1) {
+        const int u = s - 1, uslot = slot == 0 ? 2 : slot - 1;
+        if (wave - 4 == (u & 3) && lane < 32) {               // the column sums of slab u: four groups -> one row of the workspace
+          const float4* src = sPart + (u & 1) * (4 * 32) + lane;
+          float4 t = src[0];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) { const float4 v = src[w * 32]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+          float* dst = wslot + u * 32 + lane;
+          atomicAdd(dst, t.x); atomicAdd(dst + ncol, t.y); atomicAdd(dst + 2 * (int64_t)ncol, t.z); atomicAdd(dst + 3 * (int64_t)ncol, t.w);
+        }
+        const uint32_t ta = lds_addr(sT + ((u & 1) * 4 + grp) * 2048) + r32 * 64;
+        const int g_ = lane >> 4, hh_ = g_ >> 1, rr_ = (lane & 15) >> 2, cc_ = lane & 3, h_ = cc_ >> 1;
+        const uint32_t ub = ring + uslot * HALF_BYTES + (g_ & 1) * 1024 + ((h_ * 32 + 8 * (hh_ ^ (g_ & 1)) + rr_) << 4) + (cc_ & 1) * 8;
+        uint32_t ua0 = ub + (h_ ? 64 : 0), ua1 = ub + (h_ ? 0 : 64);
+        pb_u32x4 a0, a1;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(ta + (((0 + half) ^ t_swz) << 4)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(ta + (((2 + half) ^ t_swz) << 4)));
+        pb_u32x2 la[PB_MAXC], ha[PB_MAXC], lb[PB_MAXC], hb[PB_MAXC];
+#pragma unroll
+        for (int i = 0; i < PB_MAXC; ++i) { asm volatile("" : "=v"(la[i])); asm volatile("" : "=v"(ha[i])); asm volatile("" : "=v"(lb[i])); asm volatile("" : "=v"(hb[i])); }
+        auto trd = [ua0, ua1](auto off_c, pb_u32x2& lo, pb_u32x2& hi) {
+          constexpr int OFF = decltype(off_c)::value;
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(ua0), "n"(OFF));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(ua1), "n"(OFF));
+        };
+        auto uissue = [&](auto jc, pb_u32x2 (&lo_)[PB_MAXC], pb_u32x2 (&hi_)[PB_MAXC]) {
+          constexpr int J = decltype(jc)::value;
+          constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+          if constexpr (C > 0) trd(std::integral_constant<int, ((F0 + 0) >> 1) * 2048 + ((F0 + 0) & 1) * 256>{}, lo_[0], hi_[0]);
+          if constexpr (C > 1) trd(std::integral_constant<int, ((F0 + 1) >> 1) * 2048 + ((F0 + 1) & 1) * 256>{}, lo_[1], hi_[1]);
+          if constexpr (C > 2) trd(std::integral_constant<int, ((F0 + 2) >> 1) * 2048 + ((F0 + 2) & 1) * 256>{}, lo_[2], hi_[2]);
+        };
+        auto ulanded = [&](pb_u32x2 (&lo_)[PB_MAXC], pb_u32x2 (&hi_)[PB_MAXC]) {
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(lo_[0]), "+v"(lo_[1]), "+v"(lo_[2]), "+v"(hi_[0]), "+v"(hi_[1]), "+v"(hi_[2]), "+v"(a0), "+v"(a1) :: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        auto uchunk = [&](auto jc, pb_u32x2 (&clo)[PB_MAXC], pb_u32x2 (&chi)[PB_MAXC], pb_u32x2 (&nlo)[PB_MAXC], pb_u32x2 (&nhi)[PB_MAXC]) {
+          constexpr int J = decltype(jc)::value;
+          constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+          if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, pb_u32x4{clo[0].x, clo[0].y, chi[0].x, chi[0].y}, du[(F0 + 0) >> 1]);
+          if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, pb_u32x4{clo[1].x, clo[1].y, chi[1].x, chi[1].y}, du[(F0 + 1) >> 1]);
+          if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, pb_u32x4{clo[2].x, clo[2].y, chi[2].x, chi[2].y}, du[(F0 + 2) >> 1]);
+          if constexpr (J + 1 < 8) { uissue(std::integral_constant<int, J + 1>{}, nlo, nhi); ulanded(nlo, nhi); }
+        };
+        uissue(std::integral_constant<int, 0>{}, la, ha);
+        if (s < nslab) wrequest(s + 1, slot == 2 ? 0 : slot + 1);      // (s + 1) % 3: last read by U(s - 2); under the latency of the reads just issued
+        ulanded(la, ha);
+        *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
+        *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
+        uchunk(std::integral_constant<int, 0>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 1>{}, lb, hb, la, ha);
+        uchunk(std::integral_constant<int, 2>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 3>{}, lb, hb, la, ha);
+        uchunk(std::integral_constant<int, 4>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 5>{}, lb, hb, la, ha);
+        uchunk(std::integral_constant<int, 6>{}, la, ha, lb, hb);
+        uchunk(std::integral_constant<int, 7>{}, lb, hb, la, ha);
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    __syncthreads();     // every wave is done with the rings
+    // ---- du * SiLU'(a_i + b_j): sums over j stay in the wave, sums over i meet in LDS (the rings are dead) ----
+    float* red = reinterpret_cast<float*>(smem);                      // [4][NDT][16][32]
+    const int ia = min(i0, N - 1), ib = min(i0 + 1, N - 1);
+    float* pa = p.part_a + (((int64_t)b * p.ntiles + blockIdx.x) * PB_TI + 2 * grp + half) * D;
+#pragma unroll
+    for (int t = 0; t < NDT; ++t) {
+      const int d = 32 * t + r32;
+      const float a_lo = bf16_to_f32(abd[(int64_t)ia * 2 * D + d]), a_hi = bf16_to_f32(abd[(int64_t)ib * 2 * D + d]);
+      float bj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = min(j0 + 8 * (q >> 2) + 4 * half + (q & 3), N - 1);
+        bj[q] = bf16_to_f32(abd[(int64_t)j * 2 * D + D + d]);
+      }
+      float sa0 = 0.f, sa1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v0 = du[t][q] * silu_grad_f(a_lo + bj[q]);
+        const float v1 = du[t][8 + q] * silu_grad_f(a_hi + bj[q]);
+        sa0 += v0; sa1 += v1;
+        red[((grp * NDT + t) * 16 + 8 * (q >> 2) + 4 * half + (q & 3)) * 32 + r32] = v0 + v1;
+      }
+      sa0 += __shfl_xor(sa0, 32);
+      sa1 += __shfl_xor(sa1, 32);
+      pa[d] = half ? sa1 : sa0;
+    }
+    __syncthreads();
+    float* pb = p.part_b + ((int64_t)b * p.ntiles + blockIdx.x) * PB_TJ * D;
+    for (int e = tid - 256; e < NDT * 16 * 32; e += 256) {
+      const int c = e & 31, jl = (e >> 5) & 15, t = e >> 9;
+      float v = red[e];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += red[w * NDT * 512 + e];
+      pb[(int64_t)jl * D + 32 * t + c] = v;
+    }
+  }
 }
 
 template <int KS, bool DROP>
@@ -1230,6 +1532,19 @@ static int launch_pair_bwd_ws(const PairBwdParams& p, hipStream_t st) {
   return check_launch("peneo_pair_bwd_fused");
 }
 
+template <int KS, bool DROP>
+static int launch_pair_bwd_sv(const PairBwdParams& p, hipStream_t st) {
+  const int ncol = p.a.num_heads * p.D;
+  const size_t sh = (size_t)3 * KS * 1024 + (size_t)4 * 4 * PB_REC_BYTES + (size_t)ncol * 8 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048;
+  if (sh > 160 * 1024) { set_error("peneo_pair_bwd_saved: D=%d with %d heads needs %zu bytes of LDS", p.D, p.a.num_heads, sh); return PENEO_ERR_INVALID; }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_sv_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+    set_error("peneo_pair_bwd_saved: cannot raise dynamic LDS to %zu bytes", sh);
+    return PENEO_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL((pair_bwd_sv_kernel<KS, DROP>), dim3((unsigned)p.ntiles, (unsigned)p.B), dim3(PW_WAVES * 64), sh, st, p);
+  return check_launch("peneo_pair_bwd_saved");
+}
+
 template <int KS>
 static int launch_pair_bwd(const PairBwdParams& p, hipStream_t st) {
   return p.drop_thr16 ? launch_pair_bwd_ws<KS, true>(p, st) : launch_pair_bwd_ws<KS, false>(p, st);
@@ -1282,6 +1597,32 @@ extern "C" size_t peneo_pair_bwd_partial_bytes(int B, int N, int D) {
   return (size_t)B * pb_num_tiles(N) * (PB_TI + PB_TJ) * D * sizeof(float);
 }
 
+extern "C" int peneo_pair_bwd_saved(int dtype, const void* ab, int B, int N, int D, const void* w_packed,
+                                    const peneo_pair_dz_args* args, const void* act, void* dz, float* d_ab, float* workspace,
+                                    float* partials, peneo_stream_t stream) {
+  PENEO_REQUIRE(args && peneo_pair_save_supported(dtype, D, args->num_heads), "peneo_pair_bwd_saved: bf16, D = 384 only (peneo_pair_save_supported)");
+  PENEO_REQUIRE(ab && w_packed && act && dz && d_ab && workspace && partials && B > 0 && N > 0, "peneo_pair_bwd_saved: bad arguments");
+  PENEO_REQUIRE(args->D == D && args->scale && args->num_heads * D >= 64, "peneo_pair_bwd_saved: bad head description");
+  PENEO_REQUIRE(((reinterpret_cast<uintptr_t>(ab) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(act)) & 15) == 0,
+                "peneo_pair_bwd_saved: pointers must be 16-byte aligned");
+  for (int h = 0; h < args->num_heads; ++h)
+    PENEO_REQUIRE(args->dlogits[h] && args->w2[h] && args->classes[h] >= 1 && args->classes[h] <= 3, "peneo_pair_bwd_saved: head %d", h);
+  PairBwdParams p;
+  p.ab = reinterpret_cast<const bf16_t*>(ab); p.B = B; p.N = N; p.D = D; p.P = (int64_t)N * (N + 1) / 2;
+  p.wp = w_packed; p.b1 = nullptr; p.a = *args;
+  p.dz = reinterpret_cast<bf16_t*>(dz); p.x = nullptr; p.act = static_cast<const char*>(act); p.ws = workspace;
+  p.ntiles = pb_num_tiles(N);
+  PENEO_REQUIRE(args->drop_p >= 0.f && args->drop_p < 1.f, "peneo_pair_bwd_saved: drop_p must be in [0, 1)");
+  p.drop_thr16 = pair_drop_thr16_host(args->drop_p); p.drop_seed = args->drop_seed; p.drop_scale = pair_drop_scale_host(args->drop_p);
+  p.dbg = nullptr;
+  p.part_a = partials; p.part_b = partials + (size_t)B * p.ntiles * PB_TI * D;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = p.drop_thr16 ? launch_pair_bwd_sv<24, true>(p, st) : launch_pair_bwd_sv<24, false>(p, st);
+  if (rc != PENEO_OK) return rc;
+  hipLaunchKernelGGL(pair_bwd_reduce_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, st, p.part_a, p.part_b, N, D, p.ntiles, d_ab);
+  return check_launch("peneo_pair_bwd_saved (reduce)");
+}
+
 extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int D, const void* w_packed, const float* b1,
                                     const peneo_pair_dz_args* args, void* dz, void* x, float* d_ab, float* workspace,
                                     float* partials, peneo_stream_t stream) {
@@ -1298,7 +1639,7 @@ extern "C" int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int
   PairBwdParams p;
   p.ab = reinterpret_cast<const bf16_t*>(ab); p.B = B; p.N = N; p.D = D; p.P = (int64_t)N * (N + 1) / 2;
   p.wp = w_packed; p.b1 = b1; p.a = *args;
-  p.dz = reinterpret_cast<bf16_t*>(dz); p.x = reinterpret_cast<bf16_t*>(x); p.ws = workspace;
+  p.dz = reinterpret_cast<bf16_t*>(dz); p.x = reinterpret_cast<bf16_t*>(x); p.act = nullptr; p.ws = workspace;
   p.ntiles = pb_num_tiles(N);
   PENEO_REQUIRE(args->drop_p >= 0.f && args->drop_p < 1.f, "peneo_pair_bwd_fused: drop_p must be in [0, 1)");
   p.drop_thr16 = pair_drop_thr16_host(args->drop_p); p.drop_seed = args->drop_seed; p.drop_scale = pair_drop_scale_host(args->drop_p);

@@ -93,6 +93,9 @@ struct PairFwdParams {
   float* partials;   // [B * gridDim.x][32]: num[8] | den[8] | dl_sum[16] per workgroup
   float* dlogits[PENEO_MAX_HEADS];
   uint32_t drop_thr16, drop_seed; float drop_scale;   // K12 dropout (common.h: pair_drop_*): threshold 0 = off, scale = 1 / (1 - p)
+  // saving form (hand kernel only): the pairs are walked in the backward's blocks and the kernel leaves q / y records (common.h:
+  // PB_REC_BYTES) and x = SiLU(a_i + b_j) in block-row order for peneo_pair_bwd_saved; NULL = the plain walk, nothing saved
+  char* act; bf16_t* x_save; int ntiles;
 };
 
 constexpr float NEG_INF_F = -3.0e38f;
@@ -771,6 +774,9 @@ __global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits
 #ifdef PH_PROF
 __device__ unsigned long long* g_ph_prof;
 #endif
+#ifndef PH_ABLATE
+#define PH_ABLATE 0   // timing experiments (tools/ab_pair_fwd_save.sh): 1 the saving form without its record stores, 2 without its x stores
+#endif
 #ifndef PH_HAND_LA
 #define PH_HAND_LA 3
 #endif
@@ -802,7 +808,7 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void ph_stati
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); ph_static_for<N, I + 1>(f); }
 }
 
-template <int KS, bool DROP>
+template <int KS, bool DROP, bool SAVE>
 __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(PairFwdParams p) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -820,11 +826,28 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.D, N = p.N;
   const int b = blockIdx.y;
-  const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
-  const int64_t mypair = p0 + wave * 32 + (lane & 31);
-  const bool pair_ok = mypair < p.P;
-  int pi, pj;
-  pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
+  int64_t mypair;
+  bool pair_ok, tile_ok = false;
+  int pi, pj, tile = 0;
+  if constexpr (SAVE) {
+    // the backward's walk: a workgroup = two blocks of 8 x 16 pairs, wave = group (rows 2g, 2g + 1 of its block) - pair_bwd.hip
+    const int T2 = 2 * (int)blockIdx.x + (wave >> 2), grp = wave & 3, r32 = lane & 31;
+    tile_ok = T2 < p.ntiles;
+    tile = tile_ok ? T2 : p.ntiles - 1;
+    int ti = 0;
+    const int nti = pb_row_tiles(N);
+    while (ti + 1 < nti && pb_tiles_before(ti + 1, N) <= tile) ++ti;
+    const int tj = (ti >> 1) + (tile - pb_tiles_before(ti, N));
+    const int qi = ti * PB_TI + 2 * grp + (r32 >> 4), qj = tj * PB_TJ + (r32 & 15);
+    pair_ok = tile_ok && qi < N && qj < N && qi <= qj;
+    pi = min(qi, N - 1); pj = min(qj, N - 1);          // (rows outside the triangle: finite x / q / y, their dlogits are never read)
+    mypair = pair_ok ? pair_row_start(pi, N) + (pj - pi) : p.P - 1;
+  } else {
+    const int64_t p0 = (int64_t)blockIdx.x * PH_PAIRS;
+    mypair = p0 + wave * 32 + (lane & 31);
+    pair_ok = mypair < p.P;
+    pair_decode(pair_ok ? mypair : p.P - 1, N, pi, pj);
+  }
   const int nslab = p.num_heads * D / 32;
 
   for (int i = tid; i < p.num_heads * D; i += PH_WAVES * 64) sB1[i] = p.b1[i];
@@ -859,10 +882,14 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
         xf[4 * g + i] = pack_frag8<T>(a);
         asm volatile("" : "+v"(xf[4 * g + i].v.x), "+v"(xf[4 * g + i].v.y), "+v"(xf[4 * g + i].v.z), "+v"(xf[4 * g + i].v.w) :: "memory");
+        if constexpr (SAVE) {     // x row of the pair in block order: the B operand of the backward's dW1 = dz^T x
+          if (tile_ok && !(PH_ABLATE & 2))
+            *reinterpret_cast<uint4*>(p.x_save + ((((int64_t)b * p.ntiles + tile) * PB_ROWS + (wave & 3) * 32 + (lane & 31)) * D + 8 * half + 16 * (4 * g + i))) = xf[4 * g + i].v;
+        }
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // from here on the vm counter only sees the DMA pieces
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // from here on the vm counter only sees the DMA pieces (+ the record stores)
   __syncthreads();                                          // sB1 visible
 
   const char* wsrc = reinterpret_cast<const char*>(p.wp) + wave * (UPW * 1024) + lane * 16;
@@ -879,9 +906,30 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   const uint32_t drop_base = (uint32_t)(mypair * nslab * 2) + (uint32_t)half;
   const uint32_t thr32 = p.drop_thr16 << 16;                // field = bits 16.. of the chain state
   const uint32_t sW_l = lds_addr(sW) + lane * 16, sB1_l = lds_addr(sB1) + half * 16;
+  // records of this wave's group: slab s at + s * 4 groups * PB_REC_BYTES; the lane's 16-byte pieces at row (lane & 31), byte 16 half (+ 32)
+  // (tile layout, common.h: two 1 KiB halves of 16 units each, 32-byte rows, the second half's rows XORed with 4: every store below is
+  // 1 KiB contiguous, and the backward's transposing reads of the two halves fall on different banks)
+  char* const rec_l = SAVE ? p.act + ((((int64_t)b * p.ntiles + tile) * nslab * 4 + (wave & 3)) * PB_REC_BYTES + 16 * half) : nullptr;
+  const int rec_r0 = (lane & 31) * 32, rec_r1 = 1024 + ((lane & 31) ^ 4) * 32;
 
+  // K12 dropout.  A dropped unit's accumulator STARTS at -30000 instead of its bias: SiLU(-30000 + ...) = -0, so y needs no mask of
+  // its own and the pre-activation the saving form stores is already masked (the backward's SiLU' of it is 0 as well).  The start
+  // values of slab s + 1 are written during the epilogue of slab s - 1, into the accumulator registers that epilogue has just read
+  // (they are the registers slab s + 1 accumulates in): one v_cndmask per element, as the mask on y was.
+  auto start_values = [&](int slab_, f32x16_t& acc) {       // plain form, before the loop (slabs 0 and 1)
+    uint32_t st_ = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)slab_);
+    const uint32_t inc_ = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)slab_);
+    const float* bsrc = sB1 + slab_ * 32 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *reinterpret_cast<const float4*>(bsrc + 8 * g);
+      const float be[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { st_ = pair_drop_step(st_, inc_); acc[4 * g + e] = st_ >= thr32 ? be[e] : -30000.f; }
+    }
+  };
   // one slab: DOM = first-layer MFMAs of `slab` into zw; DOE = epilogue of slab - 1 (its accumulator: zr)
-  auto body = [&](auto m_c, auto e_c, int slab, f32x16_t& zw, const f32x16_t& zr) {
+  auto body = [&](auto m_c, auto e_c, int slab, f32x16_t& zw, f32x16_t& zr) {
     constexpr bool DOM = decltype(m_c)::value, DOE = decltype(e_c)::value;
     const uint32_t wb = sW_l + (slab % NSTAGE) * SLAB_BYTES;
     // (registers the "+v" ties below want a value in are DEFINED by an empty statement, not by an instruction: the zero moves this
@@ -895,14 +943,27 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
     float t[4], u[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { asm volatile("" : "=v"(t[e])); asm volatile("" : "=v"(u[e])); }
-    uint32_t yp[8];
+    uint32_t yp[8], zp[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(yp[i]));
-    if constexpr (DOE && DROP) { st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); sinc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(slab - 1)); }
+    for (int i = 0; i < 8; ++i) { asm volatile("" : "=v"(yp[i])); if constexpr (SAVE) asm volatile("" : "=v"(zp[i])); }
+    char* const rec = SAVE ? rec_l + (int64_t)(slab - 1) * (4 * PB_REC_BYTES) : nullptr;
+    // groups G, G + 1 done: the two halves of a pair's lanes hold 4 + 4 consecutive units of each group; a v_permlane32_swap pair makes
+    // 16 contiguous bytes per lane (lanes 0-31: group G, lanes 32-63: group G + 1)
+    auto save_rows = [&](auto gc) {
+      constexpr int G = decltype(gc)::value;
+      const auto zx = __builtin_amdgcn_permlane32_swap(zp[2 * G], zp[2 * G + 2], false, false);
+      const auto zy = __builtin_amdgcn_permlane32_swap(zp[2 * G + 1], zp[2 * G + 3], false, false);
+      if (tile_ok && !(PH_ABLATE & 1)) *reinterpret_cast<uint4*>(rec + (G == 0 ? rec_r0 : rec_r1)) = make_uint4(zx[0], zy[0], zx[1], zy[1]);
+      if constexpr ((PH_ABLATE & 1) != 0) asm volatile("" :: "v"(zx[0]), "v"(zy[0]), "v"(zx[1]), "v"(zy[1]));
+    };
+    // DROP: the chain run here belongs to slab + 1 (see start_values)
+    constexpr bool NEXT = DROP && DOM && DOE;
+    if constexpr (NEXT) { st = pair_drop_seed(drop_key, drop_base + 2u * (uint32_t)(slab + 1)); sinc = pair_drop_inc(drop_key, drop_base + 2u * (uint32_t)(slab + 1)); }
     if constexpr (DOM) {
       // The chain's accumulator STARTS at the first-layer bias: registers 4g .. 4g+3 = hidden rows 8g + 4 half + 0..3 of the slab, one
-      // 16-byte read per group straight into the accumulator's registers - the epilogue needs no bias add (16 VALU slots per slab)
-      const uint32_t ba = sB1_l + (uint32_t)slab * 128;
+      // 16-byte read per group (no dropout: straight into the accumulator's registers; dropout: the bias rows of slab + 1 for the selects
+      // below) - the epilogue needs no bias add (16 VALU slots per slab)
+      const uint32_t ba = sB1_l + (uint32_t)(DROP ? min(slab + 1, nslab - 1) : slab) * 128;
       ph_dsr<0>(bv[0], ba); ph_dsr<32>(bv[1], ba); ph_dsr<64>(bv[2], ba); ph_dsr<96>(bv[3], ba);
       ph_static_for<LA>([&](auto ic) { constexpr int I = decltype(ic)::value; ph_dsr<I * 1024>(fs[I], wb); });
     }
@@ -912,6 +973,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
       if constexpr (S == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { t[e] = zr[4 * G + e]; u[e] = t[e] * -1.4426950408889634f; }
+        if constexpr (SAVE) { zp[2 * G] = pack_f16x2(t[0], t[1]); zp[2 * G + 1] = pack_f16x2(t[2], t[3]); }
       } else if constexpr (S == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = __builtin_amdgcn_exp2f(u[e]);
@@ -922,26 +984,31 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
       } else if constexpr (S == 3) {
         u[2] = __builtin_amdgcn_rcpf(u[2]); u[3] = __builtin_amdgcn_rcpf(u[3]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = t[e] * u[e];          // y = z sigmoid(z)
+        for (int e = 0; e < 4; ++e) t[e] = t[e] * u[e];          // y = z sigmoid(z)   (-0 where the unit is dropped)
       } else if constexpr (S == 4) {
-        if constexpr (DROP) {
-          // K12 dropout: the lane's 16 hidden units of the slab are the 16 fields of ONE chain, in register order
+        if constexpr (NEXT) {
+          // the lane's 16 hidden units of a slab are the 16 fields of ONE chain, in register order
+          const float be[3] = {__uint_as_float(bv[G].x), __uint_as_float(bv[G].y), __uint_as_float(bv[G].z)};
 #pragma unroll
-          for (int e = 0; e < 3; ++e) { st = pair_drop_step(st, sinc); t[e] = st >= thr32 ? t[e] : 0.f; }
+          for (int e = 0; e < 3; ++e) { st = pair_drop_step(st, sinc); zr[4 * G + e] = st >= thr32 ? be[e] : -30000.f; }
         }
       } else {
-        if constexpr (DROP) { st = pair_drop_step(st, sinc); t[3] = st >= thr32 ? t[3] : 0.f; }
+        if constexpr (NEXT) { st = pair_drop_step(st, sinc); zr[4 * G + 3] = st >= thr32 ? __uint_as_float(bv[G].w) : -30000.f; }
         yp[2 * G] = pack_bf16x2(t[0], t[1]); yp[2 * G + 1] = pack_bf16x2(t[2], t[3]);
       }
       // anchor: the piece stays between the MFMAs it was written between
       asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(st), "+v"(sinc));
       if constexpr (S == 5) asm volatile("" : "+v"(yp[2 * G]), "+v"(yp[2 * G + 1]));
+      if constexpr (S == 0 && SAVE) asm volatile("" : "+v"(zp[2 * G]), "+v"(zp[2 * G + 1]));
+      if constexpr (S >= 4 && NEXT) asm volatile("" : "+v"(zr));
       // groups 0, 1 done: y rows 0..15 of the slab are complete -> the first second-layer MFMA
       if constexpr (Q == 11) ph_mma_late(w2a, ph_u32x4{yp[0], yp[1], yp[2], yp[3]}, lg);
       if constexpr (Q == 23) {
         if constexpr (DOM) ph_mma_late(w2b, ph_u32x4{yp[4], yp[5], yp[6], yp[7]}, lg);
         else ph_mma_late_final(w2b, ph_u32x4{yp[4], yp[5], yp[6], yp[7]}, lg);
       }
+      if constexpr (SAVE && Q == 11) save_rows(std::integral_constant<int, 0>{});
+      if constexpr (SAVE && Q == 23) save_rows(std::integral_constant<int, 2>{});
     };
     if constexpr (DOM) {
       ph_static_for<KS>([&](auto kc) {
@@ -952,9 +1019,11 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         // statement keeps the compiler from using their registers any earlier)
         if constexpr (K == 0) {
           asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
-          zw = __builtin_bit_cast(f32x16_t, __builtin_shufflevector(__builtin_shufflevector(bv[0], bv[1], 0, 1, 2, 3, 4, 5, 6, 7),
-                                                                     __builtin_shufflevector(bv[2], bv[3], 0, 1, 2, 3, 4, 5, 6, 7),
-                                                                     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+          if constexpr (!DROP)
+            zw = __builtin_bit_cast(f32x16_t, __builtin_shufflevector(__builtin_shufflevector(bv[0], bv[1], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                       __builtin_shufflevector(bv[2], bv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                                       0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+          else asm volatile("" : "+v"(zw));      // (its start values were written by the previous epilogue / before the loop)
         }
         ph_mma(fs[K % NS], xf[K].v, zw);
         if constexpr (K + LA < KS) ph_dsr<(K + LA) * 1024>(fs[(K + LA) % NS], wb);
@@ -1005,6 +1074,7 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
     }
     mark(1);
   };
+  if constexpr (DROP) { start_values(0, z0); start_values(min(1, nslab - 1), z1); }
   top(0); body(yes{}, no{}, 0, z0, z1);
   int slab = 1;
   for (; slab + 1 < nslab; slab += 2) {
@@ -1028,18 +1098,18 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
   pair_epilogue(p, lg, smem, tid, lane, wave, half, b, mypair, pair_ok);
 }
 
-template <int KS, bool DROP>
+template <int KS, bool DROP, bool SAVE>
 static int launch_pair_fwd_hand(const PairFwdParams& p, hipStream_t st) {
   const size_t slab = (size_t)slab_stride_bytes(KS * 16, 2);
   const size_t nstage = 4 * slab + 5 * 512 * 4 <= 160 * 1024 ? 4 : 3;      // as in the kernel
   size_t sh = nstage * slab + (size_t)p.num_heads * p.D * sizeof(float);
   if (sh > 160 * 1024) { set_error("peneo_pair_heads_fwd: D=%d needs %zu bytes of LDS", p.D, sh); return PENEO_ERR_INVALID; }
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_hand_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_heads_fwd_hand_kernel<KS, DROP, SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
     set_error("peneo_pair_heads_fwd: cannot raise dynamic LDS to %zu bytes", sh);
     return PENEO_ERR_LAUNCH;
   }
-  dim3 grid((unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
-  hipLaunchKernelGGL((pair_heads_fwd_hand_kernel<KS, DROP>), grid, dim3(PH_WAVES * 64), sh, st, p);
+  dim3 grid(SAVE ? (unsigned)((p.ntiles + 1) / 2) : (unsigned)((p.P + PH_PAIRS - 1) / PH_PAIRS), p.B);
+  hipLaunchKernelGGL((pair_heads_fwd_hand_kernel<KS, DROP, SAVE>), grid, dim3(PH_WAVES * 64), sh, st, p);
   return check_launch("peneo_pair_heads_fwd");
 }
 
@@ -1070,9 +1140,12 @@ template <typename T, int KS>
 static int launch_pair_fwd(const PairFwdParams& p, hipStream_t st) {
   constexpr int V = sizeof(T) == 2 ? PH_DEFAULT_VARIANT : 0;
   if constexpr (sizeof(T) == 2 && (KS == 24 || KS == 32)) {
+    if (p.act && KS == 24 && p.num_heads * p.D / 32 >= 2)
+      return p.drop_thr16 ? launch_pair_fwd_hand<KS, true, true>(p, st) : launch_pair_fwd_hand<KS, false, true>(p, st);
     if (pair_fwd_hand() && p.num_heads * p.D / 32 >= 2)
-      return p.drop_thr16 ? launch_pair_fwd_hand<KS, true>(p, st) : launch_pair_fwd_hand<KS, false>(p, st);
+      return p.drop_thr16 ? launch_pair_fwd_hand<KS, true, false>(p, st) : launch_pair_fwd_hand<KS, false, false>(p, st);
   }
+  if (p.act) { set_error("peneo_pair_heads_fwd: the saving form exists for bf16, D = 384 (peneo_pair_save_supported)"); return PENEO_ERR_INVALID; }
   return p.drop_thr16 ? launch_pair_fwd_v<T, KS, V, true>(p, st) : launch_pair_fwd_v<T, KS, V, false>(p, st);
 }
 
@@ -1442,8 +1515,8 @@ extern "C" int peneo_pair_heads_pack(int dtype, const float* const* w1, const fl
   return check_launch("peneo_pair_heads_pack");
 }
 
-extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
-                                    float* const* logits, const peneo_pair_loss* loss, peneo_stream_t stream) {
+static int pair_heads_fwd_impl(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
+                               float* const* logits, const peneo_pair_loss* loss, void* act, void* x_rows, peneo_stream_t stream) {
   PENEO_REQUIRE(ok_dt(dtype) && ab && desc && B > 0 && N > 0, "peneo_pair_heads_fwd: bad arguments");
   PENEO_REQUIRE(desc->num_heads > 0 && desc->num_heads <= PENEO_MAX_HEADS, "peneo_pair_heads_fwd: num_heads out of range");
   PENEO_REQUIRE(desc->D > 0 && desc->D % 32 == 0, "peneo_pair_heads_fwd: D must be a multiple of 32");
@@ -1471,7 +1544,31 @@ extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, con
     for (int h = 0; h < desc->num_heads; ++h) any = any || loss->tags[h];
     if (any) PENEO_REQUIRE(p.partials, "peneo_pair_heads_fwd: loss->partials workspace missing");
   }
+  if (act) {
+    PENEO_REQUIRE(x_rows && peneo_pair_save_supported(dtype, desc->D, desc->num_heads), "peneo_pair_heads_fwd_save: not supported for this dtype / D (peneo_pair_save_supported)");
+    PENEO_REQUIRE((reinterpret_cast<uintptr_t>(act) & 15) == 0 && (reinterpret_cast<uintptr_t>(x_rows) & 15) == 0, "peneo_pair_heads_fwd_save: act / x must be 16-byte aligned");
+    p.act = static_cast<char*>(act); p.x_save = static_cast<bf16_t*>(x_rows); p.ntiles = pb_num_tiles(N);
+  }
   return dtype == PENEO_BF16 ? dispatch_pair_fwd<bf16_t>(p, (hipStream_t)stream) : dispatch_pair_fwd<float>(p, (hipStream_t)stream);
+}
+
+extern "C" int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
+                                    float* const* logits, const peneo_pair_loss* loss, peneo_stream_t stream) {
+  return pair_heads_fwd_impl(dtype, ab, B, N, desc, logits, loss, nullptr, nullptr, stream);
+}
+
+extern "C" int peneo_pair_save_supported(int dtype, int D, int num_heads) {
+  return dtype == PENEO_BF16 && D == 384 && num_heads >= 1 && num_heads <= PENEO_MAX_HEADS;
+}
+extern "C" size_t peneo_pair_save_bytes(int B, int N, int num_heads, int D) {
+  return B > 0 && N > 0 && num_heads > 0 && D > 0 ? (size_t)B * pb_num_tiles(N) * (num_heads * D / 32) * 4 * PB_REC_BYTES : 0;
+}
+extern "C" int64_t peneo_pair_loss_partials_save(int B, int N) { return (int64_t)B * ((pb_num_tiles(N) + 1) / 2); }
+extern "C" int peneo_pair_heads_fwd_save(int dtype, const void* ab, int B, int N, const peneo_pair_heads_desc* desc,
+                                         float* const* logits, const peneo_pair_loss* loss, void* act, void* x_rows,
+                                         peneo_stream_t stream) {
+  PENEO_REQUIRE(act && x_rows, "peneo_pair_heads_fwd_save: null act / x");
+  return pair_heads_fwd_impl(dtype, ab, B, N, desc, logits, loss, act, x_rows, stream);
 }
 
 static int chunk_check(const char* who, int dtype, int N, int D, int i0, int i1) {

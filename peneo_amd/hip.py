@@ -148,6 +148,11 @@ SIGNATURES = {
     "peneo_pair_bwd_pack": (_i, [_vp, _i, _i, _vp, _vp]),
     "peneo_pair_bwd_partial_bytes": (_sz, [_i, _i, _i]),
     "peneo_pair_bwd_fused": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "peneo_pair_save_supported": (_i, [_i, _i, _i]),
+    "peneo_pair_save_bytes": (_sz, [_i, _i, _i, _i]),
+    "peneo_pair_loss_partials_save": (_i64, [_i, _i]),
+    "peneo_pair_heads_fwd_save": (_i, [_i, _vp, _i, _i, C.POINTER(PairHeadsDesc), _vp, C.POINTER(PairLoss), _vp, _vp, _vp]),
+    "peneo_pair_bwd_saved": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "peneo_ohem_workspace_bytes": (_sz, [_i64]),
     "peneo_ohem_ce": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "peneo_ohem_finish": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),

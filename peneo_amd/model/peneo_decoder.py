@@ -213,10 +213,17 @@ class _DecoderStage(torch.autograd.Function):
         # the Dropout between the two layers of every classifier (reference :261) acts on the [B, P, 5D] hidden inside the
         # kernel; the backward regenerates the mask from (p, seed)
         saved["k12_drop"] = (seeds.p_hidden, seeds.seed(903))
-        logits, partials, dlog = ops.pair_heads_fwd(ab, wp, b1cat, b2cat, HEAD_CLASSES, want_logits=want_logits,
-                                                    tags=tags, class_weights=cws,
-                                                    want_dlogits=need_grad and tags is not None,
-                                                    drop_p=seeds.p_hidden, drop_seed=seeds.seed(903))
+        # a step that will run the fused backward lets the forward leave the classifiers' pre-activations (f16, dropout applied) and
+        # x in the backward's block order: what autograd under autocast would have saved of reference :253-271, 2 bytes per pair and
+        # hidden unit (4.2 GB at 8 x 511 tokens) - the backward then neither repeats the first-layer product nor the dropout chain
+        save = (need_grad and tags is not None and dec.fused_bwd and dec.save_pair_act and ops.pair_bwd_supported(dt, D, len(HEAD_NAMES))
+                and ops.pair_save_supported(dt, D, len(HEAD_NAMES)))
+        res = ops.pair_heads_fwd(ab, wp, b1cat, b2cat, HEAD_CLASSES, want_logits=want_logits,
+                                 tags=tags, class_weights=cws, want_dlogits=need_grad and tags is not None,
+                                 drop_p=seeds.p_hidden, drop_seed=seeds.seed(903), save=save)
+        logits, partials, dlog = res[:3]
+        if save:
+            saved["pair_act"], saved["pair_x"] = res[3]
         outs = []
         if tags is not None and dec.le_loss.ohem:
             # OHEM: the kept pairs of each head are chosen from its finished logit map; the un-normalised dlogits of the
@@ -300,9 +307,13 @@ class _DecoderStage(torch.autograd.Function):
             wp2 = wc.get(("dec.pack2", dt), w1s, lambda: ops.pair_bwd_pack([w.detach() for w in w1s]))
             rows = ops.pair_bwd_rows(N)
             dzbuf = torch.empty((B * rows, nh * D), dtype=dt, device=dev)
-            xbuf1 = torch.empty((B * rows, D), dtype=dt, device=dev)
             dza = ops.pair_dz_args(D, HEAD_CLASSES, sv["dlog"], w2d, scale, drop_p=drop_p, drop_seed=drop_seed)
-            ops.pair_bwd_fused(ab, wp2, b1cat, dza, dzbuf, xbuf1, d_ab, dz_ws)
+            if "pair_act" in sv:
+                xbuf1 = sv.pop("pair_x")
+                ops.pair_bwd_saved(ab, wp2, dza, sv.pop("pair_act"), dzbuf, d_ab, dz_ws)
+            else:
+                xbuf1 = torch.empty((B * rows, D), dtype=dt, device=dev)
+                ops.pair_bwd_fused(ab, wp2, b1cat, dza, dzbuf, xbuf1, d_ab, dz_ws)
             # dW1 = dz^T x (2 ms of pure MFMA work, needed by nobody until the optimizer) runs on the side stream beside the
             # shrink-MLP backward and the first encoder layers, whose short kernels leave CUs idle; joined one stage later
             if dec.dw1_on_side:
@@ -615,6 +626,7 @@ class PEneoDecoder(nn.Module):
         self.bwd_chunk_pairs = int(os.environ.get("PENEO_BWD_CHUNK_PAIRS", 1 << 18))
         self.fused_dz = os.environ.get("PENEO_DZ_FUSED", "1") != "0"            # bf16: dz without x / z in memory
         self.fused_bwd = os.environ.get("PENEO_BWD_FUSED", "1") != "0"          # bf16: the whole pair-space backward in one kernel
+        self.save_pair_act = os.environ.get("PENEO_PAIR_SAVE", "1") != "0"      # D = 384: the forward saves the classifiers' pre-activations
         self.dw1_on_side = os.environ.get("PENEO_DW1_SIDE", "1") != "0"          # its dW1 GEMM beside the following stages
         self.dw1_hold = os.environ.get("PENEO_DW1_HOLD", "1") != "0"             # ... joined at the end of the backward only
         self.dw1_side_split = int(os.environ.get("PENEO_DW1_SPLIT", "0"))   # fixed split-k of that GEMM; 0: from the targets below

@@ -606,9 +606,11 @@ def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence
 def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor,
                    classes: Sequence[int], *, want_logits: bool = True, tags: Optional[Sequence[torch.Tensor]] = None,
                    class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False,
-                   drop_p: float = 0.0, drop_seed: int = 0):
+                   drop_p: float = 0.0, drop_seed: int = 0, save: bool = False):
     """ab: [B, N, 2D].  Returns (logits list | None, loss partials [n, 32] | None, dlogits list | None).
-    drop_p / drop_seed: the Dropout between the two classifier layers (train mode, model/peneo_decoder.py:261)."""
+    drop_p / drop_seed: the Dropout between the two classifier layers (train mode, model/peneo_decoder.py:261).
+    save (pair_save_supported): the launch also leaves the hidden activations the backward needs; returns a fourth value
+    (act [bytes] uint8, x_rows [B * pair_bwd_rows(N), D]) for pair_bwd_saved."""
     _c(ab)
     B, N, D2 = ab.shape
     D = D2 // 2
@@ -627,7 +629,8 @@ def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: tor
     dlog = None
     if tags is not None:
         loss = hip.PairLoss()
-        partials = torch.empty((lib().peneo_pair_loss_partials(B, N), 32), dtype=torch.float32, device=ab.device)
+        nrows = lib().peneo_pair_loss_partials_save(B, N) if save else lib().peneo_pair_loss_partials(B, N)
+        partials = torch.empty((nrows, 32), dtype=torch.float32, device=ab.device)
         if want_dlogits:
             dlog = [torch.empty((B, P, c), dtype=torch.float32, device=ab.device) for c in classes]
         for h in range(nh):
@@ -637,10 +640,23 @@ def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: tor
             if dlog is not None:
                 loss.dlogits[h] = ptr(dlog[h])
         loss.partials = ptr(partials)
+    if save:
+        act = torch.empty(lib().peneo_pair_save_bytes(B, N, nh, D), dtype=torch.uint8, device=ab.device)
+        x_rows = torch.empty((B * pair_bwd_rows(N), D), dtype=ab.dtype, device=ab.device)
+        with kernel_timer("pair_heads_fwd"):
+            check(lib().peneo_pair_heads_fwd_save(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
+                                                  C.byref(loss) if loss is not None else None, ptr(act), ptr(x_rows), stream()),
+                  "peneo_pair_heads_fwd_save")
+        return logits, partials, dlog, (act, x_rows)
     with kernel_timer("pair_heads_fwd"):
         check(lib().peneo_pair_heads_fwd(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
                                          C.byref(loss) if loss is not None else None, stream()), "peneo_pair_heads_fwd")
     return logits, partials, dlog
+
+
+def pair_save_supported(dtype, D: int, num_heads: int) -> bool:
+    """True when peneo_pair_heads_fwd_save / peneo_pair_bwd_saved exist for this shape (bf16, D = 384)."""
+    return bool(lib().peneo_pair_save_supported(dtype_code(dtype), int(D), int(num_heads)))
 
 
 def pair_x_fwd(ab_doc: torch.Tensor, i0: int, i1: int, out: torch.Tensor, pre: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -730,6 +746,20 @@ def pair_bwd_fused(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, args: "
         check(lib().peneo_pair_bwd_fused(dtype_code(ab.dtype), ptr(_c(ab)), B, N, D2 // 2, ptr(wp), ptr(b1), C.byref(args),
                                          ptr(_c(dz)), ptr(_c(x)), ptr(_c(d_ab)), ptr(workspace), ptr(partials), stream()),
               "peneo_pair_bwd_fused")
+
+
+def pair_bwd_saved(ab: torch.Tensor, wp: torch.Tensor, args: "hip.PairDzArgs", act: torch.Tensor, dz: torch.Tensor,
+                   d_ab: torch.Tensor, workspace: torch.Tensor) -> None:
+    """pair_bwd_fused for a forward that saved its hidden activations (pair_heads_fwd(save=True)): same outputs except x, which
+    the forward already wrote."""
+    B, N, D2 = ab.shape
+    assert d_ab.dtype == torch.float32 and d_ab.shape == ab.shape and dz.dtype == torch.bfloat16
+    assert dz.shape[0] == B * pair_bwd_rows(N)
+    partials = torch.empty(lib().peneo_pair_bwd_partial_bytes(B, N, D2 // 2) // 4, dtype=torch.float32, device=ab.device)
+    with kernel_timer("pair_bwd_saved"):
+        check(lib().peneo_pair_bwd_saved(dtype_code(ab.dtype), ptr(_c(ab)), B, N, D2 // 2, ptr(wp), C.byref(args), ptr(act),
+                                         ptr(_c(dz)), ptr(_c(d_ab)), ptr(workspace), ptr(partials), stream()),
+              "peneo_pair_bwd_saved")
 
 
 def pair_dz_finish(workspace: torch.Tensor, nh: int, D: int, classes: Sequence[int]):
