@@ -231,6 +231,7 @@ def main():
     elapsed = max_over_ranks(elapsed, dev)
     ph = ops.TIMER.durations_ms("pair_heads_fwd")
     pb = ops.TIMER.durations_ms("pair_bwd_fused")     # fused pair-space backward + its partial-row reduction (one C call)
+    pbs = ops.TIMER.durations_ms("pair_bwd_saved")    # ... the form that reads the pre-activations the forward saved (D = 384)
     eb = ops.TIMER.durations_ms("embed_bwd")          # word / position / box table scatter (fp32 atomics)
     ops.TIMER.reset(False)
     loss_val = float(loss.detach())
@@ -408,13 +409,28 @@ def main():
         pb_achieved = pb_gflop * B / pb_ms if pb_ms > 0 else 0.0
         ks_f = pcfg['backbone_config']['hidden_size'] // 32      # D / 16; bf16 at 24 / 32: the hand-interleaved kernel (unless switched off)
         hand = args.dtype == "bf16" and ks_f in (24, 32) and os.environ.get("PENEO_PAIR_FWD_HAND", "1") != "0"
-        fwd_roof = {"bound": "mfma", "kernel": f"pair_heads_fwd_hand_kernel<{ks_f}>" if hand else f"pair_heads_fwd_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},{ks_f}>",
+        fwd_roof = {"bound": "mfma", "kernel": (f"pair_heads_fwd_hand_kernel<{ks_f}>" + (" (saving form: + 2 B per pair and hidden unit written)" if pbs else "")) if hand else f"pair_heads_fwd_kernel<{'bf16' if args.dtype == 'bf16' else 'f32'},{ks_f}>",
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                    "traffic": pmc_traffic_bytes("pair_heads_fwd_train_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
+                    "traffic": pmc_traffic_bytes(("pair_heads_fwd_save_" if pbs else "pair_heads_fwd_train_") + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
                     "traffic_source": "profiles/pmc_traffic.json (recorded rocprofv3 --pmc passes, not measured by this run)",
                     "avg_launch_ms": round(ph_ms, 4), "launches": len(ph)}
-        if pb_ms > 0:
+        if pbs:
+            # the saved-activation form: the forward left z (f16) per pair and hidden unit, the backward reads it back and writes dz -
+            # one contraction (du = dz W1) is left for the matrix cores, and what bounds the launch is the traffic: per document
+            # P * nh*D * 2 B of z read + as much dz written + the dlogits (SURVEY 8d's per-unit figure for this kernel)
+            pbs_ms = sum(pbs) / len(pbs)
+            Pn = (args.seq_len - 1) * args.seq_len // 2
+            Dd = pcfg["backbone_config"]["hidden_size"] // 2
+            algo_bytes = B * (2 * Pn * 5 * Dd * 2 + Pn * 14 * 4)
+            dom_roof = {"bound": "hbm", "kernel": f"pair_bwd_sv_kernel<{Dd // 16}> (+ pair_bwd_reduce_kernel)",
+                        "achieved": round(algo_bytes / pbs_ms / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(algo_bytes / pbs_ms / 1e6 / 8000.0, 4),
+                        "traffic": pmc_traffic_bytes("pair_bwd_saved_" + args.dtype, B) if args.size == "base" and args.seq_len == 512 else None,
+                        "traffic_source": "profiles/pmc_traffic.json (recorded rocprofv3 --pmc passes, not measured by this run)",
+                        "algorithmic_bytes": algo_bytes, "mfma_tflops": round(l1 * B / pbs_ms, 1),
+                        "avg_launch_ms": round(pbs_ms, 4), "launches": len(pbs)}
+        elif pb_ms > 0:
             ks = pcfg['backbone_config']['hidden_size'] // 32       # D / 16: 24 -> the wave-specialised kernel, 32 -> the one-wave kernel
             dom_roof = {"bound": "mfma", "kernel": f"pair_bwd_{'one' if ks == 32 else 'ws'}_kernel<{ks}> (+ pair_bwd_reduce_kernel)",
                         "achieved": round(pb_achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -730,6 +730,12 @@ __device__ __forceinline__ void pb_mma_acc(const pb_u32x4& a, const pb_u32x4& b,
 // landed"); the consumers have weight pieces (6 per wave and slab), the dz row stores and the flush atomics: loads and writes may
 // retire out of order with each other, so the count that proves "the 6 pieces of slab s-1 are in" is 6.
 // ================================================================================================
+#ifndef PSV_NR
+#define PSV_NR 4        // record ring slots (requests run PSV_NR - 1 slabs ahead)
+#endif
+#ifndef PSV_SPREAD
+#define PSV_SPREAD 0    // 1: a consumer's weight pieces go out one per chunk instead of all behind the first reads
+#endif
 template <int KS, bool DROP>
 __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdParams p) {
   using T = bf16_t;
@@ -744,8 +750,8 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdPa
   const int grp = wave & 3;
   const int D = p.D, N = p.N, nh = p.a.num_heads, ncol = nh * D;
   char* sA = smem;                                                          // [3][HALF_BYTES] weight ring: slab s in slot s % 3
-  char* sR = smem + 3 * HALF_BYTES;                                         // [4][4 groups][PB_REC_BYTES] record ring: slab s in slot s & 3
-  uint2* sW2p = reinterpret_cast<uint2*>(sR + 4 * 4 * PB_REC_BYTES);        // [ncol]: the column's W2 rows as bf16 (w0, w1 | w2, 0)
+  char* sR = smem + 3 * HALF_BYTES;                                         // [PSV_NR][4 groups][PB_REC_BYTES] record ring: slab s in slot s % PSV_NR
+  uint2* sW2p = reinterpret_cast<uint2*>(sR + PSV_NR * 4 * PB_REC_BYTES);   // [ncol]: the column's W2 rows as bf16 (w0, w1 | w2, 0)
   float4* sG = reinterpret_cast<float4*>(sW2p + ncol);                      // [4][32]
   float4* sPart = sG + 4 * 32;                                              // [2][4][32]
   char* sT = reinterpret_cast<char*>(sPart + 2 * 4 * 32);                   // [2][4][32 rows][64 B]
@@ -799,12 +805,13 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // from here on this wave's vm counter only sees its record pieces
     // record of slab s: 2 pieces of 1 KiB into slot s & 3
     const char* rsrc = p.act + ((((int64_t)b * p.ntiles + blockIdx.x) * nslab * 4 + grp) * PB_REC_BYTES) + lane * 16;
-    auto request = [&](int s) {
+    auto request = [&](int s, int slot) {
       const char* src = rsrc + (int64_t)min(s, nslab - 1) * (4 * PB_REC_BYTES);     // (past the end: the last slab again, into a free slot)
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(recs + ((s & 3) * 4 + grp) * PB_REC_BYTES);
-      lds_dma_1k<0>(src, dst); lds_dma_1k<1024>(src, dst);
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(recs + (slot * 4 + grp) * PB_REC_BYTES);
+      if constexpr (!(PB_ABLATE & 16)) { lds_dma_1k<0>(src, dst); lds_dma_1k<1024>(src, dst); }
     };
-    request(0); request(1); request(2);
+#pragma unroll
+    for (int k = 0; k < PSV_NR - 1; ++k) request(k, k);
     // MFMA operands of the current head (see the kernel above): gA = A operand of dy, gT0 / gT1 = A operands of the dW2 sums
     pb_u32x4 gA = pb_u32x4{0u, 0u, 0u, 0u}, gT0 = gA, gT1 = gA;
     auto stage_g = [&](int h) {
@@ -838,12 +845,14 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdPa
     const uint32_t tA0 = tbase + ((((r32 >> 3) ^ half)) << 4), tB0 = tbase + ((((r32 >> 3) ^ half ^ 2)) << 4);
     const float nl2e = -1.4426950408889634f;
     __syncthreads();                                          // sW2p visible (matches the consumers' barrier)
+    int rslot = 0;                                            // s % PSV_NR
     for (int s = 0; s < nslab; ++s) {
-      top(std::integral_constant<int, 4>{});                  // record s has landed (records s + 1, s + 2 may be on their way)
-      request(s + 3);                                         // slot (s + 3) & 3: last read by E(s - 1)
+      top(std::integral_constant<int, 2 * (PSV_NR - 2)>{});   // record s has landed (records s + 1 .. s + PSV_NR - 2 may be on their way)
+      request(s + PSV_NR - 1, rslot == 0 ? PSV_NR - 1 : rslot - 1);   // slot (s - 1) % PSV_NR: last read by E(s - 1)
       if (s % spb == 0) stage_g(s / spb);
       const uint2 cw2 = sW2p[s * 32 + r32];
-      const uint32_t ra = recs + ((s & 3) * 4 + grp) * PB_REC_BYTES + tr_l;
+      const uint32_t ra = recs + (rslot * 4 + grp) * PB_REC_BYTES + tr_l;
+      rslot = rslot == PSV_NR - 1 ? 0 : rslot + 1;
       pb_u32x2 zv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(zv[i]));
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdPa
         // an inline-asm reader gets none and read zeros for rows 0, 1)
         const f16x2_t zh = __builtin_bit_cast(f16x2_t, zw2);
         const float t0 = __builtin_fmaf((float)zh[0], nl2e, 0.f), t1 = __builtin_fmaf((float)zh[1], nl2e, 0.f);
-        const float sg0 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(t0) + 1.f), sg1 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(t1) + 1.f);
+        const float sg0 = (PB_ABLATE & 8) ? t0 : __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(t0) + 1.f), sg1 = (PB_ABLATE & 8) ? t1 : __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(t1) + 1.f);
         const float y0 = __builtin_fmaf((float)zh[0], sg0, 0.f), y1 = __builtin_fmaf((float)zh[1], sg1, 0.f);
         // SiLU'(z) = sg (1 + z (1 - sg)) = (sg + y) - y sg
         const float d0 = dy[r0] * fmaf(-y0, sg0, sg0 + y0), d1 = dy[r0 + 1] * fmaf(-y1, sg1, sg1 + y1);
@@ -906,8 +915,13 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdPa
 #pragma unroll
       for (int k = 0; k < PPC; ++k) {
         const int q = (wave - 4) + k * 4;
-        lds_dma_1k<0>(src + q * 1024, __builtin_amdgcn_readfirstlane(ring + slot * HALF_BYTES + q * 1024));
+        if constexpr (!(PB_ABLATE & 32)) lds_dma_1k<0>(src + q * 1024, __builtin_amdgcn_readfirstlane(ring + slot * HALF_BYTES + q * 1024));
       }
+    };
+    auto wpiece = [&](int slab, int slot, int k) {
+      const int q = (wave - 4) + k * 4;
+      const char* src = wbase + (int64_t)min(slab, nslab - 1) * (3 * HALF_BYTES) + 2 * HALF_BYTES;
+      if constexpr (!(PB_ABLATE & 32)) lds_dma_1k<0>(src + q * 1024, __builtin_amdgcn_readfirstlane(ring + slot * HALF_BYTES + q * 1024));
     };
     wrequest(0, 0);
     wrequest(1, 1);
@@ -958,16 +972,22 @@ __global__ __launch_bounds__(PW_WAVES * 64, 2) void pair_bwd_sv_kernel(PairBwdPa
         auto uchunk = [&](auto jc, pb_u32x2 (&clo)[PB_MAXC], pb_u32x2 (&chi)[PB_MAXC], pb_u32x2 (&nlo)[PB_MAXC], pb_u32x2 (&nhi)[PB_MAXC]) {
           constexpr int J = decltype(jc)::value;
           constexpr int C = pb_chunk_count<KS>(J), F0 = pb_chunk_first<KS>(J);
+          if constexpr (!(PB_ABLATE & 2)) {
           if constexpr (C > 0) pb_mma(((F0 + 0) & 1) ? a1 : a0, pb_u32x4{clo[0].x, clo[0].y, chi[0].x, chi[0].y}, du[(F0 + 0) >> 1]);
           if constexpr (C > 1) pb_mma(((F0 + 1) & 1) ? a1 : a0, pb_u32x4{clo[1].x, clo[1].y, chi[1].x, chi[1].y}, du[(F0 + 1) >> 1]);
           if constexpr (C > 2) pb_mma(((F0 + 2) & 1) ? a1 : a0, pb_u32x4{clo[2].x, clo[2].y, chi[2].x, chi[2].y}, du[(F0 + 2) >> 1]);
-          if constexpr (J + 1 < 8) { uissue(std::integral_constant<int, J + 1>{}, nlo, nhi); ulanded(nlo, nhi); }
+          }
+          if constexpr (J + 1 < 8) uissue(std::integral_constant<int, J + 1>{}, nlo, nhi);
+          if constexpr (PSV_SPREAD && J < PPC) { if (s < nslab) wpiece(s + 1, slot == 2 ? 0 : slot + 1, J); }   // under the latency of the reads just issued
+          if constexpr (J + 1 < 8) ulanded(nlo, nhi);
         };
         uissue(std::integral_constant<int, 0>{}, la, ha);
-        if (s < nslab) wrequest(s + 1, slot == 2 ? 0 : slot + 1);      // (s + 1) % 3: last read by U(s - 2); under the latency of the reads just issued
+        if constexpr (!PSV_SPREAD) { if (s < nslab) wrequest(s + 1, slot == 2 ? 0 : slot + 1); }   // (s + 1) % 3: last read by U(s - 2)
         ulanded(la, ha);
-        *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
-        *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
+        if constexpr (!(PB_ABLATE & 1)) {
+          *reinterpret_cast<pb_u32x4*>(dz_row + u * 32) = a0;
+          *reinterpret_cast<pb_u32x4*>(dz_row + u * 32 + 16) = a1;
+        }
         uchunk(std::integral_constant<int, 0>{}, la, ha, lb, hb);
         uchunk(std::integral_constant<int, 1>{}, lb, hb, la, ha);
         uchunk(std::integral_constant<int, 2>{}, la, ha, lb, hb);
@@ -1535,7 +1555,7 @@ static int launch_pair_bwd_ws(const PairBwdParams& p, hipStream_t st) {
 template <int KS, bool DROP>
 static int launch_pair_bwd_sv(const PairBwdParams& p, hipStream_t st) {
   const int ncol = p.a.num_heads * p.D;
-  const size_t sh = (size_t)3 * KS * 1024 + (size_t)4 * 4 * PB_REC_BYTES + (size_t)ncol * 8 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048;
+  const size_t sh = (size_t)3 * KS * 1024 + (size_t)PSV_NR * 4 * PB_REC_BYTES + (size_t)ncol * 8 + (size_t)4 * 32 * 16 * 3 + (size_t)2 * 4 * 2048;
   if (sh > 160 * 1024) { set_error("peneo_pair_bwd_saved: D=%d with %d heads needs %zu bytes of LDS", p.D, p.a.num_heads, sh); return PENEO_ERR_INVALID; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(pair_bwd_sv_kernel<KS, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
     set_error("peneo_pair_bwd_saved: cannot raise dynamic LDS to %zu bytes", sh);

@@ -1304,6 +1304,60 @@ def test_ohem_ce_matches_reference_cases_and_oracle(ops):
     assert (got[both] - lr.grad[both]).abs().max() <= 2e-5 * lr.grad.abs().max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,drop", [(2, 150, 0.1), (1, 40, 0.0), (3, 97, 0.2), (1, 511, 0.1)])
+def test_pair_saved_activations_path_is_the_recomputing_path(ops, B, N, drop):
+    """peneo_pair_heads_fwd_save + peneo_pair_bwd_saved (the forward leaves the classifiers' pre-activations as f16, the backward reads
+    them) against peneo_pair_heads_fwd + peneo_pair_bwd_fused (the backward rebuilds them): logits, dlogits and the x rows are the same
+    numbers bit for bit (same arithmetic per pair, another walk of the triangle); dz, d_ab and the dW2 / db1 sums differ by the f16
+    rounding of the saved z only.  Reference: model/peneo_decoder.py:231-292 forward and its autograd graph."""
+    D, classes, nh = 384, [2, 3, 3, 3, 3], 5
+    dt, dev = torch.bfloat16, "cuda"
+    assert ops.pair_save_supported(dt, D, nh) and not ops.pair_save_supported(torch.float32, D, nh) and not ops.pair_save_supported(dt, 512, nh)
+    g = torch.Generator().manual_seed(N + int(100 * drop))
+    P = N * (N + 1) // 2
+    ab = torch.randn(B, N, 2 * D, generator=g).to(dev).to(dt)
+    w1 = [(torch.randn(D, D, generator=g) / math.sqrt(D)).to(dev) for _ in classes]
+    w2 = [(torch.randn(c, D, generator=g) / math.sqrt(D)).to(dev) for c in classes]
+    b1, b2 = (0.1 * torch.randn(nh * D, generator=g)).to(dev), (0.1 * torch.randn(14, generator=g)).to(dev)
+    wp = ops.pair_heads_pack(dt, w1, w2)
+    tags = [torch.randint(0, c, (B, P), generator=g).to(dev) for c in classes]
+    cw = [(torch.rand(c, generator=g) + 0.5).to(dev) for c in classes]
+    kw = dict(tags=tags, class_weights=cw, want_dlogits=True, want_logits=True, drop_p=drop, drop_seed=77)
+    lg0, pt0, dl0 = ops.pair_heads_fwd(ab, wp, b1, b2, classes, **kw)
+    lg1, pt1, dl1, (act, xr) = ops.pair_heads_fwd(ab, wp, b1, b2, classes, save=True, **kw)
+    for h in range(nh):
+        assert torch.equal(lg0[h], lg1[h]) and torch.equal(dl0[h], dl1[h])
+    s0, s1 = pt0.sum(0), pt1.sum(0)
+    assert float((s0 - s1).abs().max() / s0.abs().max()) < 1e-5          # the same terms in other partial rows
+    wp2 = ops.pair_bwd_pack(w1)
+    rows = ops.pair_bwd_rows(N)
+    scale = (torch.rand(nh, generator=g) + 0.5).to(dev)
+    outs = []
+    for saved in (False, True):
+        dz = torch.full((B * rows, nh * D), 3.0, device=dev, dtype=dt)
+        d_ab = torch.zeros(B, N, 2 * D, device=dev)
+        ws = ops.pair_dz_workspace(nh, D, dev, slots=256)
+        args = ops.pair_dz_args(D, classes, dl0, w2, scale, drop_p=drop, drop_seed=77)
+        if saved:
+            ops.pair_bwd_saved(ab, wp2, args, act, dz, d_ab, ws)
+            x = xr
+        else:
+            x = torch.empty(B * rows, D, device=dev, dtype=dt)
+            ops.pair_bwd_fused(ab, wp2, b1, args, dz, x, d_ab, ws)
+        torch.cuda.synchronize()
+        outs.append((dz.float(), x, d_ab, ws.sum(0)))
+    assert torch.equal(outs[0][1], outs[1][1])                            # x rows: bit for bit
+    for i, tol in ((0, 2e-3), (2, 1e-3), (3, 1e-3)):                       # dz (bf16 values from an f16-rounded z), d_ab, column sums
+        a, b_ = outs[0][i], outs[1][i]
+        assert torch.isfinite(b_).all()
+        assert float((a - b_).norm() / (a.norm() + 1e-30)) < tol, (i, float((a - b_).norm() / a.norm()))
+    # a dropped unit is dropped in both: the zero pattern of dz is the same
+    if drop > 0:
+        assert torch.equal(outs[0][0] == 0, outs[1][0] == 0)
+
+
+
 @pytest.mark.parametrize("B,N,D,p_drop", [(2, 45, 128, 0.0), (1, 70, 384, 0.0), (3, 23, 32, 0.0), (1, 130, 64, 0.0),
                                           (2, 16, 384, 0.0), (1, 9, 128, 0.0), (2, 45, 128, 0.1), (1, 70, 384, 0.1),
                                           (3, 23, 32, 0.25), (2, 511, 384, 0.0), (2, 511, 384, 0.1),
