@@ -882,11 +882,32 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         for (int e = 0; e < 8; ++e) a[e] = silu_f(a[e] + bb[e]);
         xf[4 * g + i] = pack_frag8<T>(a);
         asm volatile("" : "+v"(xf[4 * g + i].v.x), "+v"(xf[4 * g + i].v.y), "+v"(xf[4 * g + i].v.z), "+v"(xf[4 * g + i].v.w) :: "memory");
-        if constexpr (SAVE) {     // x row of the pair in block order: the B operand of the backward's dW1 = dz^T x
-          if (tile_ok && !(PH_ABLATE & 2))
-            *reinterpret_cast<uint4*>(p.x_save + ((((int64_t)b * p.ntiles + tile) * PB_ROWS + (wave & 3) * 32 + (lane & 31)) * D + 8 * half + 16 * (4 * g + i))) = xf[4 * g + i].v;
-        }
       }
+    }
+  }
+  if constexpr (SAVE) {
+    // x rows of the group's 32 pairs in block order (the B operand of the backward's dW1 = dz^T x).  A lane owns 16 bytes of every
+    // 32-byte piece of its pair's row: stored from the fragments directly, an instruction writes 64 scattered 16-byte pieces (0.11 ms
+    // of the launch and 330 MB of line fills).  Eight fragments at a time go through the wave's corner of the still empty weight ring
+    // (rows of 256 + 16 bytes) and leave as four 256-byte runs per instruction.
+    constexpr int XPITCH = 272;
+    char* const sX = smem + wave * (32 * XPITCH);
+    static_assert(PH_WAVES * 32 * XPITCH <= NSTAGE * SLAB_BYTES, "the x staging area lives in the weight ring");
+    T* const xdst = p.x_save + (((int64_t)b * p.ntiles + tile) * PB_ROWS + (wave & 3) * 32) * D;
+#pragma unroll
+    for (int pass = 0; pass < KS / 8; ++pass) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sX + (lane & 31) * XPITCH + 32 * i + 16 * half) = xf[8 * pass + i].v;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + (lane >> 4), c = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(sX + r * XPITCH + 16 * c);
+        if (tile_ok && !(PH_ABLATE & 2)) *reinterpret_cast<uint4*>(xdst + (int64_t)r * D + 128 * pass + 8 * c) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // from here on the vm counter only sees the DMA pieces (+ the record stores)
