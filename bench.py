@@ -221,10 +221,21 @@ def main():
         dist.barrier()
     ops.TIMER.reset(True)
     torch.cuda.synchronize()
+    dbg_alloc = os.environ.get("PENEO_BENCH_ALLOC_STATS") == "1"       # tools/: device allocations and host time per step inside the timed region
+    if dbg_alloc:
+        ms0 = torch.cuda.memory_stats(dev); host_t = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+        if dbg_alloc:
+            host_t.append(time.perf_counter())
     torch.cuda.synchronize()
+    if dbg_alloc:
+        print("dW1 GEMM ms per launch (side stream: beside the encoder backward):", [round(v, 2) for v in ops.TIMER.durations_ms("dw1_gemm")], file=sys.stderr)
+        ms1 = torch.cuda.memory_stats(dev)
+        print("alloc stats over the timed region:", {k: ms1[k] - ms0[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")},
+              "reserved GB", round(ms1["reserved_bytes.all.current"] / 1e9, 2), "peak allocated GB", round(ms1["allocated_bytes.all.peak"] / 1e9, 2),
+              "host ms per step", [round((b - a) * 1e3, 2) for a, b in zip([t0] + host_t[:-1], host_t)], file=sys.stderr)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0

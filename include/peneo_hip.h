@@ -351,13 +351,12 @@ int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pa
 /* The same launch for a train step whose backward is peneo_pair_bwd_saved (bf16, D = 384: peneo_pair_save_supported).  It walks the
  * pairs in the backward's blocks of 8 rows i x 16 columns j and leaves what the backward would otherwise rebuild:
  *   act    [peneo_pair_save_bytes(B, N, num_heads, D)]: per document, block, 32-unit slab of the num_heads * D hidden units and
- *          group of 32 pairs one 4 KiB record: q = SiLU'(z) m as f16 [32 pairs][32 units], then y = SiLU(z) m as bf16
- *          (z = W1_h x + b1_h, m = the K12 dropout's keep mask; 1 / (1 - p) is applied by the consumer) - what autograd under
- *          autocast saves of model/peneo_decoder.py:253-271 (the classifier's hidden activation), here as the two factors
- *          the backward needs so that it runs no transcendental and no dropout chain;
+ *          group of 32 pairs one 2 KiB record: the classifiers' pre-activations z = W1_h x + b1_h as f16 [32 pairs][32 units], a
+ *          unit the K12 dropout drops stored as -30000 (SiLU and SiLU' of that are 0: the backward needs no mask and runs no dropout
+ *          chain) - what autograd under autocast saves of model/peneo_decoder.py:253-271, 2 bytes per pair and hidden unit;
  *   x_rows [B * peneo_pair_bwd_rows(N), D] bf16: x = SiLU(a_i + b_j) in block order (the B operand of dW1 = dz^T x).
- * Logits, loss partial rows and dlogits are those of peneo_pair_heads_fwd (same arithmetic per pair, indexed by the packed
- * pair index); `loss->partials` has peneo_pair_loss_partials_save(B, N) rows here.  16-byte aligned buffers. */
+ * Logits, loss partial rows and dlogits are those of peneo_pair_heads_fwd bit for bit (same arithmetic per pair, indexed by the
+ * packed pair index); `loss->partials` has peneo_pair_loss_partials_save(B, N) rows here.  16-byte aligned buffers. */
 int peneo_pair_save_supported(int dtype, int D, int num_heads);
 size_t peneo_pair_save_bytes(int B, int N, int num_heads, int D);
 int64_t peneo_pair_loss_partials_save(int B, int N);
@@ -434,11 +433,11 @@ int peneo_pair_bwd_fused(int dtype, const void* ab, int B, int N, int D, const v
                          const peneo_pair_dz_args* args, void* dz, void* x, float* d_ab, float* workspace,
                          float* partials, peneo_stream_t stream);
 
-/* peneo_pair_bwd_fused for a forward that ran as peneo_pair_heads_fwd_save (bf16, D = 384): `act` holds q = SiLU'(z) m and
- * y = SiLU(z) m of every pair and hidden unit, so this launch computes dz = (g W2 / (1 - p)) * q with one multiply per element, runs
- * no first-layer product, no transcendental and no dropout chain, and leaves the same dz [B * rows, nh*D], d_ab and workspace sums
- * (x_rows was written by the forward).  `w_packed`: peneo_pair_bwd_pack.  Results differ from peneo_pair_bwd_fused by the f16 /
- * bf16 rounding of the saved factors (what autograd under autocast would have saved). */
+/* peneo_pair_bwd_fused for a forward that ran as peneo_pair_heads_fwd_save (bf16, D = 384): `act` holds the pre-activation z of
+ * every pair and hidden unit (dropout applied), so this launch computes y = SiLU(z) and dz = (g W2 / (1 - p)) SiLU'(z) from it, runs
+ * neither the first-layer product (24 of the 51 MFMAs per 32 pairs x 32 units) nor a dropout chain, and leaves the same dz
+ * [B * rows, nh*D], d_ab and workspace sums (x_rows was written by the forward).  `w_packed`: peneo_pair_bwd_pack.  Results differ
+ * from peneo_pair_bwd_fused by the f16 rounding of the saved z (what autograd under autocast would have saved; 5e-4 relative on dz). */
 int peneo_pair_bwd_saved(int dtype, const void* ab, int B, int N, int D, const void* w_packed,
                          const peneo_pair_dz_args* args, const void* act, void* dz, float* d_ab, float* workspace,
                          float* partials, peneo_stream_t stream);

@@ -336,10 +336,12 @@ class _DecoderStage(torch.autograd.Function):
                     split = None if not can_hold else \
                         dec.dw1_side_split or max(1, dec.dw1_side_wgs // (-(-nh * D // 128) * -(-D // 128)),
                                                   -(-B * rows // dec.dw1_side_rows))
-                    ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat, split_k=split)
+                    with ops.kernel_timer("dw1_gemm"):
+                        ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat, split_k=split)
                 ctx.side_work = (side, (dzbuf, xbuf1, dW1cat, ab), can_hold)
             else:
-                ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
+                with ops.kernel_timer("dw1_gemm"):
+                    ops.gemm(dzbuf, xbuf1, a_kmajor=False, b_kmajor=False, out=dW1cat)
             chunks = []
         else:
             chunks = _row_chunks(N, dec.bwd_chunk_pairs)
