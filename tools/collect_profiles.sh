@@ -10,6 +10,9 @@ python tools/timeline.py $T +4 --gaps > $OUT/step_timeline.txt 2>&1
 python tools/prof_summary_csv.py $T 40 > $OUT/steps5_summary.txt 2>&1
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/steps5_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/prof
+PENEO_PAIR_SAVE=0 python bench.py --no-cpu-baseline --no-ragged > $OUT/default_line_recompute.json 2> /dev/null    # round 5: the backward rebuilding z (the round-4 data flow)
+(echo "-- pair_heads_fwd_hand_kernel<24, true, true> (saving form)"; WHICH=fwd bash tools/pmc_traffic.sh pair_heads_fwd_hand tools/run_pair_saved_once.py; echo "-- pair_bwd_sv_kernel<24, true>"; bash tools/pmc_traffic.sh pair_bwd_sv_kernel tools/run_pair_saved_once.py; python tools/run_pair_saved_once.py) > $OUT/pmc_pair_saved.txt 2>&1
+TIME=1 python tools/check_pair_saved.py > $OUT/pair_saved_check.txt 2>&1
 bash tools/pmc_traffic.sh pair_bwd_ws_kernel tools/run_pair_bwd_once.py > $OUT/pmc_pair_bwd.txt 2>&1
 bash tools/pmc_traffic.sh pair_heads_fwd tools/run_pair.py > $OUT/pmc_pair_fwd.txt 2>&1
 python tools/run_pair_bwd.py > $OUT/pair_bwd_kernel.txt 2>&1
