@@ -189,7 +189,8 @@ def main():
     # The job runs on a HIGH-priority stream (the training loop's choice, like any stream): the step's side streams (weight
     # gradients, dW1, table reductions) stay at normal priority, so the dispatcher hands CU slots to the main chain first and the
     # side work fills what is left instead of sharing round-robin: 17.57 against 17.72 ms per step (tools/run_prio.py).
-    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
+    if os.environ.get("PENEO_BENCH_PRIORITY", "1") != "0":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 
     torch.manual_seed(1234)
     model, pcfg = build_model(args.size, dtype, args.backbone, args.vocab)

@@ -185,6 +185,39 @@ def side_stream(device, role: str) -> "torch.cuda.Stream":
 
 
 
+# ---- step-sized buffers --------------------------------------------------------------------------------------------
+# The decoder's three multi-gigabyte buffers of a train step (saved pre-activations, x rows, dz: 4.2 + 0.8 + 4.2 GB at 8 x 511
+# tokens) are kept between steps instead of going back to torch's allocator.  With per-step allocation the allocator reaches its
+# steady state only in the third or fourth step (the previous step's graph is still alive while the next one allocates), and on
+# some boxes the driver needs 30 - 100 ms of host time for one such hipMalloc (memory handed out cleared): a training loop pays that
+# once, a 10-step measurement after two warm-up steps saw it as 18 - 24 ms per step instead of 16 (profiles/r05_pair_saved.txt).
+# acquire() hands out a free buffer of at least the size asked for (a view of a flat byte buffer) or allocates one; release()
+# returns it once every launch that touches it has been issued or ordered behind the main stream (stream order does the rest).
+# A buffer that is never released (a forward without its backward) is simply dropped with its graph.
+_BIG_FREE: dict = {}
+
+
+def big_acquire(tag: str, shape, dtype, device):
+    """-> (tensor of `shape` / `dtype`, handle for big_release)."""
+    import math
+    nbytes = int(math.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    free = _BIG_FREE.setdefault((tag, str(device)), [])
+    best = None
+    for i, b in enumerate(free):
+        if b.numel() >= nbytes and (best is None or b.numel() < free[best].numel()):
+            best = i
+    base = free.pop(best) if best is not None else torch.empty(-(-nbytes // (2 << 20)) * (2 << 20), dtype=torch.uint8, device=device)
+    if best is None:
+        free.clear()                                  # (a larger request: the smaller buffers of this tag will not be used again)
+    return base[:nbytes].view(dtype).view(shape), base
+
+
+def big_release(tag: str, base) -> None:
+    free = _BIG_FREE.setdefault((tag, str(base.device)), [])
+    if len(free) < 2 and all(b is not base for b in free):
+        free.append(base)
+
+
 # ---- deferred joins of side-stream work ------------------------------------------------------------------------------
 # A backward stage that put its weight-gradient kernels on a side stream used to end with main.wait_stream(side): the main
 # stream (= the activation-gradient critical path) then idles until the last weight gradient of the layer is done (~50 us

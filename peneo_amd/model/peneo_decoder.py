@@ -21,7 +21,7 @@ from transformers.modeling_outputs import ModelOutput
 
 from .. import ops
 from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
-from .engine import DropoutSeeds, WeightCache, can_defer, defer_join, mark_late
+from .engine import DropoutSeeds, WeightCache, big_acquire, big_release, can_defer, defer_join, join_pending, mark_late
 
 HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
@@ -218,12 +218,17 @@ class _DecoderStage(torch.autograd.Function):
         # hidden unit (4.2 GB at 8 x 511 tokens) - the backward then neither repeats the first-layer product nor the dropout chain
         save = (need_grad and tags is not None and dec.fused_bwd and dec.save_pair_act and ops.pair_bwd_supported(dt, D, len(HEAD_NAMES))
                 and ops.pair_save_supported(dt, D, len(HEAD_NAMES)))
+        bufs = None
+        if save:
+            # (step-sized buffers are kept between steps: engine.big_acquire)
+            act, act_h = big_acquire("pair_act", (ops.pair_save_bytes(B, N, len(HEAD_NAMES), D),), torch.uint8, dev)
+            xr, xr_h = big_acquire("pair_x", (B * ops.pair_bwd_rows(N), D), dt, dev)
+            bufs = (act, xr)
+            saved["pair_act"], saved["pair_x"] = (act, act_h), (xr, xr_h)
         res = ops.pair_heads_fwd(ab, wp, b1cat, b2cat, HEAD_CLASSES, want_logits=want_logits,
                                  tags=tags, class_weights=cws, want_dlogits=need_grad and tags is not None,
-                                 drop_p=seeds.p_hidden, drop_seed=seeds.seed(903), save=save)
+                                 drop_p=seeds.p_hidden, drop_seed=seeds.seed(903), save=save, save_buffers=bufs)
         logits, partials, dlog = res[:3]
-        if save:
-            saved["pair_act"], saved["pair_x"] = res[3]
         outs = []
         if tags is not None and dec.le_loss.ohem:
             # OHEM: the kept pairs of each head are chosen from its finished logit map; the un-normalised dlogits of the
@@ -306,14 +311,23 @@ class _DecoderStage(torch.autograd.Function):
             # dz and x themselves (block order), which the one remaining GEMM dW1 = dz^T x reads back once
             wp2 = wc.get(("dec.pack2", dt), w1s, lambda: ops.pair_bwd_pack([w.detach() for w in w1s]))
             rows = ops.pair_bwd_rows(N)
-            dzbuf = torch.empty((B * rows, nh * D), dtype=dt, device=dev)
+            # (a kept buffer may still be read by an earlier decoder backward of THIS autograd run - two forwards summed into one loss -
+            # whose side-stream join is deferred to the end of the backward: join first; nothing is pending in the usual step)
+            join_pending()
+            dzbuf, dz_h = big_acquire("pair_dz", (B * rows, nh * D), dt, dev)
             dza = ops.pair_dz_args(D, HEAD_CLASSES, sv["dlog"], w2d, scale, drop_p=drop_p, drop_seed=drop_seed)
             if "pair_act" in sv:
-                xbuf1 = sv.pop("pair_x")
-                ops.pair_bwd_saved(ab, wp2, dza, sv.pop("pair_act"), dzbuf, d_ab, dz_ws)
+                xbuf1, x_h = sv.pop("pair_x")
+                act, act_h = sv.pop("pair_act")
+                ops.pair_bwd_saved(ab, wp2, dza, act, dzbuf, d_ab, dz_ws)
+                big_release("pair_act", act_h)           # (read by that launch only: the next forward's stores are ordered behind it)
             else:
-                xbuf1 = torch.empty((B * rows, D), dtype=dt, device=dev)
+                xbuf1, x_h = big_acquire("pair_x", (B * rows, D), dt, dev)
                 ops.pair_bwd_fused(ab, wp2, b1cat, dza, dzbuf, xbuf1, d_ab, dz_ws)
+            # dz and x are read by the dW1 GEMM below, on the side stream or here: whoever takes them next (the next step's forward /
+            # backward, on the main stream) is issued after this backward has ended, i.e. behind the join of that side stream
+            big_release("pair_dz", dz_h)
+            big_release("pair_x", x_h)
             # dW1 = dz^T x (2 ms of pure MFMA work, needed by nobody until the optimizer) runs on the side stream beside the
             # shrink-MLP backward and the first encoder layers, whose short kernels leave CUs idle; joined one stage later
             if dec.dw1_on_side:

@@ -606,11 +606,11 @@ def pair_heads_pack(dtype: torch.dtype, w1: Sequence[torch.Tensor], w2: Sequence
 def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor,
                    classes: Sequence[int], *, want_logits: bool = True, tags: Optional[Sequence[torch.Tensor]] = None,
                    class_weights: Optional[Sequence[Optional[torch.Tensor]]] = None, want_dlogits: bool = False,
-                   drop_p: float = 0.0, drop_seed: int = 0, save: bool = False):
+                   drop_p: float = 0.0, drop_seed: int = 0, save: bool = False, save_buffers=None):
     """ab: [B, N, 2D].  Returns (logits list | None, loss partials [n, 32] | None, dlogits list | None).
     drop_p / drop_seed: the Dropout between the two classifier layers (train mode, model/peneo_decoder.py:261).
     save (pair_save_supported): the launch also leaves the hidden activations the backward needs; returns a fourth value
-    (act [bytes] uint8, x_rows [B * pair_bwd_rows(N), D]) for pair_bwd_saved."""
+    (act [bytes] uint8, x_rows [B * pair_bwd_rows(N), D]) for pair_bwd_saved; save_buffers = (act, x_rows) supplies them."""
     _c(ab)
     B, N, D2 = ab.shape
     D = D2 // 2
@@ -641,8 +641,13 @@ def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: tor
                 loss.dlogits[h] = ptr(dlog[h])
         loss.partials = ptr(partials)
     if save:
-        act = torch.empty(lib().peneo_pair_save_bytes(B, N, nh, D), dtype=torch.uint8, device=ab.device)
-        x_rows = torch.empty((B * pair_bwd_rows(N), D), dtype=ab.dtype, device=ab.device)
+        if save_buffers is not None:
+            act, x_rows = save_buffers
+            assert act.dtype == torch.uint8 and act.numel() >= lib().peneo_pair_save_bytes(B, N, nh, D) and act.is_contiguous()
+            assert x_rows.shape == (B * pair_bwd_rows(N), D) and x_rows.dtype == ab.dtype and x_rows.is_contiguous()
+        else:
+            act = torch.empty(lib().peneo_pair_save_bytes(B, N, nh, D), dtype=torch.uint8, device=ab.device)
+            x_rows = torch.empty((B * pair_bwd_rows(N), D), dtype=ab.dtype, device=ab.device)
         with kernel_timer("pair_heads_fwd"):
             check(lib().peneo_pair_heads_fwd_save(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
                                                   C.byref(loss) if loss is not None else None, ptr(act), ptr(x_rows), stream()),
@@ -652,6 +657,10 @@ def pair_heads_fwd(ab: torch.Tensor, wp: torch.Tensor, b1: torch.Tensor, b2: tor
         check(lib().peneo_pair_heads_fwd(dtype_code(ab.dtype), ptr(ab), B, N, C.byref(desc), lp,
                                          C.byref(loss) if loss is not None else None, stream()), "peneo_pair_heads_fwd")
     return logits, partials, dlog
+
+
+def pair_save_bytes(B: int, N: int, num_heads: int, D: int) -> int:
+    return int(lib().peneo_pair_save_bytes(int(B), int(N), int(num_heads), int(D)))
 
 
 def pair_save_supported(dtype, D: int, num_heads: int) -> bool:
