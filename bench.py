@@ -213,7 +213,7 @@ def main():
             p.grad = None
         out = net(**batches[i % len(batches)])
         out["loss"].backward()
-        return out["loss"]
+        return out["loss"].detach()       # (what a training loop logs; holding the loss itself would keep the step's graph alive through the next step)
 
     for i in range(args.warmup):
         step(i)
