@@ -775,7 +775,7 @@ __global__ __launch_bounds__(1024) void spots_compact_kernel(const float* logits
 __device__ unsigned long long* g_ph_prof;
 #endif
 #ifndef PH_ABLATE
-#define PH_ABLATE 0   // timing experiments (tools/ab_pair_fwd_save.sh): 1 the saving form without its record stores, 2 without its x stores, 4 record stores non-temporal
+#define PH_ABLATE 0   // timing experiments (tools/ab_pair_fwd_save.sh): 1 the saving form without its record stores, 2 without its x stores, 4 record stores non-temporal, 8 no exp / rcp in the epilogue (timing only)
 #endif
 #ifndef PH_HAND_LA
 #define PH_HAND_LA 3
@@ -1002,13 +1002,13 @@ __global__ __launch_bounds__(PH_WAVES * 64, 2) void pair_heads_fwd_hand_kernel(P
         if constexpr (SAVE) { zp[2 * G] = pack_f16x2(t[0], t[1]); zp[2 * G + 1] = pack_f16x2(t[2], t[3]); }
       } else if constexpr (S == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = __builtin_amdgcn_exp2f(u[e]);
+        for (int e = 0; e < 4; ++e) u[e] = (PH_ABLATE & 8) ? u[e] : __builtin_amdgcn_exp2f(u[e]);
       } else if constexpr (S == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = u[e] + 1.f;
-        u[0] = __builtin_amdgcn_rcpf(u[0]); u[1] = __builtin_amdgcn_rcpf(u[1]);
+        if constexpr (!(PH_ABLATE & 8)) { u[0] = __builtin_amdgcn_rcpf(u[0]); u[1] = __builtin_amdgcn_rcpf(u[1]); }
       } else if constexpr (S == 3) {
-        u[2] = __builtin_amdgcn_rcpf(u[2]); u[3] = __builtin_amdgcn_rcpf(u[3]);
+        if constexpr (!(PH_ABLATE & 8)) { u[2] = __builtin_amdgcn_rcpf(u[2]); u[3] = __builtin_amdgcn_rcpf(u[3]); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = t[e] * u[e];          // y = z sigmoid(z)   (-0 where the unit is dropped)
       } else if constexpr (S == 4) {

@@ -349,6 +349,43 @@ def test_bf16_path_matches_fp32_path_at_the_benchmark_size_with_dropout_on():
     _assert_agreement(l32, l16, stats, 0.99, 0.03, loss_tol=3e-2)
 
 
+def test_saved_pair_activations_keep_the_gradients():
+    """Round 5: in a bf16 train step at D = 384 the decoder forward saves the classifiers' pre-activations (f16, dropout applied) for
+    its backward (peneo_pair_heads_fwd_save / peneo_pair_bwd_saved) in buffers the decoder keeps between steps.  Every parameter
+    gradient of a train-mode step agrees with the step whose backward rebuilds them (PENEO_PAIR_SAVE=0's data flow; same masks: the
+    dropout is a function of (seed, element)), and a second step reuses the kept buffers with the same result.
+    (reference: model/peneo_decoder.py:231-292 and its autograd graph)"""
+    from seeded import layoutlmv3_config, peneo_config, seeded_fill_
+    from peneo_amd.data import synthetic_rfund_batch
+    from peneo_amd.model import engine
+    torch.manual_seed(20251003)
+    pcfg = peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
+    m = build_model(pcfg)
+    seeded_fill_(m.state_dict(), 11)
+    batch = to_cuda(synthetic_rfund_batch(2, 512, 128, pcfg["backbone_config"]["vocab_size"], seed=1008))
+    m = m.train()
+    dec = m.peneo_decoder
+    assert dec.save_pair_act
+    l_on, g_on = _fwd_bwd(m, batch, torch.bfloat16, seed_step=4000)
+    kept = {k: [b.data_ptr() for b in v] for k, v in engine._BIG_FREE.items() if k[0].startswith("pair_")}
+    assert sorted(k[0] for k in kept) == ["pair_act", "pair_dz", "pair_x"] and all(len(v) == 1 for v in kept.values()), kept
+    l_again, g_again = _fwd_bwd(m, batch, torch.bfloat16, seed_step=4000)
+    assert {k: [b.data_ptr() for b in v] for k, v in engine._BIG_FREE.items() if k[0].startswith("pair_")} == kept      # the same three buffers
+    dec.save_pair_act = False
+    try:
+        l_off, g_off = _fwd_bwd(m, batch, torch.bfloat16, seed_step=4000)
+    finally:
+        dec.save_pair_act = True
+    assert abs(l_on - l_off) <= 1e-6 * abs(l_off) and l_again == l_on, (l_on, l_again, l_off)      # the forward is the same arithmetic per pair
+
+    def close(stats, cos_min, tol):      # (gradients that are zero in exact arithmetic - the key biases - are rounding noise: skipped by norm)
+        gmax = max(v[2] for v in stats.values())
+        bad = {n: v for n, v in stats.items() if v[2] > 1e-4 * gmax and (v[0] < cos_min or abs(v[1] - 1) > tol)}
+        assert not bad, sorted(bad.items(), key=lambda kv: kv[1][0])[:8]
+    close(_grad_stats(g_on, g_off), 0.999, 1e-2)
+    close(_grad_stats(g_again, g_on), 0.9999, 2e-3)       # (the same step again: equal up to the order of the fp32 atomics)
+
+
 def test_lilt_base_bf16_path_matches_fp32_path():
     """BASELINE config 5 at full size: LiLT-base (12 layers, text H = 768 + layout H = 192, head dim 64 + 16 = 80 in ONE attention
     call, modeling_lilt.py:269-429), B = 8, S = 512, ragged masks: every parameter gradient of the bf16 path (head-dim-80

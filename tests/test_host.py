@@ -272,3 +272,25 @@ def test_bench_launch_plan_never_relabels_a_smaller_job():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(os.environ, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr, (r.returncode, r.stderr[-400:])
+
+
+def test_step_sized_buffers_are_kept_and_handed_out_once():
+    """engine.big_acquire / big_release (the decoder's multi-gigabyte buffers of a train step): a released buffer comes back for the
+    same or a smaller request, never to two holders at once, and a larger request drops the smaller kept ones."""
+    import torch
+    from peneo_amd.model import engine
+    engine._BIG_FREE.clear()
+    a, ha = engine.big_acquire("t", (4, 8), torch.float32, "cpu")
+    b, hb = engine.big_acquire("t", (4, 8), torch.float32, "cpu")
+    assert a.shape == (4, 8) and a.dtype == torch.float32 and ha is not hb and a.data_ptr() != b.data_ptr()
+    engine.big_release("t", ha)
+    engine.big_release("t", ha)                       # (released twice: kept once)
+    c, hc = engine.big_acquire("t", (2, 8), torch.bfloat16, "cpu")
+    assert hc is ha and c.shape == (2, 8) and c.dtype == torch.bfloat16 and c.data_ptr() == a.data_ptr()
+    d, hd = engine.big_acquire("t", (4, 8), torch.float32, "cpu")
+    assert hd is not ha and hd is not hb              # nothing free: a new one
+    engine.big_release("t", hb); engine.big_release("t", hc); engine.big_release("t", hd)
+    assert len(engine._BIG_FREE[("t", "cpu")]) == 2   # at most two kept per tag
+    e, he = engine.big_acquire("t", (1 << 22,), torch.uint8, "cpu")       # larger than anything kept: the kept ones go
+    assert he.numel() >= 1 << 22 and engine._BIG_FREE[("t", "cpu")] == []
+    engine._BIG_FREE.clear()
