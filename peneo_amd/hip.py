@@ -224,7 +224,15 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+# the current stream's raw handle: torch.cuda.current_stream().cuda_stream builds a Python Stream object per call (~9 us; a LiLT
+# train step asks ~300 times), the C accessor behind it answers in ~0.3 us
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> int:
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
