@@ -200,7 +200,7 @@ _BIG_FREE: dict = {}
 def big_acquire(tag: str, shape, dtype, device):
     """-> (tensor of `shape` / `dtype`, handle for big_release)."""
     import math
-    nbytes = int(math.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    nbytes = int(math.prod(shape)) * dtype.itemsize
     free = _BIG_FREE.setdefault((tag, str(device)), [])
     best = None
     for i, b in enumerate(free):
