@@ -294,3 +294,18 @@ def test_step_sized_buffers_are_kept_and_handed_out_once():
     e, he = engine.big_acquire("t", (1 << 22,), torch.uint8, "cpu")       # larger than anything kept: the kept ones go
     assert he.numel() >= 1 << 22 and engine._BIG_FREE[("t", "cpu")] == []
     engine._BIG_FREE.clear()
+
+
+def test_saved_activation_sizes_follow_the_block_walk():
+    """Host-side size queries of the saving forward (no GPU): one 2 KiB record per document, block of 8 x 16 pairs, 32-unit slab and
+    group of 32 pairs; one loss-partial row per workgroup of two blocks; bf16 at D = 384 only (include/peneo_hip.h)."""
+    from peneo_amd import hip
+    lib = hip.lib()
+    rows = lib.peneo_pair_bwd_rows(511)
+    assert rows % 128 == 0 and rows >= 511 * 512 // 2
+    assert lib.peneo_pair_save_bytes(8, 511, 5, 384) == 8 * (rows // 128) * (5 * 384 // 32) * 4 * 2048 == 4152360960
+    assert lib.peneo_pair_loss_partials_save(8, 511) == 8 * ((rows // 128 + 1) // 2)
+    assert lib.peneo_pair_save_bytes(0, 511, 5, 384) == 0
+    assert lib.peneo_pair_save_supported(hip.BF16, 384, 5) == 1
+    assert lib.peneo_pair_save_supported(hip.F32, 384, 5) == 0 and lib.peneo_pair_save_supported(hip.BF16, 512, 5) == 0
+    assert lib.peneo_pair_save_supported(hip.BF16, 384, 0) == 0
