@@ -566,6 +566,12 @@ int peneo_spots_compact(const float* logits, int64_t P, int C, int N, int32_t* s
  * choice (default; also set by PENEO_GEMM_BIG), 256 / 384 / 128 = force one big-tile shape where its constraints hold.  A plain
  * global: set it while no peneo_gemm call is in flight on any thread.  Used by the kernel tests and tools/ only. */
 void peneo_gemm_set_big_mode(int mode);
+/* The same for the persistent stream-k launch (gemm_sk.hip; first choice of peneo_gemm for large bf16 problems with a k-major A):
+ * 0 = off (the tiled kernels above), 1 = where the problem is large enough (default; also set by PENEO_GEMM_SK), 128 / 256 = force
+ * the 256 x 128 / 256 x 256 tile wherever the kernel's constraints hold.  The launch keeps one fp32 slab per workgroup and a flag
+ * word per workgroup in a buffer the library allocates per (device, stream) at the first call -- not during a stream capture: run
+ * the captured sequence once eagerly first (a capture that meets a missing buffer falls back to the tiled kernels). */
+void peneo_gemm_set_sk_mode(int mode);
 
 #ifdef __cplusplus
 }

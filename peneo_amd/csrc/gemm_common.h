@@ -74,6 +74,102 @@ __device__ __forceinline__ void store8_any(void* p, int dtype, int64_t idx, cons
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p) + idx) = pack16<bf16_t>(f);
   }
 }
+// The epilogue of 8 consecutive columns in two halves, so that a kernel can issue the loads of a BATCH of granules before the
+// arithmetic and stores of any of them (every wait for a load issued behind a store is a full memory round trip on the one vm
+// counter: gemm_sk.hip measured 0.56 us per granule with load and store alternating).  The "primary" matrix-shaped input of
+// the granule -- the gradient source if there is one, else the residual, else the old fp32 C of an accumulating call -- travels as
+// raw 16-byte words; any further matrix input (combinations the model does not use) is loaded in place by the arithmetic half.
+enum { EP_PRIM_NONE = 0, EP_PRIM_GRAD = 1, EP_PRIM_RES = 2, EP_PRIM_ACC = 3 };
+struct EpIn8 { uint4 x0, x1; };
+__device__ __forceinline__ int ep_primary(const GemmParams& p) {
+  return p.ep.grad_src ? EP_PRIM_GRAD : (p.ep.residual ? EP_PRIM_RES : (p.ep.accumulate ? EP_PRIM_ACC : EP_PRIM_NONE));
+}
+__device__ __forceinline__ void ep_load_primary(const GemmParams& p, int prim, int m, int n, EpIn8& in) {
+  if (prim == EP_PRIM_NONE) return;
+  const peneo_gemm_epilogue& e = p.ep;
+  const void* base = prim == EP_PRIM_GRAD ? e.grad_src : (prim == EP_PRIM_RES ? e.residual : p.C);
+  const int64_t ld = prim == EP_PRIM_GRAD ? e.ld_grad : (prim == EP_PRIM_RES ? e.ld_res : p.ldc);
+  const int64_t idx = (int64_t)m * ld + n;
+  if (prim == EP_PRIM_ACC || p.c_dtype == PENEO_F32) {
+    const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(base) + idx);
+    in.x0 = q[0]; in.x1 = q[1];
+  } else {
+    in.x0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(base) + idx);
+  }
+}
+__device__ __forceinline__ void ep_unpack_primary(const GemmParams& p, int prim, const EpIn8& in, float* f) {
+  if (prim == EP_PRIM_ACC || p.c_dtype == PENEO_F32) { unpack16<float>(in.x0, f); unpack16<float>(in.x1, f + 4); }
+  else unpack16<bf16_t>(in.x0, f);
+}
+// bias8: the 8 bias values of these columns (already loaded), or null when the call has no bias
+__device__ __forceinline__ void epilogue_apply8(const GemmParams& p, int m, int n, float* v, const float* bias8, int prim, const EpIn8& in) {
+  const peneo_gemm_epilogue& e = p.ep;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+  if (bias8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += bias8[i];
+  }
+  if (e.preact) store8_any(e.preact, p.c_dtype, (int64_t)m * e.ld_preact + n, v);
+  const bool fast = p.c_dtype == PENEO_BF16;   // bf16 tiles: polynomial erf (2e-5) instead of the library erff
+  // one uniform branch per activation kind AROUND the element loop: with the kind tested per element the compiler turned the
+  // nested conditional into selects and evaluated GELU and SiLU for every element (FFN1 forward: +15 us for either)
+  if (e.act == PENEO_ACT_GELU) {
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = gelu_fast_f(v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+    }
+  } else if (e.act == PENEO_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+  }
+  if (e.grad_src) {
+    float g[8];
+    if (prim == EP_PRIM_GRAD) ep_unpack_primary(p, prim, in, g);
+    else load8_any(e.grad_src, p.c_dtype, (int64_t)m * e.ld_grad + n, g);
+    if (e.grad_act == PENEO_ACT_GELU) {
+      if (fast) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_fast_f(g[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(g[i]);
+      }
+    } else if (e.grad_act == PENEO_ACT_SILU) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= silu_grad_f(g[i]);
+    }
+  }
+  if (e.drop_p > 0.f) {
+    const uint32_t thresh = (uint32_t)fminf(e.drop_p * 4294967296.0f, 4294967040.0f);
+    const float ks = 1.0f / (1.0f - e.drop_p);
+    const uint32_t keep = dropout_keep8(e.drop_seed, (uint64_t)m * (uint64_t)p.N + n, thresh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * ks : 0.f;
+  }
+  if (e.residual) {
+    float r[8];
+    if (prim == EP_PRIM_RES) ep_unpack_primary(p, prim, in, r);
+    else load8_any(e.residual, p.c_dtype, (int64_t)m * e.ld_res + n, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += r[i];
+  }
+  const int64_t ci = (int64_t)m * p.ldc + n;
+  if (e.accumulate) {
+    float c[8];
+    if (prim == EP_PRIM_ACC) ep_unpack_primary(p, prim, in, c);
+    else load8_any(p.C, PENEO_F32, ci, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += c[i];
+  }
+  store8_any(p.C, p.c_dtype, ci, v);
+}
+// (The tiled kernels of gemm.hip / gemm_big.hip keep this single-granule form -- the same arithmetic in the same order as
+//  epilogue_apply8 above; written out rather than composed from the two halves because their register allocation sits at the
+//  edge where one more live scalar sends an LDS-DMA base pointer to a VGPR.)
 __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int n, float* v) {
   const peneo_gemm_epilogue& e = p.ep;
 #pragma unroll
@@ -142,5 +238,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
 
 // gemm_big.hip: 0 = the shape / options are not covered (the caller runs the 128 x 128 kernel), 1 = launched
 int launch_gemm_big(const GemmParams& p, bool b_kmajor, hipStream_t st);
+// gemm_sk.hip (persistent stream-k launch): same return convention
+int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st);
 
 }  // namespace peneo

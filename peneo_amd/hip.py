@@ -168,6 +168,7 @@ SIGNATURES = {
     "peneo_spots_to_tags": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "peneo_gemm_set_big_mode": (None, [_i]),    # diagnostics block of the header: process-wide, not thread-safe
+    "peneo_gemm_set_sk_mode": (None, [_i]),
 }
 
 _lib: Optional[C.CDLL] = None

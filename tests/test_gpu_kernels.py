@@ -793,6 +793,55 @@ def test_gemm_big_tiles_match_fp32_matmul(ops, mode, bk):
         lib.peneo_gemm_set_big_mode(1)
 
 
+@pytest.mark.parametrize("mode", [128, 256])
+@pytest.mark.parametrize("bk", [True, False])
+def test_gemm_stream_k_matches_fp32_matmul(ops, mode, bk):
+    """gemm_sk.hip (one persistent launch, every workgroup a contiguous range of (tile, k-tile) units) forced for ragged problems:
+    tiles cut once, twice and three times by range boundaries (few tiles x many k-tiles), ranges of one unit, M / N that are no
+    multiple of the tile, both B layouts, every fused epilogue option -- against an fp32 matmul of the same bf16 operands and
+    against the 128 x 128 kernel (same dropout mask function, same epilogue arithmetic: only the summation order differs).
+    Every problem is launched three times with fresh operands: the slab flags are reset by their consumers, so a stale flag or a
+    stale slab from the launch before shows as a wrong tile."""
+    import ctypes
+    from peneo_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    g = torch.Generator().manual_seed(mode + bk)
+    dt = torch.bfloat16
+    try:
+        for (M, N, K) in [(2101, 1032, 320), (2800, 776, 832), (300, 136, 128), (1500, 768, 3072), (5672, 768, 768), (777, 264, 1920)]:
+            for rep in range(3):
+                a = torch.randn(M, K, generator=g).to(DEV).to(dt)
+                b = (torch.randn(N, K, generator=g) if bk else torch.randn(K, N, generator=g)).to(DEV).to(dt)
+                bias = torch.randn(N, generator=g).to(DEV)
+                res = torch.randn(M, N, generator=g).to(DEV).to(dt)
+                src = torch.randn(M, N, generator=g).to(DEV).to(dt)
+                z = a.float() @ (b.float().t() if bk else b.float())
+                outs = {}
+                for m_ in (mode, 0):
+                    lib.peneo_gemm_set_sk_mode(m_)
+                    lib.peneo_gemm_set_big_mode(1 if m_ else 0)
+                    pre = torch.empty(M, N, device=DEV, dtype=dt)
+                    o1 = ops.gemm(a, b, b_kmajor=bk, bias=bias, act=1, preact=pre, split_k=1)                       # bias + GELU + pre-activation
+                    o2 = ops.gemm(a, b, b_kmajor=bk, bias=bias, residual=res, drop_p=0.1, drop_seed=77, split_k=1)   # bias + dropout + residual
+                    o3 = ops.gemm(a, b, b_kmajor=bk, grad_src=src, grad_act=2, split_k=1)                            # x SiLU'(src)
+                    o4 = ops.gemm(a, b, b_kmajor=bk, out_dtype=torch.float32, split_k=1)
+                    outs[m_] = (pre, o1, o2, o3, o4)
+                pre, o1, o2, o3, o4 = outs[mode]
+                assert rel_err(pre, z + bias) < 2e-2 and rel_err(o1, F.gelu(z + bias)) < 2e-2, (M, N, K, rep)
+                sg = torch.sigmoid(src.float())
+                assert rel_err(o3, z * (sg * (1 + src.float() * (1 - sg)))) < 2e-2, (M, N, K, rep)
+                assert rel_err(o4, z) < 2e-3, (M, N, K, rep, rel_err(o4, z))
+                kept = (o2.float() - res.float()).abs() > 0
+                assert 0.85 < float(kept.float().mean()) < 0.95
+                for x, y in zip(outs[mode], outs[0]):
+                    assert rel_err(x, y) < 1e-2, (M, N, K, rep)
+                # (a kept value that rounds into its residual reads as dropped: a handful of elements differ with the summation order)
+                assert float((((outs[0][2].float() - res.float()) != 0) != kept).float().mean()) < 1e-4
+    finally:
+        lib.peneo_gemm_set_sk_mode(1)
+        lib.peneo_gemm_set_big_mode(1)
+
+
 def test_cast_multi_equals_single_casts(ops):
     """peneo_cast_multi (all weight copies of a step in one launch) == peneo_cast tensor by tensor, ragged sizes included."""
     g = torch.Generator().manual_seed(5)
