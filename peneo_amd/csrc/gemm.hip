@@ -1004,9 +1004,13 @@ extern "C" int peneo_gemm(int dtype, int a_kmajor, int b_kmajor, int M, int N, i
   bool launched = false;
   if (dtype == PENEO_BF16 && a_kmajor && dma_ok(A, lda, true, M, K) && dma_ok(B, ldb, b_kmajor != 0, N, K)) {
     // large forward problems: one 8-wave workgroup per CU on 256 x 256 / 384 x 192 / 256 x 128 tiles (gemm_big.hip, split_k == 1)
-    // first choice: the persistent stream-k launch (gemm_sk.hip); then the tiled 8-wave kernels
-    int big = launch_gemm_sk(p, b_kmajor != 0, st);
+    // first choice: the persistent launch (gemm_sk.hip) where its rules pick the problem -- it balances a deep reduction itself
+    // (stream-k ranges), so a split the caller asked for is dropped with it; then the tiled 8-wave kernels
+    GemmParams q = p;
+    q.split_k = 1;
+    int big = launch_gemm_sk(q, b_kmajor != 0, st);
     if (big < 0) return big;
+    if (big == 1) split_k = 1;
     if (big == 0) big = launch_gemm_big(p, b_kmajor != 0, st);
     if (big < 0) return big;
     launched = big == 1;

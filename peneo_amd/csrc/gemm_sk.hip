@@ -1,31 +1,35 @@
 // bf16 GEMM as ONE persistent launch: at most one 8-wave workgroup per CU, each walking a contiguous range of
-// (tile, k-tile) units -- "stream-k" (gfx950).
+// (tile, k-stage) units -- whole tiles ("data-parallel") or ranges that cut tiles ("stream-k") (gfx950).
 //
-// Why (profiles/r03_gemm_fixed_cost_and_host_time.txt, r05_vendor_gemm_configs.txt): the tiled kernels of gemm.hip / gemm_big.hip
-// multiply at ~920 TFLOP/s per ADDED k-tile, but a QKV-shaped launch costs 17 us before its first and after its last k-tile
-// (cold instruction fetch, first-touch load latency, epilogue with nothing to overlap, 1.6 rounds of tiles on the CUs), and the
-// M = 5672 problems quantise badly on any tile grid (270 / 414 / 552 / 810 tiles on 256 CUs).  Here
-//   * the launch has G <= #CUs workgroups; workgroup v owns units [v U / G, (v + 1) U / G) of the U = tiles x k-tiles units, in
-//     tile-major order: every CU does the same number of k-tiles (+- 1) whatever the tile count;
-//   * the LDS ring is ONE stream over the units: the LDS-DMA of the next tile's first k-tiles is in flight while the last k-tiles
-//     of this tile are multiplied and while its epilogue runs (the epilogue never touches LDS, below), so a tile boundary costs
-//     no prologue;
-//   * a tile cut by a range boundary is finished by the workgroup that holds its k = 0 piece: every other piece is the FIRST
-//     thing its workgroup computes, leaves as an fp32 slab in accumulator-register order (16-byte write-through stores, 1 KiB
-//     per wave instruction; every wave drains its vm counter, barrier, one lane stores the flag) and is added by the finisher --
-//     at the END of its own range -- behind one relaxed poll + one agent-scope acquire (cdna guide, Guideline 16 recipe R1).  Flags are reset by
-//     their single consumer, so a captured launch replays.  Pieces of one tile sit on consecutive v = the same XCD (v is
-//     XCD-major), except at the seven XCD seams.
-//   * progress: a finisher waits only for workgroups v + 1 .. v + 3, which publish before anything else; workgroups of an XCD
-//     are dispatched in id order, so whatever subset is resident, its lowest members can finish (the vendor library's stream-k
-//     kernels rely on the same).
-// Operands / LDS images / ring are gemm_big.hip's (A k-major [M][K]; B k-major [N][K] or mn-major [K][N]; rows of 128 B with
-// the 16-byte slot swizzled on the DMA source address; one s_barrier per k-tile; LDS-DMA NSTAGE - 1 units ahead, issued from
-// inline asm in four groups between the MFMA steps).
-// Epilogue: the MFMA runs with the operands SWAPPED (D = B_tile x A_tile^T), so a lane holds one output ROW (m = lane & 31) and
-// 4 consecutive columns per register group; one v_permlane32_swap per register pair makes that 8 consecutive columns = the
-// 16-byte granule of gemm_common.h's fused epilogue, straight from the accumulators: no LDS patch, nothing to fence against
-// the ring.  The loads of the epilogue's inputs are issued in batches ahead of its stores (gemm_common.h: epilogue_apply8).
+// What bounds a GEMM on this chip (profiles/r06_gemm_fill_model.txt): a CU turns global -> LDS requests into LDS lines at ~22
+// B/clk whatever the kernel (ours, the vendor library's, the guide's template), so a launch costs (bytes staged through LDS) /
+// (22 B/clk x CUs) when everything else hides under that stream, and the tiled kernels of gemm.hip / gemm_big.hip are far from
+// it on the model's M = 5672 problems: 17 us of a QKV-shaped launch sit before the first and after the last k-tile, the tile
+// counts (270 / 414 / 552 / 810 on 256 CUs) quantise badly, and a two-stage ring lets the request queue run dry in every k-tile.
+// Here
+//   * the tile is chosen per problem from a FAMILY -- M extent 32 F (F = 4..8: 128 .. 256 rows), N extent 128 or 256 -- so that the
+//     tiles fill one or two rounds of the CUs (QKV: 224 x 256 -> 234 tiles; FFN1: 160 x 256 -> 432; out-proj: 160 x 128 -> 216),
+//     which the 16 x 16 x 32 MFMA allows: 2 x 4 waves, wave tile 16 F x (N extent / 4);
+//   * the ring holds 3 .. 6 stages of 64 k (every LDS-DMA instruction fetches 8 whole 128-byte lines: the fill rate is a REQUEST
+//     rate -- the same kernel staging 16 rows x 64 bytes per instruction fills at 14.6 instead of 22 B/clk), NSTAGE - 1 stages always
+//     in flight: the request queue never drains inside a tile, nor between tiles -- the ring is ONE stream over the workgroup's
+//     units, the next tile's first stages land while this tile's last stages are multiplied and while its epilogue runs;
+//   * the epilogue never touches LDS (so nothing fences it against the ring): the MFMA runs with the operands SWAPPED
+//     (D = B_tile x A_tile^T), a lane holds one output row and 4 consecutive columns per accumulator; the B rows are dealt to the
+//     MFMA in an order that puts columns c .. c + 3 and c + 4 .. c + 7 on lanes 32 apart, so one v_permlane32_swap per register
+//     pair makes 8 consecutive columns = the 16-byte granule of gemm_common.h's fused epilogue (four lanes = 64 contiguous
+//     bytes of a row); the epilogue's loads are issued in batches ahead of its stores (epilogue_apply8);
+//   * stream-k, where no tile fits (few tiles x deep K): workgroup v owns units [v U / G, (v + 1) U / G).  A tile cut by a range
+//     boundary is finished by the workgroup that holds its k = 0 piece; every other piece is the FIRST thing its workgroup
+//     computes, leaves as an fp32 slab in accumulator order (16-byte write-through stores; every wave drains its vm counter,
+//     barrier, one lane stores the flag) and is added by the finisher at the END of its range behind one relaxed poll + one
+//     agent-scope acquire (cdna guide, Guideline 16 recipe R1).  Flags are reset by their single consumer (a captured launch
+//     replays).  v is XCD-major, so the pieces of a tile sit on one XCD except at the seven seams.  Progress: a finisher waits
+//     only for workgroups v + 1 .. v + 3, which publish before anything else, and an XCD dispatches its workgroups in id order.
+// Layouts: A k-major [M][K]; B k-major [N][K] (forward, x W^T); K % 64 == 0, N % 8 == 0, 16-byte aligned rows.
+// LDS image of a stage (gemm_big.hip's): rows of 128 B (64 k), A rows then B rows, pieces of 8 rows = one LDS-DMA instruction;
+// the 16-byte slot s of row r sits at s ^ ((r >> 1) & 7) (applied to the DMA source address, the destination is lane-linear):
+// every 16-lane group of a ds_read_b128 fragment read (16 rows x 32 k: lane = row + 16 x slot) covers all 16 bank slots.
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -35,60 +39,60 @@
 
 namespace peneo {
 
-typedef short sk_s16x4 __attribute__((ext_vector_type(4)));
-
 struct SkPlan {
   int tiles_n, tiles, ktiles, G;
+  int cut;              // 1 = ranges of units (stream-k), 0 = ranges of whole tiles
   float* ws;            // [G] slabs of BM x BN floats (a workgroup's first piece when it is not the tile's k = 0 piece)
   uint32_t* flags;      // [G] 0 = empty, 1 = slab published; reset by the finisher
   uint64_t* prof;       // tools only (peneo_gemm_sk_set_prof): [G][16] s_memrealtime stamps of one lane, or null
 };
 #define SK_STAMP(k) do { if (pl.prof && tid == 0) pl.prof[v * 16 + (k)] = wall_clock64(); } while (0)
 
-template <bool BK_, int WGM_, int WGN_, int FM_, int FN_, int NSTAGE_>
+template <int F_, int BN_, int NSTAGE_>
 struct SkCfg {
-  static constexpr bool BK = BK_;
-  static constexpr int WGM = WGM_, WGN = WGN_, FM = FM_, FN = FN_, NSTAGE = NSTAGE_;
-  static constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
-  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static constexpr int APW = BM / 64, BPW = BN / 64, PPW = APW + BPW;   // 1 KiB pieces per wave and k-tile
+  static constexpr int F = F_, BN = BN_, NSTAGE = NSTAGE_;
+  static constexpr int NB = BN / 64;                   // 16-column fragments of a wave
+  static constexpr int BM = 32 * F;
+  static constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8, PIECES = A_PIECES + B_PIECES;   // 8 rows x 128 B each
+  static constexpr int PPW = (PIECES + 7) / 8;         // LDS-DMA instructions per wave and stage (odd F: the last four waves have one fewer)
+  static constexpr int STAGE = PIECES * 1024;
   static constexpr int LDS_BYTES = NSTAGE * STAGE;
   static constexpr int SLAB_FLOATS = BM * BN;
-  static_assert(WGM * WGN == 8, "eight waves");
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "pieces of 8 rows are dealt to 8 waves");
+  static_assert(NB == 2 || NB == 4, "column fragments pair up in the epilogue");
+  static_assert(NSTAGE >= 2, "ring");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
+
+typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
 
 template <typename C>
 __global__ __launch_bounds__(512) void gemm_sk_kernel(GemmParams p, SkPlan pl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int FM = C::FM, FN = C::FN, NSTAGE = C::NSTAGE;
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  constexpr int F = C::F, NB = C::NB, NSTAGE = C::NSTAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WGN, wn = wave % C::WGN;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r16 = lane & 15, c4 = lane >> 4;
 
-  // ---- this workgroup's range of units.  v is XCD-major: workgroup ids go round-robin to the 8 XCDs, so the 32 workgroups of an
+  // ---- this workgroup's range of units.  v is XCD-major: workgroup ids go round-robin to the 8 XCDs, so the workgroups of an
   //      XCD hold consecutive ranges (neighbouring tiles share their A panel in that XCD's L2; a cut tile's pieces meet there) ----
   const int G = pl.G, lin = blockIdx.x;
   const int q8 = G >> 3, r8 = G & 7, xcd = lin & 7, slot = lin >> 3;
   const int v = xcd * q8 + min(xcd, r8) + slot;
-  const int64_t U = (int64_t)pl.tiles * pl.ktiles;
   const int ktiles = pl.ktiles;
-  const int64_t u_begin = v * U / G, u_end = (v + 1) * U / G;
+  const int64_t U = (int64_t)pl.tiles * ktiles;
+  const int64_t u_begin = pl.cut ? v * U / G : ((int64_t)v * pl.tiles / G) * ktiles;
+  const int64_t u_end = pl.cut ? (v + 1) * U / G : ((int64_t)(v + 1) * pl.tiles / G) * ktiles;
   const int n_units = (int)(u_end - u_begin);
   if (n_units <= 0) return;
   SK_STAMP(0);
   const int tile_begin = (int)(u_begin / ktiles), kt_begin = (int)(u_begin % ktiles);
 
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-
-  // ---- LDS-DMA side: runs NSTAGE - 1 units ahead of the multiply.  Per tile: per-lane 32-bit byte offsets of this wave's pieces
-  //      inside the tile (piece g = wave + 8 u) + one uniform 64-bit base per operand that walks k with scalar adds ----
-  uint32_t offA[C::APW], offB[C::BPW];
+  // ---- LDS-DMA side: runs NSTAGE - 1 units ahead of the multiply.  Piece g = wave + 8 u of the stage (A pieces, then B pieces):
+  //      per-lane 32-bit byte offset inside the tile + one uniform 64-bit base per operand that walks k with scalar adds ----
+  uint32_t off[C::PPW];
   const char* bA = nullptr;
   const char* bB = nullptr;
-  const int64_t stepB = C::BK ? 128 : (int64_t)64 * p.ldb * 2;
   auto uniform_ptr = [](const void* q) -> const char* {
     const uint64_t w = reinterpret_cast<uint64_t>(q);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)w), hi = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
@@ -97,232 +101,167 @@ __global__ __launch_bounds__(512) void gemm_sk_kernel(GemmParams p, SkPlan pl) {
   auto dma_set_tile = [&](int tile, int kt) {
     const int m0 = (tile / pl.tiles_n) * C::BM, n0 = (tile % pl.tiles_n) * C::BN;
 #pragma unroll
-    for (int u = 0; u < C::APW; ++u) {
-      const int row = (wave + 8 * u) * 8 + (lane >> 3);
-      const int sg = (lane & 7) ^ ((row >> 1) & 7);
-      offA[u] = (uint32_t)(((int64_t)(min(m0 + row, p.M - 1) - m0) * p.lda + sg * 8) * 2);
-    }
-#pragma unroll
-    for (int u = 0; u < C::BPW; ++u) {
-      const int g = wave + 8 * u;
-      if constexpr (C::BK) {
-        const int row = g * 8 + (lane >> 3);
-        const int sg = (lane & 7) ^ ((row >> 1) & 7);
-        offB[u] = (uint32_t)(((int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldb + sg * 8) * 2);
+    for (int u = 0; u < C::PPW; ++u) {
+      const int g = min(wave + 8 * u, C::PIECES - 1);
+      if (g < C::A_PIECES) {
+        const int row = g * 8 + (lane >> 3), sg = (lane & 7) ^ ((row >> 1) & 7);
+        off[u] = (uint32_t)(((int64_t)(min(m0 + row, p.M - 1) - m0) * p.lda + sg * 8) * 2);
       } else {
-        constexpr int NQ = C::BN / 64;
-        const int kb = g / NQ, nq = g % NQ, kr = lane >> 3;
-        const int cg = (lane & 7) ^ (((kr >> 1) & 1) << 2);
-        offB[u] = (uint32_t)(((int64_t)(kb * 8 + kr) * p.ldb + (min(n0 + nq * 64 + cg * 8, p.N - 8) - n0)) * 2);
+        const int row = (g - C::A_PIECES) * 8 + (lane >> 3), sg = (lane & 7) ^ ((row >> 1) & 7);
+        off[u] = (uint32_t)(((int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldb + sg * 8) * 2);
       }
     }
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
     bA = uniform_ptr(reinterpret_cast<const char*>(A + (int64_t)m0 * p.lda) + (int64_t)kt * 128);
-    bB = uniform_ptr(reinterpret_cast<const char*>(C::BK ? B + (int64_t)n0 * p.ldb : B + n0) + kt * stepB);
+    bB = uniform_ptr(reinterpret_cast<const char*>(B + (int64_t)n0 * p.ldb) + (int64_t)kt * 128);
   };
   int d_tile = tile_begin, d_kt = kt_begin;      // the next unit to issue
   dma_set_tile(d_tile, d_kt);
   const uint32_t lds0 = lds_addr(smem);
-  uint32_t dbase = 0;
-  // The pieces of a k-tile are issued in four groups, one between the MFMA clusters of each k-step (gemm_big.hip: a wave that
-  // issues all of its pieces back to back stalls on the memory pipeline)
-  auto issue_group = [&](auto gc) {
-    constexpr int GI = decltype(gc)::value;
+  const bool full = wave + 8 * (C::PPW - 1) < C::PIECES;      // this wave has a piece in the last round (selects its wait count)
+  auto issue = [&](int stage) {
+    const uint32_t dbase = __builtin_amdgcn_readfirstlane(lds0 + stage * C::STAGE + wave * 1024);
 #pragma unroll
     for (int u = 0; u < C::PPW; ++u) {
-      if (u * 4 / C::PPW != GI) continue;
-      if (u < C::APW) lds_dma_1k_s<0>(offA[u], bA, dbase + u * 8192);
-      else lds_dma_1k_s<0>(offB[u - C::APW], bB, dbase + C::A_BYTES + (u - C::APW) * 8192);
+      if (u == C::PPW - 1 && !full) continue;
+      lds_dma_1k_s<0>(off[u], (wave + 8 * u < C::A_PIECES) ? bA : bB, dbase + u * 8192);
     }
-    if constexpr (GI == 3) {      // the unit is complete: the bases move on, into the next tile when this one is through
-      if (++d_kt == ktiles) {
-        d_kt = 0;
-        // (the tile after the last one of the problem is never issued: its units are beyond u_end; the offsets computed for it
-        //  here are clamped addresses of the last rows and are not used)
-        if (++d_tile < pl.tiles) dma_set_tile(d_tile, 0);
-      } else {
-        bA += 128; bB += stepB;
-      }
+    // the unit is complete: the bases move on, into the next tile when this one is through (the tile after the last one of the
+    // problem is never issued: its units are beyond u_end)
+    if (++d_kt == ktiles) {
+      d_kt = 0;
+      if (++d_tile < pl.tiles) dma_set_tile(d_tile, 0);
+    } else {
+      bA += 128; bB += 128;
     }
-  };
-  auto issue = [&](int stage) {
-    dbase = __builtin_amdgcn_readfirstlane(lds0 + stage * C::STAGE + wave * 1024);
-    issue_group(std::integral_constant<int, 0>{}); issue_group(std::integral_constant<int, 1>{});
-    issue_group(std::integral_constant<int, 2>{}); issue_group(std::integral_constant<int, 3>{});
   };
 
-  // ---- fragment offsets inside a stage ----
-  int aoff[4], boff[C::BK ? 4 : FN];
+  // ---- fragment offsets inside a stage.  A fragment i: rows wm 16 F + 16 i + r16.  B fragment j: rows wn BN / 4 + 16 j + pi(r16),
+  //      pi = swap bits 2 and 3: the MFMA's result rows 4 g .. 4 g + 3 of lane group g = lane >> 4 are then columns 0-3, 8-11, 4-7,
+  //      12-15 for g = 0 .. 3 -- lanes 32 apart hold the two halves of 8 consecutive columns ----
+  const int pr = (r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1);
+  int aoff[2], boff[2];                // k-half 0 / 1 of the stage (the 16-byte slot of row r sits at slot ^ ((r >> 1) & 7))
   {
-    const int row = wm * FM * 32 + (lane & 31), swz = (row >> 1) & 7;
+    const int ra = wm * 16 * F + r16, rb = wn * (C::BN / 4) + pr;      // (fragment i / j: + 16 rows = + 2048 bytes, same swizzle)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) aoff[ks] = row * 128 + (((2 * ks + half) ^ swz) << 4);
-  }
-  if constexpr (C::BK) {
-    const int row = wn * FN * 32 + (lane & 31), swz = (row >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) boff[ks] = C::A_BYTES + row * 128 + (((2 * ks + half) ^ swz) << 4);
-  } else {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = wn * FN * 32 + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-      boff[j] = C::A_BYTES + (half * (C::BN / 64) + (n >> 6)) * 1024 + ((lane & 15) >> 2) * 128 +
-                (((n & 63) * 2) ^ (((lane >> 3) & 1) << 6));
+    for (int kh = 0; kh < 2; ++kh) {
+      aoff[kh] = ra * 128 + (((4 * kh + c4) ^ ((ra >> 1) & 7)) << 4);
+      boff[kh] = C::A_PIECES * 1024 + rb * 128 + (((4 * kh + c4) ^ ((rb >> 1) & 7)) << 4);
     }
   }
 
-  f32x16_t acc[FM][FN];
+  sk_f32x4 acc[F][NB];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < F; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < NB; ++j) acc[i][j] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
   };
   zero_acc();
 
-  auto load_a = [&](const char* st, int ks, uint4 (&fa)[FM]) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const uint4*>(st + aoff[ks] + i * 4096);
-  };
-  auto load_b = [&](const char* st, int ks, uint4 (&fb)[FN]) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      if constexpr (C::BK) {
-        fb[j] = *reinterpret_cast<const uint4*>(st + boff[ks] + j * 4096);
-      } else {
-        typedef __attribute__((address_space(3))) sk_s16x4* lds_s4p;
-        const char* q = st + boff[j] + ks * (2 * (C::BN / 64) * 1024);
-        const sk_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q));
-        const sk_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(q + 512));
-        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        fb[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-      }
-    }
-  };
-  // operands swapped: the 32 x 32 result is [n (registers, 4 consecutive per group)][m (lane & 31)]
-  auto mma = [&](const uint4 (&fa)[FM], const uint4 (&fb)[FN]) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[j]), __builtin_bit_cast(bf16x8_t, fa[i]),
-                                                            acc[i][j], 0, 0, 0);
-  };
-
   // ---- the end of a piece ----
-  float* const my_slab = pl.ws + (int64_t)v * C::SLAB_FLOATS;
   // write-through (sc1) 16-byte stores: the slab is in memory when the vm counter says so, no release fence (a buffer_wbl2
   // here writes back everything the XCD's L2 holds dirty -- the other workgroups' slabs and C tiles: measured 25 us per launch)
-  auto slab_store = [&]() {            // accumulator-register order: [(i, j, q)][thread] float4
-    const char* base = uniform_ptr(my_slab);
+  auto slab_store = [&]() {            // accumulator order: [(i, j)][thread] float4
+    const char* base = uniform_ptr(pl.ws + (int64_t)v * C::SLAB_FLOATS);
     const uint32_t voff = tid * 16;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < F; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4_t x = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(voff), "v"(x), "s"(base) : "memory");
-          base += 8192;
-        }
+      for (int j = 0; j < NB; ++j) {
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(voff), "v"(acc[i][j]), "s"(base) : "memory");
+        base += 8192;
+      }
   };
   auto slab_add = [&](int w) {
     const float4* src = reinterpret_cast<const float4*>(pl.ws + (int64_t)w * C::SLAB_FLOATS) + tid;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < F; ++i) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 x = src[((i * FN + j) * 4 + q) * 512];
-          acc[i][j][4 * q] += x.x; acc[i][j][4 * q + 1] += x.y; acc[i][j][4 * q + 2] += x.z; acc[i][j][4 * q + 3] += x.w;
-          // (every wait for a batch of loads is a memory round trip: as many in flight as the registers hold)
-          if constexpr (FM * FN > 4) { if (q == 3 && (j & 1)) __builtin_amdgcn_sched_barrier(0); }
-        }
+      for (int j = 0; j < NB; ++j) {
+        const float4 x = src[(i * NB + j) * 512];
+        acc[i][j][0] += x.x; acc[i][j][1] += x.y; acc[i][j][2] += x.z; acc[i][j][3] += x.w;
+      }
+      // (every wait for a batch of loads is a memory round trip: as many in flight as the registers hold)
+      if constexpr (F * NB > 16) { if (i & 1) __builtin_amdgcn_sched_barrier(0); }
+    }
   };
-  // Batched epilogue: the bias of the tile's (j, pp) column granules once, then per 32-row block i the primary matrix input of
-  // all its granules (block i + 1's before block i's stores), then arithmetic + stores.
+  // Batched epilogue: the bias of the tile's column granules once, then per pair of 16-row blocks the primary matrix input of all
+  // their granules, then arithmetic + stores.
   auto epilogue = [&](int tile) {
     const int m0 = (tile / pl.tiles_n) * C::BM, n0 = (tile % pl.tiles_n) * C::BN;
     const int prim = ep_primary(p);
-    const int nbase = n0 + wn * FN * 32 + 8 * half;
-    float bias[FN][2][8];
+    const int nbase = n0 + wn * (C::BN / 4) + 16 * (c4 >> 1) + 8 * (c4 & 1);     // + 32 jj
+    const int mbase = m0 + wm * (16 * F) + r16;                                   // + 16 i
+    float bias[NB / 2][8];
     if (p.ep.bias) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-          const int n = nbase + j * 32 + 16 * pp;
-          load8_any(p.ep.bias, PENEO_F32, min(n, p.N - 8), bias[j][pp]);
-        }
+      for (int jj = 0; jj < NB / 2; ++jj) load8_any(p.ep.bias, PENEO_F32, min(nbase + 32 * jj, p.N - 8), bias[jj]);
     }
-    EpIn8 in[2][FN][2];
-    auto load_block = [&](auto ic) {
+    auto load_block = [&](auto ic, EpIn8 (&in)[NB / 2]) {
       constexpr int i = decltype(ic)::value;
-      const int m = m0 + (wm * FM + i) * 32 + (lane & 31);
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-          const int n = nbase + j * 32 + 16 * pp;
-          if (m < p.M && n + 8 <= p.N) ep_load_primary(p, prim, m, n, in[i & 1][j][pp]);
-        }
+      for (int jj = 0; jj < NB / 2; ++jj) {
+        const int m = mbase + 16 * i, n = nbase + 32 * jj;
+        if (m < p.M && n + 8 <= p.N) ep_load_primary(p, prim, m, n, in[jj]);
+      }
     };
-    auto store_block = [&](auto ic) {
+    auto store_block = [&](auto ic, const EpIn8 (&in)[NB / 2]) {
       constexpr int i = decltype(ic)::value;
-      const int m = m0 + (wm * FM + i) * 32 + (lane & 31);
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+      for (int jj = 0; jj < NB / 2; ++jj) {
+        float val[8];
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-          float val[8];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * pp + t]), __float_as_uint(acc[i][j][8 * pp + 4 + t]),
-                                                             false, false);
-            val[t] = __uint_as_float(sw[0]); val[4 + t] = __uint_as_float(sw[1]);
-          }
-          const int n = nbase + j * 32 + 16 * pp;
-          if (m < p.M && n + 8 <= p.N) epilogue_apply8(p, m, n, val, p.ep.bias ? bias[j][pp] : nullptr, prim, in[i & 1][j][pp]);
+        for (int t = 0; t < 4; ++t) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][2 * jj][t]), __float_as_uint(acc[i][2 * jj + 1][t]), false, false);
+          val[t] = __uint_as_float(sw[0]); val[4 + t] = __uint_as_float(sw[1]);
         }
+        const int m = mbase + 16 * i, n = nbase + 32 * jj;
+        if (m < p.M && n + 8 <= p.N) epilogue_apply8(p, m, n, val, p.ep.bias ? bias[jj] : nullptr, prim, in[jj]);
+      }
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    load_block(I0{});
-    if constexpr (FM > 1) load_block(I1{});
-    store_block(I0{});
-    if constexpr (FM > 2) { __builtin_amdgcn_sched_barrier(0); load_block(I2{}); }
-    if constexpr (FM > 1) store_block(I1{});
-    if constexpr (FM > 3) { __builtin_amdgcn_sched_barrier(0); load_block(I3{}); }
-    if constexpr (FM > 2) store_block(I2{});
-    if constexpr (FM > 3) store_block(I3{});
-    static_assert(FM <= 4, "row blocks");
+    auto batch = [&](auto i0c) {          // two 16-row blocks per batch
+      constexpr int i0 = decltype(i0c)::value;
+      EpIn8 in0[NB / 2], in1[NB / 2];
+      load_block(std::integral_constant<int, i0>{}, in0);
+      if constexpr (i0 + 1 < F) load_block(std::integral_constant<int, i0 + 1>{}, in1);
+      store_block(std::integral_constant<int, i0>{}, in0);
+      if constexpr (i0 + 1 < F) store_block(std::integral_constant<int, i0 + 1>{}, in1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    batch(std::integral_constant<int, 0>{});
+    if constexpr (F > 2) batch(std::integral_constant<int, 2>{});
+    if constexpr (F > 4) batch(std::integral_constant<int, 4>{});
+    if constexpr (F > 6) batch(std::integral_constant<int, 6>{});
+    static_assert(F <= 8, "row blocks");
   };
 
   // ---- prologue of the stream: units 0 .. NSTAGE - 2 ----
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < n_units) issue(s);
-
   SK_STAMP(1);
+
   int tile = tile_begin, kt = kt_begin;
-  int kt_first = kt_begin;             // first k-tile of the piece being accumulated
+  int kt_first = kt_begin;             // first k-stage of the piece being accumulated
   // Waiting.  A counted s_waitcnt vmcnt(N) says "at most N vector-memory operations of this wave are outstanding"; LDS-DMA loads
   // complete in order among themselves, so N = the pieces of the younger units is a correct wait for unit t whatever stores are
   // mixed in (they only make it wait longer).  At the end of a piece every wave first EMPTIES its counter (the NSTAGE - 1 units
   // in flight have landed: `landed` tops need no wait, and the compiler's own counts for the epilogue's loads are exact), then
-  // issues its epilogue / slab traffic; the slab flag is published at the first top that waits again, behind a full drain.
+  // issues its epilogue / slab traffic; the slab flag is published at the first top that drains again.
   int landed = 0;
   bool publish = false;
+  int st_cur = 0, st_fill = NSTAGE - 1;             // stage of unit t / stage refilled while unit t is multiplied
   for (int t = 0; t < n_units; ++t) {
     bool drained = false;
     if (landed > 0) {
       --landed;
     } else {
       // this wave's pieces of unit t have landed (younger units may still be in flight) ...
-      if (!publish && NSTAGE > 2 && t + NSTAGE - 2 < n_units) wait_vm<(NSTAGE - 2) * C::PPW>(); else { wait_vm<0>(); drained = true; }
+      if (!publish && NSTAGE > 2 && t + NSTAGE - 2 < n_units) {
+        if (full) wait_vm<(NSTAGE - 2) * C::PPW>(); else wait_vm<(NSTAGE - 2) * (C::PPW - 1)>();
+      } else { wait_vm<0>(); drained = true; }
     }
     // ... and everybody's: the barrier also says that every wave is done reading unit t - 1, whose stage is refilled now
     __builtin_amdgcn_s_barrier();
@@ -334,34 +273,46 @@ __global__ __launch_bounds__(512) void gemm_sk_kernel(GemmParams p, SkPlan pl) {
       SK_STAMP(4);
     }
     if (t == 0) SK_STAMP(2);
-    const bool more = t + NSTAGE - 1 < n_units;
-    dbase = __builtin_amdgcn_readfirstlane(lds0 + ((t + NSTAGE - 1) % NSTAGE) * C::STAGE + wave * 1024);
-    const char* st = smem + (t % NSTAGE) * C::STAGE;
-    uint4 fa0[FM], fb0[FN], fa1[FM], fb1[FN];
-    load_a(st, 0, fa0); load_b(st, 0, fb0);
-    if (more) issue_group(std::integral_constant<int, 0>{});
-    load_a(st, 1, fa1); load_b(st, 1, fb1);
+    const char* st = smem + st_cur * C::STAGE;
+    uint4 fb0[NB], fa0[F], fb1[NB], fa1[F];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) fb0[j] = *reinterpret_cast<const uint4*>(st + boff[0] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < F; ++i) fa0[i] = *reinterpret_cast<const uint4*>(st + aoff[0] + i * 2048);
     __builtin_amdgcn_sched_barrier(0);
-    mma(fa0, fb0);
+    if (t + NSTAGE - 1 < n_units) issue(st_fill);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) issue_group(std::integral_constant<int, 1>{});
-    load_a(st, 2, fa0); load_b(st, 2, fb0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) fb1[j] = *reinterpret_cast<const uint4*>(st + boff[1] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < F; ++i) fa1[i] = *reinterpret_cast<const uint4*>(st + aoff[1] + i * 2048);
     __builtin_amdgcn_sched_barrier(0);
-    mma(fa1, fb1);
+    // operands swapped: the 16 x 16 result is [column (registers, 4 consecutive)][row (lane & 15)]
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb0[j]), __builtin_bit_cast(bf16x8_t, fa0[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb1[j]), __builtin_bit_cast(bf16x8_t, fa1[i]), acc[i][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) issue_group(std::integral_constant<int, 2>{});
-    load_a(st, 3, fa1); load_b(st, 3, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) issue_group(std::integral_constant<int, 3>{});
-    mma(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
+    st_cur = st_cur + 1 == NSTAGE ? 0 : st_cur + 1;
+    st_fill = st_fill + 1 == NSTAGE ? 0 : st_fill + 1;
 
     const bool tile_done = kt + 1 == ktiles;
     if (tile_done || t + 1 == n_units) {
       wait_vm<0>();
       landed = min(NSTAGE - 1, n_units - 1 - t);
+      if (publish) {
+        // (a second piece end before any top drained: the flag must be out before this workgroup waits for anybody)
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) __hip_atomic_store(pl.flags + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish = false;
+        SK_STAMP(4);
+      }
       if (kt_first != 0) {
         // not the k = 0 piece (only ever the first piece of a range): leave it for the finisher
         SK_STAMP(3);
@@ -422,7 +373,7 @@ static int sk_cu_count(int dev) {
   return g_sk_cus[dev];
 }
 
-// 0 = no workspace (allocation failed or a capture is in progress: the caller runs another kernel)
+// false = no workspace (allocation failed or a capture is in progress: the caller runs another kernel)
 static bool sk_workspace(int dev, hipStream_t st, int G, size_t slab_floats, SkWorkspace& out) {
   std::lock_guard<std::mutex> lock(g_sk_mutex);
   const uint64_t key = (reinterpret_cast<uint64_t>(st) << 6) ^ (uint64_t)dev;
@@ -431,9 +382,10 @@ static bool sk_workspace(int dev, hipStream_t st, int G, size_t slab_floats, SkW
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
     // the old slabs may still be read by a launch in flight on this stream
-    if (w.ws) { (void)hipStreamSynchronize(st); (void)hipFree(w.ws); (void)hipFree(w.flags); w = SkWorkspace{}; }
+    if (w.ws) { (void)hipStreamSynchronize(st); (void)hipFree(w.ws); (void)hipFree(w.flags); }
     const int g = G > w.G ? G : w.G;
     const size_t sf = slab_floats > w.slab_floats ? slab_floats : w.slab_floats;
+    w = SkWorkspace{};
     float* ws = nullptr; uint32_t* fl = nullptr;
     if (hipMalloc(&ws, (size_t)g * sf * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipMalloc(&fl, 4096) != hipSuccess || hipMemset(fl, 0, 4096) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ws); return false; }
@@ -444,7 +396,7 @@ static bool sk_workspace(int dev, hipStream_t st, int G, size_t slab_floats, SkW
 }
 
 template <typename C>
-static int launch_sk(const GemmParams& p, hipStream_t st) {
+static int launch_sk(const GemmParams& p, bool cut, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   SkPlan pl;
@@ -452,17 +404,24 @@ static int launch_sk(const GemmParams& p, hipStream_t st) {
   pl.tiles_n = (p.N + C::BN - 1) / C::BN;
   pl.tiles = tm * pl.tiles_n;
   pl.ktiles = p.K / 64;
+  pl.cut = cut ? 1 : 0;
   const int64_t U = (int64_t)pl.tiles * pl.ktiles;
   int G = sk_cu_count(dev) & ~7;
   if (G > 1024) G = 1024;
-  // every range holds at least a third of a tile's k-tiles: a cut tile has at most three foreign pieces
-  const int64_t min_units = (pl.ktiles + 2) / 3;
-  while (G > 8 && U / G < min_units) G -= 8;
-  if (U < G) return 0;
+  pl.ws = nullptr; pl.flags = nullptr;
+  if (cut) {
+    // every range holds at least a third of a tile's k-stages: a cut tile has at most three foreign pieces
+    const int64_t min_units = (pl.ktiles + 2) / 3;
+    while (G > 8 && U / G < min_units) G -= 8;
+    if (U < G) return 0;
+    SkWorkspace w;
+    if (!sk_workspace(dev, st, G, C::SLAB_FLOATS, w)) return 0;
+    pl.ws = w.ws; pl.flags = w.flags;
+  } else if (pl.tiles < G) {
+    G = pl.tiles;
+  }
   pl.G = G;
-  SkWorkspace w;
-  if (!sk_workspace(dev, st, G, C::SLAB_FLOATS, w)) return 0;
-  pl.ws = w.ws; pl.flags = w.flags; pl.prof = g_sk_prof;
+  pl.prof = g_sk_prof;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sk_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
@@ -472,21 +431,34 @@ static int launch_sk(const GemmParams& p, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL(gemm_sk_kernel<C>, dim3((unsigned)G), dim3(512), C::LDS_BYTES, st, p, pl);
-  const int rc = check_launch("peneo_gemm (stream-k)");
+  const int rc = check_launch("peneo_gemm (persistent)");
   return rc == PENEO_OK ? 1 : rc;
 }
 
-// Tile shapes: (workgroup tile, wave grid, wave tile, stages)
-//   256 x 128: 4 x 2 waves of  64 x 64, 3 stages of 48 KiB, slab 128 KiB
-//   256 x 256: 2 x 4 waves of 128 x 64, 2 stages of 64 KiB, slab 256 KiB
-template <bool BK> using Sk128 = SkCfg<BK, 4, 2, 2, 2, 3>;
-template <bool BK> using Sk256 = SkCfg<BK, 2, 4, 4, 2, 2>;
+// ring depth: as many stages as fit, at most 6
+template <int F, int BN> struct SkPick {
+  static constexpr int STAGE = (32 * F + BN) * 128;
+  static constexpr int NS = (160 * 1024) / STAGE > 6 ? 6 : (160 * 1024) / STAGE;
+  using type = SkCfg<F, BN, NS>;
+};
 
-static int g_sk_mode = -1;   // PENEO_GEMM_SK: 0 = off, 1 = auto (default), 128 / 256 = force that tile where the kernel applies
+static int g_sk_mode = -1;   // PENEO_GEMM_SK: 0 = off, 1 = auto (default), else F * 1000 + BN (+ 100000: stream-k ranges)
+
+template <int BN>
+static int launch_sk_f(const GemmParams& p, int F, bool cut, hipStream_t st) {
+  switch (F) {
+    case 4: return launch_sk<typename SkPick<4, BN>::type>(p, cut, st);
+    case 5: return launch_sk<typename SkPick<5, BN>::type>(p, cut, st);
+    case 6: return launch_sk<typename SkPick<6, BN>::type>(p, cut, st);
+    case 7: return launch_sk<typename SkPick<7, BN>::type>(p, cut, st);
+    case 8: return launch_sk<typename SkPick<8, BN>::type>(p, cut, st);
+    default: return 0;
+  }
+}
 
 int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   if (g_sk_mode < 0) { const char* e = getenv("PENEO_GEMM_SK"); g_sk_mode = e ? atoi(e) : 1; }
-  if (g_sk_mode == 0) return 0;
+  if (g_sk_mode == 0 || !b_kmajor) return 0;
   if (p.split_k > 1 || p.dz_on || p.K % 64 != 0 || p.K < 128 || p.N % 8 != 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) return 0;
   if ((p.lda * 2) % 16 != 0 || (p.ldb * 2) % 16 != 0) return 0;
@@ -502,18 +474,43 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   }
   // per-lane 32-bit offsets inside a tile
   if ((int64_t)256 * p.lda * 2 >= ((int64_t)1 << 31) || (int64_t)256 * p.ldb * 2 >= ((int64_t)1 << 31)) return 0;
-  int pick = g_sk_mode;
-  if (pick == 1) {
-    if ((int64_t)p.M * p.N < (int64_t)1 << 21 || p.M < 256 || p.N < 128) return 0;   // small problems: the 128 x 128 kernel
-    pick = 128;
+  int mode = g_sk_mode;
+  if (mode == 1) {
+    // The choice per problem (profiles/r06_gemm_persistent.txt).  One workgroup per CU has nothing to overlap a tile's epilogue
+    // with (the C tiles of a round leave in one burst at ~3.5 TB/s), so at M = 5672 the launch only ties the tiled kernels
+    // (two workgroups per CU: one's epilogue under the other's k loop) and they keep those shapes.  It wins
+    //   (1) with many tiles per workgroup (the stream hides every prologue; epilogues drift apart): -25 % at 32 rounds;
+    //   (2) when a tile of the family fills ONE round almost exactly (large-backbone QKV / FFN1: -9 % / -25 %);
+    //   (3) few tiles x deep K (large-backbone FFN2): stream-k ranges, -28 %.
+    if ((int64_t)p.M * p.N < (int64_t)1 << 21 || p.M < 256 || p.N < 128) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int G = sk_cu_count(dev) & ~7;
+    auto tiles = [&](int F, int BN) { return (int64_t)((p.M + 32 * F - 1) / (32 * F)) * ((p.N + BN - 1) / BN); };
+    mode = 0;
+    if (p.N >= 256 && tiles(4, 256) >= 3 * (int64_t)G) mode = 4256;                                   // (1)
+    else if (p.N < 256 && tiles(5, 128) >= 3 * (int64_t)G) mode = 5128;
+    else {
+      const int cand[4][2] = {{5, 256}, {4, 256}, {6, 128}, {5, 128}};                                 // (2): most intense first
+      for (int c = 0; c < 4 && !mode; ++c) {
+        const int64_t t = tiles(cand[c][0], cand[c][1]);
+        if (p.N >= cand[c][1] && t <= G && t * 100 >= (int64_t)G * 90) mode = cand[c][0] * 1000 + cand[c][1];
+      }
+      if (!mode && p.K >= 2048 && tiles(5, 128) * 10 <= (int64_t)G * 6) mode = 105128;                 // (3)
+    }
+    if (!mode) return 0;
   }
-  if (pick == 256) return b_kmajor ? launch_sk<Sk256<true>>(p, st) : launch_sk<Sk256<false>>(p, st);
-  return b_kmajor ? launch_sk<Sk128<true>>(p, st) : launch_sk<Sk128<false>>(p, st);
+  const bool cut = mode >= 100000;
+  mode %= 100000;
+  const int F = mode / 1000, BN = mode % 1000;
+  if (BN == 256) return launch_sk_f<256>(p, F, cut, st);
+  if (BN == 128) return launch_sk_f<128>(p, F, cut, st);
+  return 0;
 }
 
 }  // namespace peneo
 
-/* tools/ and tests only (declared in the header next to peneo_gemm_set_big_mode): 0 = off, 1 = auto, 128 / 256 = force that tile */
+/* tools/ and tests only (declared in the header next to peneo_gemm_set_big_mode) */
 extern "C" void peneo_gemm_set_sk_mode(int mode) { peneo::g_sk_mode = mode; }
 /* tools only, not in the header: device buffer of [1024][16] uint64 that receives one lane's s_memrealtime stamps (100 MHz) at the
  * stations of every workgroup's range (0 start, 1 stream primed, 2 first unit landed, 3 / 4 slab publish, 5 / 6 / 7 flag wait,

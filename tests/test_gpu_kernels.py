@@ -793,12 +793,13 @@ def test_gemm_big_tiles_match_fp32_matmul(ops, mode, bk):
         lib.peneo_gemm_set_big_mode(1)
 
 
-@pytest.mark.parametrize("mode", [128, 256])
-@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("mode", [5128, 4256, 7256, 8256, 6128, 105128, 107256, 104128])
+@pytest.mark.parametrize("bk", [True])
 def test_gemm_stream_k_matches_fp32_matmul(ops, mode, bk):
-    """gemm_sk.hip (one persistent launch, every workgroup a contiguous range of (tile, k-tile) units) forced for ragged problems:
-    tiles cut once, twice and three times by range boundaries (few tiles x many k-tiles), ranges of one unit, M / N that are no
-    multiple of the tile, both B layouts, every fused epilogue option -- against an fp32 matmul of the same bf16 operands and
+    """gemm_sk.hip (one persistent launch, every workgroup a contiguous range of (tile, k-stage) units; mode = F * 1000 + N extent of
+    the tile, + 100000 for ranges that cut tiles = stream-k) forced for ragged problems: tiles cut once, twice and three times by
+    range boundaries (few tiles x many k-stages), ranges of one unit, M / N that are no multiple of the tile, every fused epilogue
+    option -- against an fp32 matmul of the same bf16 operands and
     against the 128 x 128 kernel (same dropout mask function, same epilogue arithmetic: only the summation order differs).
     Every problem is launched three times with fresh operands: the slab flags are reset by their consumers, so a stale flag or a
     stale slab from the launch before shows as a wrong tile."""

@@ -7,7 +7,7 @@ hip.load_library()
 lib = ctypes.CDLL(hip.LIB_PATH)
 lib.peneo_gemm_sk_set_prof.argtypes = [ctypes.c_void_p]
 names = ["start", "primed", "unit0", "pub>", "pub<", "wait>", "flag", "acq<", "ep>", "ep<", "fin ep>", "fin ep<", "end"]
-mode = int(os.environ.get("MODE", 128))
+mode = int(os.environ.get("MODE", 7256))
 for name, m, n, k, bk in [("qkv", 5672, 2304, 768, True), ("out", 5672, 768, 768, True), ("ffn2", 5672, 768, 3072, True), ("4096^3", 4096, 4096, 4096, True)]:
     a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
