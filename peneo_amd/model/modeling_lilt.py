@@ -167,15 +167,16 @@ class _LiltEmbedStage(torch.autograd.Function):
         H, Hl = cfg.hidden_size, cfg.hidden_size // cfg.channel_shrink_ratio
         dev = input_ids.device
         seeds = st.seeds
-        if getattr(model, "check_inputs", True) and (int(bbox.min()) < 0 or int(bbox.max()) > cfg.max_2d_position_embeddings - 1):
-            raise IndexError("The :obj:`bbox`coordinate values should be within 0-1000 range.")
+        # the bbox range check of the reference is the layout embedding kernel's sticky device flag (see LayoutLMv3's _EmbedStage):
+        # check_inputs = True reads it at once (one host sync), "deferred" leaves it to raise_on_bad_inputs(), False ignores it
+        check = getattr(model, "check_inputs", True)
         seeds.prepare_attn_words(cfg.num_hidden_layers, B, cfg.num_attention_heads, S, dev)
         pid = ops.position_ids(input_ids, cfg.pad_token_id)
         x0 = torch.empty((B * S, H), dtype=dt, device=dev)
         ops.embed_fwd(dt, x0, B, S, H, input_ids=input_ids, pos_ids=pid, word=word, type0=type_w[0], pos=pos_w)
         x, m1, r1 = ops.layernorm_fwd(x0, ln_g, ln_b, cfg.layer_norm_eps, drop_p=seeds.p_hidden, drop_seed=seeds.seed(1))
         # layout stream
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = model.input_status(dev) if check else None
         sp = torch.empty((B * S, H), dtype=dt, device=dev)
         ops.embed_fwd(dt, sp, B, S, H, bbox=bbox, x=xw, y=yw, h=hw, w=ww, clip_hw=False, status=status)
         bp = torch.empty((B * S, Hl), dtype=dt, device=dev)
@@ -186,8 +187,8 @@ class _LiltEmbedStage(torch.autograd.Function):
         Wl = wc.cast("boxlin", lin_w, dt)
         l0 = ops.gemm(sp, Wl, bias=lin_b, residual=bp)
         l, m2, r2 = ops.layernorm_fwd(l0, lln_g, lln_b, cfg.layer_norm_eps, drop_p=seeds.p_hidden, drop_seed=seeds.seed(2))
-        if getattr(model, "check_inputs", True) and int(status) != 0:
-            raise IndexError("The :obj:`bbox`coordinate values should be within 0-1000 range.")
+        if check is True:
+            model.raise_on_bad_inputs()
         ctx.model, ctx.st = model, st
         ctx.saved = (pid, x0, m1, r1, sp, l0, m2, r2)
         ctx.inputs = (input_ids, bbox)
@@ -486,6 +487,18 @@ class LiltModel(nn.Module):
     def side_stream(self, device) -> "torch.cuda.Stream":
         return engine_side_stream(device, "wgrad")
 
+
+    def input_status(self, dev) -> torch.Tensor:
+        """int32 [1] on `dev`, sticky: set to 1 by the layout embedding kernel when a box coordinate is out of range."""
+        return self.zeros_i32("input_status", 1, dev)
+
+    def raise_on_bad_inputs(self) -> None:
+        """Read (one host sync per flag) and clear the input flags; raises the reference's IndexError if any forward since the last
+        call saw a bbox coordinate outside its table (reference modeling_lilt.py)."""
+        for key, st in self._consts.items():
+            if key[0] == "input_status" and int(st) != 0:
+                st.zero_()
+                raise IndexError("The :obj:`bbox`coordinate values should be within 0-1000 range.")
 
     def zeros(self, key, shape, dev):
         k = (key, str(shape), str(dev))

@@ -134,6 +134,34 @@ def test_missing_labels_raise():
         m(**bad)
 
 
+@pytest.mark.parametrize("name", ["lmv3_tiny", "lilt_tiny"])
+def test_bbox_out_of_range_raises_like_the_reference(name):
+    """Reference modeling_layoutlmv3.py:133 / modeling_lilt.py raise IndexError on a bbox coordinate outside 0..1000-ish tables.  Here
+    the embedding kernel sets a sticky device flag: read at once by default (the reference's behaviour), left on the device with
+    check_inputs = "deferred" until raise_on_bad_inputs() (what bench.py runs with), ignored with check_inputs = False."""
+    fx = load_golden(name)
+    m = build_model(fx["config"], fx["state_dict"]).eval()
+    good = to_cuda(fx["batch"])
+    bad = dict(good)
+    bad["bbox"] = good["bbox"].clone()
+    bad["bbox"][0, 3, 2] = 5000
+    with torch.no_grad():
+        m(**good)                                             # clean inputs: no flag
+        m.backbone.raise_on_bad_inputs()
+        with pytest.raises(IndexError):
+            m(**bad)
+        m.backbone.check_inputs = "deferred"
+        m(**bad)                                              # no host sync, no exception here ...
+        m(**good)                                             # ... the flag is sticky across forwards ...
+        with pytest.raises(IndexError):
+            m.backbone.raise_on_bad_inputs()                  # ... until it is read
+        m.backbone.raise_on_bad_inputs()                      # and cleared by the read
+        m.backbone.check_inputs = False
+        m(**bad)
+        m.backbone.check_inputs = "deferred"
+        m.backbone.raise_on_bad_inputs()                      # (nothing was recorded with the check off)
+
+
 def test_cpu_tensors_are_rejected_loudly():
     from peneo_amd.hip import PeneoHipError
     fx = load_golden("lmv3_tiny")
