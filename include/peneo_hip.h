@@ -356,7 +356,12 @@ int peneo_pair_heads_fwd(int dtype, const void* ab, int B, int N, const peneo_pa
  *          chain) - what autograd under autocast saves of model/peneo_decoder.py:253-271, 2 bytes per pair and hidden unit;
  *   x_rows [B * peneo_pair_bwd_rows(N), D] bf16: x = SiLU(a_i + b_j) in block order (the B operand of dW1 = dz^T x).
  * Logits, loss partial rows and dlogits are those of peneo_pair_heads_fwd bit for bit (same arithmetic per pair, indexed by the
- * packed pair index); `loss->partials` has peneo_pair_loss_partials_save(B, N) rows here.  16-byte aligned buffers. */
+ * packed pair index); `loss->partials` has peneo_pair_loss_partials_save(B, N) rows here.  16-byte aligned buffers.
+ * RANGE: z is stored as f16 and a dropped unit as -30000 + W1 x, so the saved form assumes |W1 x + b1| < 30000 for every pair and
+ * hidden unit (then a dropped z stays below -20 where SiLU and SiLU' are 0 in f16, and nothing reaches the f16 limit 65504: an
+ * overflow to -inf would give -inf * 0 = NaN in peneo_pair_bwd_saved).  With LayerNorm-ed inputs and initializer_range-scale
+ * weights |z| is O(10); a caller that cannot bound it runs peneo_pair_heads_fwd + peneo_pair_bwd_fused (the recomputing form has
+ * no such limit; PEneoDecoder.save_pair_act = False / PENEO_PAIR_SAVE=0). */
 int peneo_pair_save_supported(int dtype, int D, int num_heads);
 size_t peneo_pair_save_bytes(int B, int N, int num_heads, int D);
 int64_t peneo_pair_loss_partials_save(int B, int N);

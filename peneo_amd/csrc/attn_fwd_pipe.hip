@@ -189,6 +189,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnParams p) {
         mt = fmaxf(mt, v);
       }
     }
+    // Keys past T (the ragged last tile only; a wave-uniform branch taken once per launch).  Round 6: masked HERE, as attn_fwd_kernel
+    // does -- until then the kernel relied on the caller's bias holding -1e30 in its padding columns (true for peneo_relpos_bias_fwd's
+    // output, not part of peneo_attn_fwd's contract: a zero or uninitialised padding put the clamped key rows into the softmax).
+    if (t + 1 == nt && (Tn & (TK - 1)) != 0) {
+      mt = kMasked;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (t * TK + 8 * g + 4 * half + e >= Tn) s[4 * g + e] = kMasked;
+          mt = fmaxf(mt, s[4 * g + e]);
+        }
+    }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = (mt > m_run + kRescaleTau) ? mt : m_run;
     if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {   // rare after the first tiles (wave-uniform branch)

@@ -41,14 +41,12 @@ int gemm(int ak, int bk, int M, int N, int K, const void* A, int64_t lda, const 
 // two reusable events per (host thread, device) for the main -> side hand-offs of a backward (a wait captures the record that
 // precedes it, so re-recording an event for the next layer does not disturb waits already enqueued).  Per THREAD: two host threads
 // running backwards on one device with different stream pairs must not interleave record / wait on one event (round-4 review); a
-// thread's events are destroyed when it exits.
+// thread's two events per device are NOT destroyed when it exits: backwards run on autograd's worker threads, whose
+// thread-locals are torn down at process exit, possibly after the HIP runtime has begun unloading -- two events per thread are a
+// negligible leak, a hipEventDestroy into a half-unloaded runtime is not.
 struct DevEvents { hipEvent_t e[2]; bool ok; };
 struct ThreadEvents {
   DevEvents tab[64] = {};
-  ~ThreadEvents() {
-    for (DevEvents& d : tab)
-      if (d.ok) { (void)hipEventDestroy(d.e[0]); (void)hipEventDestroy(d.e[1]); }
-  }
 };
 DevEvents* events_of_current_device() {
   static thread_local ThreadEvents mine;

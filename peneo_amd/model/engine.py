@@ -218,6 +218,19 @@ def big_release(tag: str, base) -> None:
         free.append(base)
 
 
+def big_clear(device=None) -> int:
+    """Drop the step-sized buffers kept between steps (all devices, or one) and return how many bytes that hands back to the caching
+    allocator (torch.cuda.empty_cache() then returns them to the driver).  Called by PEneoDecoder.train(False) -- after training,
+    inference on the same model needs none of them (9.2 GB at 8 x 511 tokens, ~35 GB at N = 1023) -- and by anyone who wants the
+    memory; the next training step simply allocates them again.  Buffers of a step in flight are not in the pool and are untouched."""
+    n = 0
+    for key in list(_BIG_FREE):
+        if device is None or key[1] == str(device):
+            n += sum(b.numel() for b in _BIG_FREE[key])
+            del _BIG_FREE[key]
+    return n
+
+
 # ---- deferred joins of side-stream work ------------------------------------------------------------------------------
 # A backward stage that put its weight-gradient kernels on a side stream used to end with main.wait_stream(side): the main
 # stream (= the activation-gradient critical path) then idles until the last weight gradient of the layer is done (~50 us

@@ -21,7 +21,7 @@ from transformers.modeling_outputs import ModelOutput
 
 from .. import ops
 from ..hip import ACT_NONE, ACT_SILU, PeneoHipError
-from .engine import DropoutSeeds, WeightCache, big_acquire, big_release, can_defer, defer_join, join_pending, mark_late
+from .engine import DropoutSeeds, WeightCache, big_acquire, big_clear, big_release, can_defer, defer_join, join_pending, mark_late
 
 HEAD_NAMES = ("line_extraction", "ent_linking_h2h", "ent_linking_t2t", "line_grouping_h2h", "line_grouping_t2t")
 TAG_KWARGS = ("line_extraction_shaking_tag", "ent_linking_head_rel_shaking_tag", "ent_linking_tail_rel_shaking_tag",
@@ -220,11 +220,20 @@ class _DecoderStage(torch.autograd.Function):
                 and ops.pair_save_supported(dt, D, len(HEAD_NAMES)))
         bufs = None
         if save:
-            # (step-sized buffers are kept between steps: engine.big_acquire)
-            act, act_h = big_acquire("pair_act", (ops.pair_save_bytes(B, N, len(HEAD_NAMES), D),), torch.uint8, dev)
-            xr, xr_h = big_acquire("pair_x", (B * ops.pair_bwd_rows(N), D), dt, dev)
-            bufs = (act, xr)
-            saved["pair_act"], saved["pair_x"] = (act, act_h), (xr, xr_h)
+            # (step-sized buffers are kept between steps: engine.big_acquire.)  The saved form is an optimisation that costs memory:
+            # when its buffers do not fit, the step continues on the recomputing backward, which needs none of them
+            try:
+                act, act_h = big_acquire("pair_act", (ops.pair_save_bytes(B, N, len(HEAD_NAMES), D),), torch.uint8, dev)
+                try:
+                    xr, xr_h = big_acquire("pair_x", (B * ops.pair_bwd_rows(N), D), dt, dev)
+                except torch.cuda.OutOfMemoryError:
+                    big_release("pair_act", act_h)
+                    raise
+                bufs = (act, xr)
+                saved["pair_act"], saved["pair_x"] = (act, act_h), (xr, xr_h)
+            except torch.cuda.OutOfMemoryError:
+                big_clear(dev)
+                save = False
         res = ops.pair_heads_fwd(ab, wp, b1cat, b2cat, HEAD_CLASSES, want_logits=want_logits,
                                  tags=tags, class_weights=cws, want_dlogits=need_grad and tags is not None,
                                  drop_p=seeds.p_hidden, drop_seed=seeds.seed(903), save=save, save_buffers=bufs)
@@ -582,6 +591,13 @@ def _generic_heads_backward(dec, sv, heads, scale):
 
 class PEneoDecoder(nn.Module):
     """PEneo pair extraction downstream head (reference :201-443)."""
+
+    def train(self, mode: bool = True):
+        """Leaving training mode hands the step-sized buffers the saved-activation backward keeps between steps (engine.big_acquire:
+        9.2 GB at 8 x 511 tokens) back to the allocator: inference needs none of them, the next training step takes them again."""
+        if not mode:
+            big_clear()
+        return super().train(mode)
 
     def side_stream(self, device, which: int = 0) -> "torch.cuda.Stream":
         """Extra HIP streams of the chunked backward (created once per device)."""

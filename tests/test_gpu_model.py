@@ -399,6 +399,9 @@ def test_saved_pair_activations_keep_the_gradients():
     assert sorted(k[0] for k in kept) == ["pair_act", "pair_dz", "pair_x"] and all(len(v) == 1 for v in kept.values()), kept
     l_again, g_again = _fwd_bwd(m, batch, torch.bfloat16, seed_step=4000)
     assert {k: [b.data_ptr() for b in v] for k, v in engine._BIG_FREE.items() if k[0].startswith("pair_")} == kept      # the same three buffers
+    m.eval()                                                   # leaving training mode hands them back (PEneoDecoder.train -> engine.big_clear)
+    assert not any(k[0].startswith("pair_") for k in engine._BIG_FREE)
+    m.train()
     dec.save_pair_act = False
     try:
         l_off, g_off = _fwd_bwd(m, batch, torch.bfloat16, seed_step=4000)

@@ -293,7 +293,15 @@ def test_step_sized_buffers_are_kept_and_handed_out_once():
     assert len(engine._BIG_FREE[("t", "cpu")]) == 2   # at most two kept per tag
     e, he = engine.big_acquire("t", (1 << 22,), torch.uint8, "cpu")       # larger than anything kept: the kept ones go
     assert he.numel() >= 1 << 22 and engine._BIG_FREE[("t", "cpu")] == []
-    engine._BIG_FREE.clear()
+    # big_clear: the pool of one device, or all of it, is dropped and reported; a buffer still held is untouched
+    engine.big_release("t", he)
+    engine.big_release("u", hb)
+    held = engine.big_acquire("v", (16,), torch.uint8, "cpu")[1]
+    assert engine.big_clear("cuda:7") == 0 and len(engine._BIG_FREE[("t", "cpu")]) == 1
+    assert engine.big_clear("cpu") == he.numel() + hb.numel() and not any(k[1] == "cpu" for k in engine._BIG_FREE)
+    assert held.numel() > 0
+    engine.big_release("t", he)
+    assert engine.big_clear() == he.numel() and engine._BIG_FREE == {}
 
 
 def test_saved_activation_sizes_follow_the_block_walk():
