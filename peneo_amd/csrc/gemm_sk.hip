@@ -478,26 +478,19 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   if (mode == 1) {
     // The choice per problem (profiles/r06_gemm_persistent.txt).  One workgroup per CU has nothing to overlap a tile's epilogue
     // with (the C tiles of a round leave in one burst at ~3.5 TB/s), so at M = 5672 the launch only ties the tiled kernels
-    // (two workgroups per CU: one's epilogue under the other's k loop) and they keep those shapes.  It wins
-    //   (1) with many tiles per workgroup (the stream hides every prologue; epilogues drift apart): -25 % at 32 rounds;
-    //   (2) when a tile of the family fills ONE round almost exactly (large-backbone QKV / FFN1: -9 % / -25 %);
-    //   (3) few tiles x deep K (large-backbone FFN2): stream-k ranges, -28 %.
+    // (two workgroups per CU: one's epilogue under the other's k loop) and they keep those shapes.  Alone it wins on three kinds
+    // of problem -- many tiles per workgroup (-20 %), a tile of the family that fills one round (large-backbone QKV / FFN1: -11 /
+    // -24 %), few tiles x deep K as stream-k ranges (large-backbone FFN2: -30 %) -- but INSIDE the large backbone's forward the
+    // last two lose what they won alone (FFN1 44 us against 32 alone, with the GELU epilogue exposed; the tiled kernels run
+    // faster there than alone: 146 against 138 us of GEMM per layer), so only the first rule ships.
     if ((int64_t)p.M * p.N < (int64_t)1 << 21 || p.M < 256 || p.N < 128) return 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int G = sk_cu_count(dev) & ~7;
     auto tiles = [&](int F, int BN) { return (int64_t)((p.M + 32 * F - 1) / (32 * F)) * ((p.N + BN - 1) / BN); };
     mode = 0;
-    if (p.N >= 256 && tiles(4, 256) >= 3 * (int64_t)G) mode = 4256;                                   // (1)
+    if (p.N >= 256 && tiles(4, 256) >= 3 * (int64_t)G) mode = 4256;
     else if (p.N < 256 && tiles(5, 128) >= 3 * (int64_t)G) mode = 5128;
-    else {
-      const int cand[4][2] = {{5, 256}, {4, 256}, {6, 128}, {5, 128}};                                 // (2): most intense first
-      for (int c = 0; c < 4 && !mode; ++c) {
-        const int64_t t = tiles(cand[c][0], cand[c][1]);
-        if (p.N >= cand[c][1] && t <= G && t * 100 >= (int64_t)G * 90) mode = cand[c][0] * 1000 + cand[c][1];
-      }
-      if (!mode && p.K >= 2048 && tiles(5, 128) * 10 <= (int64_t)G * 6) mode = 105128;                 // (3)
-    }
     if (!mode) return 0;
   }
   const bool cut = mode >= 100000;

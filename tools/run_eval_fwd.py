@@ -5,14 +5,15 @@ from seeded import layoutlmv3_config, lilt_config, peneo_config
 from peneo_amd.model import PEneoConfig, PEneoModel
 from peneo_amd.data import synthetic_rfund_batch
 LILT = os.environ.get("BACKBONE", "layoutlmv3") == "lilt"
-pcfg = peneo_config("lilt-roberta-en-base", lilt_config("base")) if LILT else peneo_config("layoutlmv3-base", layoutlmv3_config("base"))
+SIZE = os.environ.get("SIZE", "base"); SEQ = int(os.environ.get("SEQ", 512)); LINES = int(os.environ.get("LINES", 128)); DOCS = int(os.environ.get("DOCS", 8))
+pcfg = peneo_config("lilt-roberta-en-base", lilt_config("base")) if LILT else peneo_config("layoutlmv3-base", layoutlmv3_config(SIZE))
 m = PEneoModel(PEneoConfig(**{k: v for k, v in pcfg.items() if k != "model_type"})).cuda().set_compute_dtype(torch.bfloat16).eval()
 m.backbone.check_inputs = False
-bs = [{k: v.cuda() for k, v in synthetic_rfund_batch(8, 512, 128, 50265, seed=s).items() if not (LILT and k == "image")} for s in range(3)]
+bs = [{k: v.cuda() for k, v in synthetic_rfund_batch(DOCS, SEQ, LINES, 50265, seed=s).items() if not (LILT and k == "image")} for s in range(3)]
 with torch.no_grad():
     for i in range(3): m(**bs[i])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = int(os.environ.get("N", "10"))
     for i in range(n): m(**bs[i % 3])
     torch.cuda.synchronize()
-print(f"eval forward {(time.perf_counter() - t0) / n * 1e3:.3f} ms per 8 documents")
+print(f"eval forward {(time.perf_counter() - t0) / n * 1e3:.3f} ms per {DOCS} documents")
