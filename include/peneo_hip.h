@@ -577,6 +577,12 @@ void peneo_gemm_set_big_mode(int mode);
  * word per workgroup in a buffer the library allocates per (device, stream) at the first call -- not during a stream capture: run
  * the captured sequence once eagerly first (a capture that meets a missing buffer falls back to the tiled kernels). */
 void peneo_gemm_set_sk_mode(int mode);
+/* tools/ only.  peneo_gemm_sk_set_prof: device buffer of [1024][16] uint64 that receives one lane's s_memrealtime stamps (100 MHz) at
+ * the stations of every workgroup's range of a persistent launch (0 start, 1 stream primed, 2 first unit landed, 3 / 4 slab publish,
+ * 5 / 6 / 7 flag wait and acquire, 8 / 9 last whole-tile epilogue, 10 / 11 finisher epilogue, 12 stores drained); NULL = off.
+ * peneo_gemm_sk_set_max_groups: at most this many workgroups per persistent launch (a multiple of 8; 0 = one per CU). */
+void peneo_gemm_sk_set_prof(void* stamps);
+void peneo_gemm_sk_set_max_groups(int n);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@
 //   * lane-linear DMA images, conflicts removed by permuting the SOURCE 16-byte slots of a row: K / V rows (128 B) use
 //     slot ^ bitrev3(row >> 1) (b128 fragment reads of S^T and transpose reads of V^T both conflict-free), the bias rows (64 B: a
 //     lane reads 8 bytes of ITS query's row) use slot ^ ((row >> 2) & 3) (two-way: the 8-byte halves cannot be permuted by a 16-byte DMA);
-//   * keys past T need no predicate: the bias tensor's padding columns are -1e30 and K / V rows are clamped to T - 1;
+//   * keys past T: K / V rows are clamped to T - 1 and the ragged last tile masks its scores itself (round 6: one wave-uniform branch
+//     per launch; until then the kernel relied on -1e30 in the bias tensor's padding columns, which peneo_attn_fwd does not promise);
 //   * O rows leave as 16-byte pieces straight from the accumulator layout (v_permlane32_swap pairs), no LDS round trip.
 #include <cstdlib>
 #include "common.h"

@@ -7,9 +7,8 @@
 // it on the model's M = 5672 problems: 17 us of a QKV-shaped launch sit before the first and after the last k-tile, the tile
 // counts (270 / 414 / 552 / 810 on 256 CUs) quantise badly, and a two-stage ring lets the request queue run dry in every k-tile.
 // Here
-//   * the tile is chosen per problem from a FAMILY -- M extent 32 F (F = 4..8: 128 .. 256 rows), N extent 128 or 256 -- so that the
-//     tiles fill one or two rounds of the CUs (QKV: 224 x 256 -> 234 tiles; FFN1: 160 x 256 -> 432; out-proj: 160 x 128 -> 216),
-//     which the 16 x 16 x 32 MFMA allows: 2 x 4 waves, wave tile 16 F x (N extent / 4);
+//   * the tile comes from a FAMILY -- M extent 32 F (F = 4..8: 128 .. 256 rows) x N extent 128, F = 4..6 x N extent 256 -- which
+//     the 16 x 16 x 32 MFMA allows: 2 x 4 waves, wave tile 16 F x (N extent / 4);
 //   * the ring holds 3 .. 6 stages of 64 k (every LDS-DMA instruction fetches 8 whole 128-byte lines: the fill rate is a REQUEST
 //     rate -- the same kernel staging 16 rows x 64 bytes per instruction fills at 14.6 instead of 22 B/clk), NSTAGE - 1 stages always
 //     in flight: the request queue never drains inside a tile, nor between tiles -- the ring is ONE stream over the workgroup's
@@ -362,6 +361,7 @@ static std::mutex g_sk_mutex;
 static std::unordered_map<uint64_t, SkWorkspace> g_sk_ws;     // per (device, stream): launches of one stream are ordered
 static int g_sk_cus[64] = {};
 static uint64_t* g_sk_prof = nullptr;
+static int g_sk_max_g = 0;        // tools: cap on the workgroups of a launch (0 = one per CU)
 
 static int sk_cu_count(int dev) {
   if (dev < 0 || dev >= 64) return 256;
@@ -408,6 +408,7 @@ static int launch_sk(const GemmParams& p, bool cut, hipStream_t st) {
   const int64_t U = (int64_t)pl.tiles * pl.ktiles;
   int G = sk_cu_count(dev) & ~7;
   if (G > 1024) G = 1024;
+  if (g_sk_max_g > 0 && G > g_sk_max_g) G = g_sk_max_g & ~7;
   pl.ws = nullptr; pl.flags = nullptr;
   if (cut) {
     // every range holds at least a third of a tile's k-stages: a cut tile has at most three foreign pieces
@@ -444,14 +445,17 @@ template <int F, int BN> struct SkPick {
 
 static int g_sk_mode = -1;   // PENEO_GEMM_SK: 0 = off, 1 = auto (default), else F * 1000 + BN (+ 100000: stream-k ranges)
 
+// F = 7, 8 at N extent 256 are not instantiated: 112 / 128 accumulators + two k-halves of fragments + the batched epilogue do not
+// fit 256 registers (the compiler spills accumulators INSIDE the k loop: 230 us for a 20 GFLOP problem) and their 61 / 64 KiB
+// stages leave a two-stage ring (the fill queue drains at every stage: DESIGN 8)
 template <int BN>
 static int launch_sk_f(const GemmParams& p, int F, bool cut, hipStream_t st) {
   switch (F) {
     case 4: return launch_sk<typename SkPick<4, BN>::type>(p, cut, st);
     case 5: return launch_sk<typename SkPick<5, BN>::type>(p, cut, st);
     case 6: return launch_sk<typename SkPick<6, BN>::type>(p, cut, st);
-    case 7: return launch_sk<typename SkPick<7, BN>::type>(p, cut, st);
-    case 8: return launch_sk<typename SkPick<8, BN>::type>(p, cut, st);
+    case 7: if constexpr (BN == 128) return launch_sk<typename SkPick<7, BN>::type>(p, cut, st); else return 0;
+    case 8: if constexpr (BN == 128) return launch_sk<typename SkPick<8, BN>::type>(p, cut, st); else return 0;
     default: return 0;
   }
 }
@@ -505,7 +509,10 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
 
 /* tools/ and tests only (declared in the header next to peneo_gemm_set_big_mode) */
 extern "C" void peneo_gemm_set_sk_mode(int mode) { peneo::g_sk_mode = mode; }
-/* tools only, not in the header: device buffer of [1024][16] uint64 that receives one lane's s_memrealtime stamps (100 MHz) at the
+/* tools only (diagnostics block of the header): device buffer of [1024][16] uint64 that receives one lane's s_memrealtime stamps (100 MHz) at the
  * stations of every workgroup's range (0 start, 1 stream primed, 2 first unit landed, 3 / 4 slab publish, 5 / 6 / 7 flag wait,
  * acquire, 8 / 9 last whole-tile epilogue, 10 / 11 finisher epilogue, 12 stores drained); null = off */
 extern "C" void peneo_gemm_sk_set_prof(void* buf) { peneo::g_sk_prof = reinterpret_cast<uint64_t*>(buf); }
+/* tools only (diagnostics block of the header): at most this many workgroups per launch (a multiple of 8; 0 = one per CU) -- how a persistent launch on a
+ * side stream shares the chip with the kernels of another stream (tools/run_sk_interference.py) */
+extern "C" void peneo_gemm_sk_set_max_groups(int n) { peneo::g_sk_max_g = n; }

@@ -169,6 +169,8 @@ SIGNATURES = {
     "peneo_spots_compact": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "peneo_gemm_set_big_mode": (None, [_i]),    # diagnostics block of the header: process-wide, not thread-safe
     "peneo_gemm_set_sk_mode": (None, [_i]),
+    "peneo_gemm_sk_set_prof": (None, [_vp]),
+    "peneo_gemm_sk_set_max_groups": (None, [_i]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -801,7 +801,7 @@ def test_gemm_big_tiles_match_fp32_matmul(ops, mode, bk):
         lib.peneo_gemm_set_big_mode(1)
 
 
-@pytest.mark.parametrize("mode", [5128, 4256, 7256, 8256, 6128, 105128, 107256, 104128])
+@pytest.mark.parametrize("mode", [5128, 4256, 6256, 8128, 7128, 105128, 105256, 104128, 108128])
 @pytest.mark.parametrize("bk", [True])
 def test_gemm_stream_k_matches_fp32_matmul(ops, mode, bk):
     """gemm_sk.hip (one persistent launch, every workgroup a contiguous range of (tile, k-stage) units; mode = F * 1000 + N extent of
