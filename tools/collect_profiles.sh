@@ -23,6 +23,7 @@ python tools/run_blas_ref.py > $OUT/gemm_vs_vendor.txt 2>&1
 python bench.py --backbone lilt --no-cpu-baseline > $OUT/lilt_line.json 2>/dev/null
 python bench.py --vocab 250002 --no-cpu-baseline --no-ragged > $OUT/xlmr_vocab_line.json 2>/dev/null
 python bench.py --size large --seq-len 1024 --lines 256 --docs-per-gpu 2 --no-cpu-baseline > $OUT/large_line.json 2>/dev/null
+python bench.py --size large --seq-len 1024 --lines 256 --docs-per-gpu 4 --no-cpu-baseline --trained-agree-steps 0 > $OUT/large_4docs_line.json 2>/dev/null
 python bench.py --dtype fp32 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fp32_line.json 2>/dev/null
 PENEO_DIST_BACKEND=gloo PENEO_DEVICE=0 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/two_ranks_one_gpu_gloo_line.json 2> $OUT/two_ranks.err
 python tools/run_phases.py > $OUT/phases.txt 2>&1
