@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmParams p, int tiles_n
       for (int r = 0; r < 16; ++r) patch[acc_row(r, lane) * C::EP_LD + j * 32 + acc_col(lane)] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
     const int mb = m0 + (wm * FM + i) * 32, nb = n0 + wn * FN * 32 + cgi * 8;
-#pragma unroll
+#pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int rl = pass * RPP + rli;
       if (rli < RPP && rl < 32 && mb + rl < p.M && nb + 8 <= p.N) {
