@@ -158,6 +158,9 @@ __device__ __forceinline__ void dz_prefetch(const GemmParams& p, int m0, int n0,
 // epilogue: park the accumulators in LDS (the staging buffers are dead now), then walk the tile
 // row-major so that consecutive lanes own consecutive columns (coalesced C / residual traffic)
 // and the fused epilogue stays a compact rolled loop.
+// DZ: the pair-head backward epilogue (peneo_gemm_epilogue.pair_dz) is compiled into its own instantiations only - 15 KB of code
+// that every other GEMM kernel used to carry (round 6: the instruction cache of a CU pair is 64 KB and a layer's kernels alternate)
+template <bool DZ>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&acc)[2][2], char* smem, int m0, int n0, int tid,
                                               int lane, int wm, int wn, const DzPre& pre, int zsplit) {
   float* sC = reinterpret_cast<float*>(smem);  // [128][128] fp32 = 64 KiB
@@ -170,7 +173,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
         sC[(wm * 64 + i * 32 + acc_row(r, lane)) * GB + wn * 64 + j * 32 + acc_col(lane)] = acc[i][j][r];
   __syncthreads();
   const int mrem = min(GB, p.M - m0), nrem = min(GB, p.N - n0);
-  if (p.dz_on) {
+  if constexpr (DZ) {
     // z = acc + b1 -> dz.  Thread = 8 consecutive columns (one 16-byte store per row) x 8 rows; the per-row dlogits of
     // the tile's head(s) are staged in LDS behind the C tile; column sums (dW2 / db1 partials) are reduced over the 16
     // row-lanes through LDS (the C tile is dead by then) and leave as one atomic per column and quantity.
@@ -354,7 +357,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16_t (&ac
   }
 }
 
-template <typename T, bool AK, bool BK>
+template <typename T, bool AK, bool BK, bool DZ = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KT = ROWB / sizeof(T);             // k elements per tile: 64 (bf16) / 32 (fp32)
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
   DzPre dzpre = {};
-  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
+  if constexpr (DZ) dz_prefetch(p, m0, n0, tid, dzpre);
   const T* A = reinterpret_cast<const T*>(p.A);
   const T* B = reinterpret_cast<const T*>(p.B);
 
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, blockIdx.z);
+  tile_epilogue<DZ>(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, blockIdx.z);
 }
 
 // ================================================================================================
@@ -515,7 +518,7 @@ __device__ __forceinline__ void pmma(const PFrag& a, const PFrag& b, f32x16_t& a
 
 // the tile (m0, n0, split slice) is chosen by the __global__ wrappers below: one problem per launch, or several
 // independent problems side by side in one launch (peneo_gemm_group)
-template <bool AK, bool BK, bool CS = false>
+template <bool AK, bool BK, bool CS = false, bool DZ = false>
 __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* smem, const int m0, const int n0, const int zsplit,
                                                    const int cs_col = 0, const int cs_mod = 1) {
   constexpr int STAGE = 2 * TILE_BYTES;
@@ -523,7 +526,7 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   DzPre dzpre = {};
-  if (p.dz_on) dz_prefetch(p, m0, n0, tid, dzpre);
+  if constexpr (DZ) dz_prefetch(p, m0, n0, tid, dzpre);
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
@@ -771,10 +774,10 @@ __device__ __forceinline__ void gemm_dma_pipe_body(const GemmParams& p, char* sm
       }
     }
   }
-  tile_epilogue(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
+  tile_epilogue<DZ>(p, acc, smem, m0, n0, tid, lane, wm, wn, dzpre, zsplit);
 }
 
-template <bool AK, bool BK, bool CS = false>
+template <bool AK, bool BK, bool CS = false, bool DZ = false>
 __global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_pipe_kernel(GemmParams p) {
   const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7, slot = lin >> 3;
   const int tile3 = xcd * q8 + min(xcd, r8) + slot;
   const int zsplit = tile3 / gxy, tile = tile3 - zsplit * gxy;
-  gemm_dma_pipe_body<AK, BK, CS>(p, smem, (tile / gx) * GB, (tile % gx) * GB, zsplit, tile % gx, gx);
+  gemm_dma_pipe_body<AK, BK, CS, DZ>(p, smem, (tile / gx) * GB, (tile % gx) * GB, zsplit, tile % gx, gx);
 }
 
 // Several independent GEMMs of one operand layout in ONE launch (no split-k): the tiles of all problems are numbered
@@ -857,8 +860,10 @@ static int launch_gemm(const GemmParams& p, bool ak, bool bk, dim3 grid, hipStre
   size_t shmem = 4 * TILE_BYTES + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
   if (p.dz_on) {
     if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
+    hipLaunchKernelGGL((gemm_kernel<T, true, true, true>), grid, dim3(256), shmem, st, p);
+    return check_launch("peneo_gemm");
   }
   if (ak && bk) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), shmem, st, p);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), shmem, st, p);
@@ -871,8 +876,10 @@ static int launch_gemm_dma_pipe(const GemmParams& p, bool ak, bool bk, dim3 grid
   size_t shmem = 4 * TILE_BYTES + (p.dz_on ? 2 * GB * 4 * sizeof(float) : 0);
   if (p.dz_on) {
     if (!(ak && bk)) { set_error("peneo_gemm: pair_dz needs k-major A and B"); return PENEO_ERR_INVALID; }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_pipe_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_pipe_kernel<true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)shmem) != hipSuccess) { set_error("peneo_gemm: cannot raise dynamic LDS"); return PENEO_ERR_LAUNCH; }
+    hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, true, false, true>), grid, dim3(256), shmem, st, p);
+    return check_launch("peneo_gemm");
   }
   if (ak && bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, true>), grid, dim3(256), shmem, st, p);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_dma_pipe_kernel<true, false>), grid, dim3(256), shmem, st, p);
