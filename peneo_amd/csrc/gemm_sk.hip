@@ -64,7 +64,13 @@ struct SkCfg {
 
 typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
 
-template <typename C>
+// EP: what the epilogue of a tile is compiled for.  The fused epilogue of gemm_common.h inlined once per granule is 56 - 142 KB of code
+// per kernel, run once per tile straight from a cold instruction cache (a tile's epilogue measured 5 - 8 us that way, 1.4 - 1.6 us
+// with 12 - 15 KB of code): the three epilogues the encoder's forward uses get their own small instantiations (bf16 C, alpha = 1, no
+// gradient source, no accumulation); everything else runs EP_GENERIC.
+enum { SK_EP_GENERIC = 0, SK_EP_BIAS = 1, SK_EP_GELU = 2, SK_EP_RES = 3 };
+
+template <typename C, int EP>
 __global__ __launch_bounds__(512) void gemm_sk_kernel(GemmParams p, SkPlan pl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int F = C::F, NB = C::NB, NSTAGE = C::NSTAGE;
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(512) void gemm_sk_kernel(GemmParams p, SkPlan pl) {
     }
     auto load_block = [&](auto ic, EpIn8 (&in)[NB / 2]) {
       constexpr int i = decltype(ic)::value;
+      if constexpr (EP == SK_EP_BIAS || EP == SK_EP_GELU) return;        // (no matrix-shaped input)
 #pragma unroll
       for (int jj = 0; jj < NB / 2; ++jj) {
         const int m = mbase + 16 * i, n = nbase + 32 * jj;
@@ -217,7 +224,37 @@ __global__ __launch_bounds__(512) void gemm_sk_kernel(GemmParams p, SkPlan pl) {
           val[t] = __uint_as_float(sw[0]); val[4 + t] = __uint_as_float(sw[1]);
         }
         const int m = mbase + 16 * i, n = nbase + 32 * jj;
-        if (m < p.M && n + 8 <= p.N) epilogue_apply8(p, m, n, val, p.ep.bias ? bias[jj] : nullptr, prim, in[jj]);
+        if (m < p.M && n + 8 <= p.N) {
+          if constexpr (EP == SK_EP_GENERIC) {
+            epilogue_apply8(p, m, n, val, p.ep.bias ? bias[jj] : nullptr, prim, in[jj]);
+          } else {
+            // the same arithmetic in the same order as epilogue_apply8 for the options this instantiation is launched with
+            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
+            if (p.ep.bias) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) val[e] += bias[jj][e];
+            }
+            if constexpr (EP == SK_EP_GELU) {
+              if (p.ep.preact) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.ep.preact) + (int64_t)m * p.ep.ld_preact + n) = pack16<bf16_t>(val);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) val[e] = gelu_fast_f(val[e]);
+            }
+            if constexpr (EP == SK_EP_RES) {
+              if (p.ep.drop_p > 0.f) {
+                const uint32_t thresh = (uint32_t)fminf(p.ep.drop_p * 4294967296.0f, 4294967040.0f);
+                const float ks = 1.0f / (1.0f - p.ep.drop_p);
+                const uint32_t keep = dropout_keep8(p.ep.drop_seed, (uint64_t)m * (uint64_t)p.N + n, thresh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = ((keep >> e) & 1u) ? val[e] * ks : 0.f;
+              }
+              float r[8];
+              unpack16<bf16_t>(in[jj].x0, r);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) val[e] += r[e];
+            }
+            *reinterpret_cast<uint4*>(crow) = pack16<bf16_t>(val);
+          }
+        }
       }
     };
     auto batch = [&](auto i0c) {          // two 16-row blocks per batch
@@ -395,8 +432,8 @@ static bool sk_workspace(int dev, hipStream_t st, int G, size_t slab_floats, SkW
   return true;
 }
 
-template <typename C>
-static int launch_sk(const GemmParams& p, bool cut, hipStream_t st) {
+template <typename C, int EP>
+static int launch_sk_ep(const GemmParams& p, bool cut, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   SkPlan pl;
@@ -425,15 +462,38 @@ static int launch_sk(const GemmParams& p, bool cut, hipStream_t st) {
   pl.prof = g_sk_prof;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sk_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sk_kernel<C, EP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
       set_error("peneo_gemm: cannot raise dynamic LDS to %d bytes", C::LDS_BYTES);
       return PENEO_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_sk_kernel<C>, dim3((unsigned)G), dim3(512), C::LDS_BYTES, st, p, pl);
+  hipLaunchKernelGGL((gemm_sk_kernel<C, EP>), dim3((unsigned)G), dim3(512), C::LDS_BYTES, st, p, pl);
   const int rc = check_launch("peneo_gemm (persistent)");
   return rc == PENEO_OK ? 1 : rc;
+}
+
+// which instantiation an epilogue runs: the small ones cover bf16 C with alpha = 1 and (bias) | (bias, GELU, pre-activation store) |
+// (bias, dropout, bf16 residual); FAST = false keeps the tile shapes the rules never pick on the generic epilogue only (build time)
+static int sk_ep_kind(const GemmParams& p) {
+  const peneo_gemm_epilogue& e = p.ep;
+  if (p.c_dtype != PENEO_BF16 || e.alpha != 1.f || e.grad_src || e.accumulate) return SK_EP_GENERIC;
+  if (e.act == PENEO_ACT_GELU && !e.residual && e.drop_p == 0.f) return SK_EP_GELU;
+  if (e.act != PENEO_ACT_NONE || e.preact) return SK_EP_GENERIC;
+  if (e.residual) return SK_EP_RES;
+  return e.drop_p == 0.f ? SK_EP_BIAS : SK_EP_GENERIC;
+}
+template <typename C, bool FAST>
+static int launch_sk(const GemmParams& p, bool cut, hipStream_t st) {
+  if constexpr (FAST) {
+    switch (sk_ep_kind(p)) {
+      case SK_EP_BIAS: return launch_sk_ep<C, SK_EP_BIAS>(p, cut, st);
+      case SK_EP_GELU: return launch_sk_ep<C, SK_EP_GELU>(p, cut, st);
+      case SK_EP_RES: return launch_sk_ep<C, SK_EP_RES>(p, cut, st);
+      default: break;
+    }
+  }
+  return launch_sk_ep<C, SK_EP_GENERIC>(p, cut, st);
 }
 
 // ring depth: as many stages as fit, at most 6
@@ -451,11 +511,11 @@ static int g_sk_mode = -1;   // PENEO_GEMM_SK: 0 = off, 1 = auto (default), else
 template <int BN>
 static int launch_sk_f(const GemmParams& p, int F, bool cut, hipStream_t st) {
   switch (F) {
-    case 4: return launch_sk<typename SkPick<4, BN>::type>(p, cut, st);
-    case 5: return launch_sk<typename SkPick<5, BN>::type>(p, cut, st);
-    case 6: return launch_sk<typename SkPick<6, BN>::type>(p, cut, st);
-    case 7: if constexpr (BN == 128) return launch_sk<typename SkPick<7, BN>::type>(p, cut, st); else return 0;
-    case 8: if constexpr (BN == 128) return launch_sk<typename SkPick<8, BN>::type>(p, cut, st); else return 0;
+    case 4: return launch_sk<typename SkPick<4, BN>::type, BN == 256>(p, cut, st);
+    case 5: return launch_sk<typename SkPick<5, BN>::type, true>(p, cut, st);
+    case 6: return launch_sk<typename SkPick<6, BN>::type, false>(p, cut, st);
+    case 7: if constexpr (BN == 128) return launch_sk<typename SkPick<7, BN>::type, false>(p, cut, st); else return 0;
+    case 8: if constexpr (BN == 128) return launch_sk<typename SkPick<8, BN>::type, false>(p, cut, st); else return 0;
     default: return 0;
   }
 }
@@ -481,12 +541,13 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
   int mode = g_sk_mode;
   if (mode == 1) {
     // The choice per problem (profiles/r06_gemm_persistent.txt).  One workgroup per CU has nothing to overlap a tile's epilogue
-    // with (the C tiles of a round leave in one burst at ~3.5 TB/s), so at M = 5672 the launch only ties the tiled kernels
-    // (two workgroups per CU: one's epilogue under the other's k loop) and they keep those shapes.  Alone it wins on three kinds
-    // of problem -- many tiles per workgroup (-20 %), a tile of the family that fills one round (large-backbone QKV / FFN1: -11 /
-    // -24 %), few tiles x deep K as stream-k ranges (large-backbone FFN2: -30 %) -- but INSIDE the large backbone's forward the
-    // last two lose what they won alone (FFN1 44 us against 32 alone, with the GELU epilogue exposed; the tiled kernels run
-    // faster there than alone: 146 against 138 us of GEMM per layer), so only the first rule ships.
+    // with, so at M = 5672 (no tile of the family fills a whole number of rounds there) the launch only ties the tiled kernels
+    // and they keep those shapes.  It is picked for
+    //   (1) many tiles per workgroup (>= 3 rounds: the stream hides every prologue, epilogues drift apart);
+    //   (2) a tile of the family that fills ONE or TWO rounds to >= 90 % (the large backbone: QKV, FFN1, FFN2, out-proj);
+    //   (3) few tiles x deep K: stream-k ranges;
+    // (2) and (3) only with one of the compact epilogues - with the generic one (56 - 142 KB of code) they lost inside the
+    // large backbone's forward what they won alone.
     if ((int64_t)p.M * p.N < (int64_t)1 << 21 || p.M < 256 || p.N < 128) return 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -495,6 +556,20 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
     mode = 0;
     if (p.N >= 256 && tiles(4, 256) >= 3 * (int64_t)G) mode = 4256;
     else if (p.N < 256 && tiles(5, 128) >= 3 * (int64_t)G) mode = 5128;
+    else if (sk_ep_kind(p) != SK_EP_GENERIC) {
+      // (where one of gemm_big.hip's more intense tiles - 256 x 256, 384 x 192 - fills its rounds, that kernel stays: 4096^3 runs at
+      //  1146 TFLOP/s on 256 tiles of 256 x 256 against 1000 here)
+      auto fits = [&](int64_t t, int pct) { return (t <= G && t * 100 >= (int64_t)G * pct) || (t <= 2 * (int64_t)G && t * 100 >= 2 * (int64_t)G * pct); };
+      const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256), t384 = (int64_t)((p.M + 383) / 384) * ((p.N + 191) / 192);
+      const bool big_fits = fits(t256, 85) || fits(t384, 85);
+      const int cand[3][2] = {{5, 256}, {4, 256}, {5, 128}};            // most intense first
+      for (int c = 0; c < 3 && !mode && !big_fits; ++c)
+        for (int k = 1; k <= 2 && !mode; ++k) {
+          const int64_t t = tiles(cand[c][0], cand[c][1]);
+          if (p.N >= cand[c][1] && t <= (int64_t)k * G && t * 10 >= (int64_t)k * G * 9) mode = cand[c][0] * 1000 + cand[c][1];
+        }
+      if (!mode && p.K >= 2048 && tiles(5, 128) * 10 <= (int64_t)G * 6) mode = 105128;
+    }
     if (!mode) return 0;
   }
   const bool cut = mode >= 100000;

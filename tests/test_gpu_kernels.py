@@ -834,8 +834,11 @@ def test_gemm_stream_k_matches_fp32_matmul(ops, mode, bk):
                     o2 = ops.gemm(a, b, b_kmajor=bk, bias=bias, residual=res, drop_p=0.1, drop_seed=77, split_k=1)   # bias + dropout + residual
                     o3 = ops.gemm(a, b, b_kmajor=bk, grad_src=src, grad_act=2, split_k=1)                            # x SiLU'(src)
                     o4 = ops.gemm(a, b, b_kmajor=bk, out_dtype=torch.float32, split_k=1)
-                    outs[m_] = (pre, o1, o2, o3, o4)
-                pre, o1, o2, o3, o4 = outs[mode]
+                    o5 = ops.gemm(a, b, b_kmajor=bk, bias=bias, split_k=1)                                            # bias only (compact epilogue)
+                    o6 = ops.gemm(a, b, b_kmajor=bk, bias=bias, residual=res, split_k=1)                              # bias + residual, no dropout
+                    outs[m_] = (pre, o1, o2, o3, o4, o5, o6)
+                pre, o1, o2, o3, o4, o5, o6 = outs[mode]
+                assert rel_err(o5, z + bias) < 2e-2 and rel_err(o6, z + bias + res.float()) < 2e-2, (M, N, K, rep)
                 assert rel_err(pre, z + bias) < 2e-2 and rel_err(o1, F.gelu(z + bias)) < 2e-2, (M, N, K, rep)
                 sg = torch.sigmoid(src.float())
                 assert rel_err(o3, z * (sg * (1 + src.float() * (1 - sg)))) < 2e-2, (M, N, K, rep)
