@@ -514,7 +514,7 @@ static int launch_sk_f(const GemmParams& p, int F, bool cut, hipStream_t st) {
     case 4: return launch_sk<typename SkPick<4, BN>::type, BN == 256>(p, cut, st);
     case 5: return launch_sk<typename SkPick<5, BN>::type, true>(p, cut, st);
     case 6: return launch_sk<typename SkPick<6, BN>::type, false>(p, cut, st);
-    case 7: if constexpr (BN == 128) return launch_sk<typename SkPick<7, BN>::type, false>(p, cut, st); else return 0;
+    case 7: if constexpr (BN == 128) return launch_sk<typename SkPick<7, BN>::type, true>(p, cut, st); else return 0;
     case 8: if constexpr (BN == 128) return launch_sk<typename SkPick<8, BN>::type, false>(p, cut, st); else return 0;
     default: return 0;
   }
@@ -544,7 +544,8 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
     // with, so at M = 5672 (no tile of the family fills a whole number of rounds there) the launch only ties the tiled kernels
     // and they keep those shapes.  It is picked for
     //   (1) many tiles per workgroup (>= 3 rounds: the stream hides every prologue, epilogues drift apart);
-    //   (2) a tile of the family that fills ONE or TWO rounds to >= 90 % (the large backbone: QKV, FFN1, FFN2, out-proj);
+    //   (2) a tile of the family that fills ONE or TWO rounds to >= 84 % (the large backbone: QKV, FFN1, FFN2, out-proj; the base
+    //       backbone: QKV on 224 x 128 - 468 tiles, 33.5 against 36.5 us - and out-proj on 160 x 128 - 216 tiles, 15.5 against 17.6);
     //   (3) few tiles x deep K: stream-k ranges;
     // (2) and (3) only with one of the compact epilogues - with the generic one (56 - 142 KB of code) they lost inside the
     // large backbone's forward what they won alone.
@@ -562,11 +563,11 @@ int launch_gemm_sk(const GemmParams& p, bool b_kmajor, hipStream_t st) {
       auto fits = [&](int64_t t, int pct) { return (t <= G && t * 100 >= (int64_t)G * pct) || (t <= 2 * (int64_t)G && t * 100 >= 2 * (int64_t)G * pct); };
       const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256), t384 = (int64_t)((p.M + 383) / 384) * ((p.N + 191) / 192);
       const bool big_fits = fits(t256, 85) || fits(t384, 85);
-      const int cand[3][2] = {{5, 256}, {4, 256}, {5, 128}};            // most intense first
-      for (int c = 0; c < 3 && !mode && !big_fits; ++c)
+      const int cand[4][2] = {{5, 256}, {4, 256}, {7, 128}, {5, 128}};            // most intense first
+      for (int c = 0; c < 4 && !mode && !big_fits; ++c)
         for (int k = 1; k <= 2 && !mode; ++k) {
           const int64_t t = tiles(cand[c][0], cand[c][1]);
-          if (p.N >= cand[c][1] && t <= (int64_t)k * G && t * 10 >= (int64_t)k * G * 9) mode = cand[c][0] * 1000 + cand[c][1];
+          if (p.N >= cand[c][1] && t <= (int64_t)k * G && t * 100 >= (int64_t)k * G * 84) mode = cand[c][0] * 1000 + cand[c][1];
         }
       if (!mode && p.K >= 2048 && tiles(5, 128) * 10 <= (int64_t)G * 6) mode = 105128;
     }
