@@ -1,10 +1,10 @@
 // bf16 GEMM as ONE persistent launch: at most one 8-wave workgroup per CU, each walking a contiguous range of
 // (tile, k-stage) units -- whole tiles ("data-parallel") or ranges that cut tiles ("stream-k") (gfx950).
 //
-// What bounds a GEMM on this chip (profiles/r06_gemm_fill_model.txt): a CU turns global -> LDS requests into LDS lines at ~22
+// What bounds a GEMM on this chip (profiles/r06_gemm_persistent.txt, (b)): a CU turns global -> LDS requests into LDS lines at ~22
 // B/clk whatever the kernel (ours, the vendor library's, the guide's template), so a launch costs (bytes staged through LDS) /
 // (22 B/clk x CUs) when everything else hides under that stream, and the tiled kernels of gemm.hip / gemm_big.hip are far from
-// it on the model's M = 5672 problems: 17 us of a QKV-shaped launch sit before the first and after the last k-tile, the tile
+// it on the model's M = 5672 problems: 15 us of a QKV-shaped launch sit before the first and after the last k-tile, the tile
 // counts (270 / 414 / 552 / 810 on 256 CUs) quantise badly, and a two-stage ring lets the request queue run dry in every k-tile.
 // Here
 //   * the tile comes from a FAMILY -- M extent 32 F (F = 4..8: 128 .. 256 rows) x N extent 128, F = 4..6 x N extent 256 -- which
