@@ -854,6 +854,48 @@ def test_gemm_stream_k_matches_fp32_matmul(ops, mode, bk):
         lib.peneo_gemm_set_big_mode(1)
 
 
+def test_gemm_stream_k_hand_off_under_uneven_load(ops):
+    """The stream-k slab hand-off (write-through slab stores, vm drain, flag; relaxed poll + one agent-scope acquire; flags reset by
+    their consumer) checked the way the CDNA guide asks for: every word of every result, many launches in a row with fresh operands
+    (a stale flag or a stale slab of the launch before shows), and beside a second stream that keeps part of the CUs busy with long
+    workgroups, so that the ranges of a launch start at uneven times and a finisher meets slabs that are not there yet."""
+    import ctypes
+    from peneo_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    g = torch.Generator().manual_seed(99)
+    dt = torch.bfloat16
+    shapes = [(1500, 768, 3072), (2442, 1024, 4096), (777, 264, 1920), (5672, 768, 768)]
+    ops_ab = {}
+    for (M, N, K) in shapes:
+        ops_ab[(M, N, K)] = [((torch.randn(M, K, generator=g)).to(DEV).to(dt), (torch.randn(N, K, generator=g) * 0.05).to(DEV).to(dt),
+                              torch.randn(N, generator=g).to(DEV)) for _ in range(3)]
+    side = torch.cuda.Stream()
+    big_a = torch.randn(8192, 4096, generator=g).to(DEV).to(dt)
+    big_b = torch.randn(4096, 4096, generator=g).to(DEV).to(dt)
+    try:
+        refs = {}
+        lib.peneo_gemm_set_sk_mode(0)
+        for key, sets in ops_ab.items():
+            refs[key] = [ops.gemm(a, b, bias=bias, split_k=1).float() for a, b, bias in sets]
+        torch.cuda.synchronize()
+        bad = 0
+        for it in range(60):
+            if it % 4 == 0:
+                with torch.cuda.stream(side):               # long tiled workgroups on another queue: uneven CU availability
+                    lib.peneo_gemm_set_sk_mode(0)
+                    ops.gemm(big_a, big_b, split_k=1)
+            key = shapes[it % len(shapes)]
+            a, b, bias = ops_ab[key][it % 3]
+            lib.peneo_gemm_set_sk_mode(105128 if it % 2 == 0 else 104256)
+            out = ops.gemm(a, b, bias=bias, split_k=1)
+            err = rel_err(out, refs[key][it % 3])
+            bad += int(not (err < 1e-2))
+        torch.cuda.synchronize()
+        assert bad == 0, f"{bad} of 60 stream-k launches differ from the tiled kernel"
+    finally:
+        lib.peneo_gemm_set_sk_mode(1)
+
+
 def test_cast_multi_equals_single_casts(ops):
     """peneo_cast_multi (all weight copies of a step in one launch) == peneo_cast tensor by tensor, ragged sizes included."""
     g = torch.Generator().manual_seed(5)
